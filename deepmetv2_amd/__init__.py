@@ -1,0 +1,23 @@
+"""deepmetv2_amd -- MI355X-native operators for the DeepMETv2 DynamicEdgeConv -> MET hot path.
+
+Drop-in names (same spelling and argument meaning as the third-party operators the reference imports at
+/root/reference/model/graph_met_network.py:7,9, model/net.py:8, train.py:10):
+
+    from deepmetv2_amd import EdgeConv, DynamicEdgeConv      # torch_geometric.nn
+    from deepmetv2_amd import knn_graph, radius_graph, knn   # torch_cluster
+    from deepmetv2_amd import scatter_add, scatter_max       # torch_scatter
+
+All of them run hand-written HIP kernels for gfx950 through the C ABI in include/dmet.h
+(deepmetv2_amd/libdmet_hip.so, built by `python -m deepmetv2_amd.build`).  There is no CPU implementation:
+calling an operator without the library or with non-GPU tensors raises.
+"""
+from .cluster import knn, knn_graph, knn_table, radius_graph, radius_table
+from .conv import DynamicEdgeConv, EdgeConv
+from .graph import NeighborTable, register_batch
+from .scatter import met_reduce, scatter_add, scatter_max
+
+__all__ = [
+    "EdgeConv", "DynamicEdgeConv", "knn", "knn_graph", "knn_table", "radius_graph", "radius_table",
+    "scatter_add", "scatter_max", "met_reduce", "NeighborTable", "register_batch",
+]
+__version__ = "0.1.0"

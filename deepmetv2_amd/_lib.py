@@ -1,0 +1,75 @@
+"""ctypes binding of libdmet_hip.so (the C ABI declared in include/dmet.h).
+
+There is NO CPU fallback: if the shared library is missing or no ROCm device tensor is supplied the ops raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libdmet_hip.so")
+
+_lock = threading.Lock()
+_lib = None
+
+_vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+
+# name -> (restype, argtypes); must list every symbol declared in include/dmet.h
+SIGNATURES = {
+    "dmet_version": (_i, []),
+    "dmet_last_error": (C.c_char_p, []),
+    "dmet_device_available": (_i, []),
+    "dmet_knn_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
+    "dmet_knn_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "dmet_radius_f32": (_i, [_vp, _vp, _i, _i64, _i, _f, _i, _vp, _vp, _vp]),
+    "dmet_edgeconv_linear_workspace_bytes": (_sz, [_i64, _i]),
+    "dmet_edgeconv_linear_max_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dmet_node_linear_split_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dmet_gather_max_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
+    "dmet_gather_max_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
+    "dmet_reverse_index_workspace_bytes": (_sz, [_i64, _i64]),
+    "dmet_reverse_index": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "dmet_edge_features_f32": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    "dmet_segment_max_f32": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    "dmet_segment_sum_f32": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "dmet_segment_max_bwd_f32": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    "dmet_segment_sum_bwd_f32": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
+    "dmet_edge_features_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp, _vp]),
+    "dmet_met_reduce_f32": (_i, [_vp, _vp, _i64, _vp, _i, _vp, _vp]),
+    "dmet_met_reduce_bwd_f32": (_i, [_vp, _vp, _i64, _vp, _i, _i64, _vp, _vp]),
+    "dmet_segment_sum_1d_f32": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "dmet_batch_to_ptr": (_i, [_vp, _i64, _i, _vp, _vp]),
+}
+
+
+class DmetLibraryError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libdmet_hip.so (built by `python -m deepmetv2_amd.build` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise DmetLibraryError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m deepmetv2_amd.build` "
+                "(needs hipcc; gfx950). deepmetv2_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here means header and library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().dmet_last_error()
+        raise RuntimeError(f"{what or 'dmet call'} failed (rc={rc}): {msg.decode(errors='replace') if msg else ''}")

@@ -1,0 +1,268 @@
+"""Tensor-level wrappers over the C ABI: validate, allocate outputs / workspace from torch's caching allocator,
+enqueue on the current HIP stream.  PyTorch is used here for device memory and streams only.
+
+Every function requires ROCm device tensors and raises otherwise -- there is no CPU path in the product.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _require_device(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if t.device.type != "cuda":
+            raise RuntimeError(
+                "deepmetv2_amd: operator called with a non-GPU tensor. The HIP extension is the only "
+                "implementation (no CPU fallback); move inputs to a ROCm device.")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("deepmetv2_amd: all tensors must live on the same device")
+    return dev
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(nbytes: int, dev: torch.device) -> torch.Tensor:
+    return torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=dev)
+
+
+# ---- K1 ------------------------------------------------------------------------------------------------------
+def knn(x: torch.Tensor, ptr: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """nbr[N,k] int32 (global ids, -1 padded), dist[N,k] fp32."""
+    dev = _require_device(x, ptr)
+    L = _lib.load()
+    x = _f32c(x.detach(), "x")
+    if x.dim() != 2:
+        raise ValueError(f"x must be 2-D [N, D], got {tuple(x.shape)}")
+    N, D = x.shape
+    B = ptr.numel() - 1
+    nbr = torch.empty((N, k), dtype=torch.int32, device=dev)
+    dist = torch.empty((N, k), dtype=torch.float32, device=dev)
+    nb = L.dmet_knn_workspace_bytes(N, B, D, k)
+    ws = _ws(nb, dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_knn_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, k, nbr.data_ptr(), dist.data_ptr(),
+                                  ws.data_ptr(), ws.numel(), _stream(dev)), "dmet_knn_f32")
+    return nbr, dist
+
+
+def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    dev = _require_device(x, ptr)
+    L = _lib.load()
+    x = _f32c(x.detach(), "x")
+    N, D = x.shape
+    B = ptr.numel() - 1
+    nbr = torch.empty((N, max_nbr), dtype=torch.int32, device=dev)
+    cnt = torch.empty((N,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_radius_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, float(r), max_nbr, nbr.data_ptr(),
+                                     cnt.data_ptr(), _stream(dev)), "dmet_radius_f32")
+    return nbr, cnt
+
+
+# ---- K2+K3 fused -----------------------------------------------------------------------------------------------
+def node_linear_split(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    dev = _require_device(x, W, b)
+    L = _lib.load()
+    x = _f32c(x, "x"); W = _f32c(W, "W")
+    N, Hin = x.shape
+    Hout = W.shape[0]
+    if W.shape[1] != 2 * Hin:
+        raise ValueError(f"W must be [Hout, 2*Hin] = [*, {2 * Hin}], got {tuple(W.shape)}")
+    PQ = torch.empty((2, N, Hout), dtype=torch.float32, device=dev)
+    bp = _f32c(b, "b").data_ptr() if b is not None else None
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_node_linear_split_f32(x.data_ptr(), N, Hin, Hout, W.data_ptr(), bp, PQ[0].data_ptr(),
+                                                PQ[1].data_ptr(), _stream(dev)), "dmet_node_linear_split_f32")
+    return PQ[0], PQ[1]
+
+
+def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optional[torch.Tensor],
+               want_arg: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    dev = _require_device(P, Q, nbr)
+    L = _lib.load()
+    N, H = P.shape
+    k = nbr.shape[1]
+    out = torch.empty((N, H), dtype=torch.float32, device=dev)
+    arg = torch.empty((N, H), dtype=torch.uint8, device=dev) if want_arg else None
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_gather_max_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(),
+                                         ptr.data_ptr() if ptr is not None else None,
+                                         (ptr.numel() - 1) if ptr is not None else 0, N, k, H, out.data_ptr(),
+                                         arg.data_ptr() if want_arg else None, _stream(dev)), "dmet_gather_max_f32")
+    return out, arg
+
+
+def gather_max_bwd(g_out: torch.Tensor, arg: torch.Tensor, rev_ptr: torch.Tensor, rev_slot: torch.Tensor,
+                   k: int) -> torch.Tensor:
+    dev = _require_device(g_out, arg, rev_ptr, rev_slot)
+    L = _lib.load()
+    g_out = _f32c(g_out, "g_out")
+    N, H = g_out.shape
+    gQ = torch.empty((N, H), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_gather_max_bwd_f32(g_out.data_ptr(), arg.data_ptr(), rev_ptr.data_ptr(),
+                                             rev_slot.data_ptr(), N, k, H, gQ.data_ptr(), _stream(dev)),
+                   "dmet_gather_max_bwd_f32")
+    return gQ
+
+
+def reverse_index(keys: torch.Tensor, num_keys: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Stable sort of positions by int32 key: rev_ptr[num_keys+1] int32, rev_pos[M] int32 (see include/dmet.h)."""
+    dev = _require_device(keys)
+    L = _lib.load()
+    if keys.dtype != torch.int32 or not keys.is_contiguous():
+        raise TypeError("keys must be a contiguous int32 tensor")
+    M = keys.numel()
+    rev_ptr = torch.empty((num_keys + 1,), dtype=torch.int32, device=dev)
+    rev_pos = torch.empty((max(M, 1),), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _ws(L.dmet_reverse_index_workspace_bytes(M, num_keys), dev)
+        _lib.check(L.dmet_reverse_index(keys.data_ptr(), M, num_keys, rev_ptr.data_ptr(), rev_pos.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), _stream(dev)), "dmet_reverse_index")
+    return rev_ptr, rev_pos
+
+
+# ---- K2 / K3 un-fused ------------------------------------------------------------------------------------------
+def edge_features(x: torch.Tensor, src: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
+    dev = _require_device(x, src, tgt)
+    L = _lib.load()
+    x = _f32c(x, "x")
+    E = src.numel()
+    H = x.shape[1]
+    feat = torch.empty((E, 2 * H), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_edge_features_f32(x.data_ptr(), src.data_ptr(), tgt.data_ptr(), E, H, feat.data_ptr(),
+                                            _stream(dev)), "dmet_edge_features_f32")
+    return feat
+
+
+def edge_features_bwd(g_feat: torch.Tensor, rowptr: torch.Tensor, srcptr: torch.Tensor, srcperm: torch.Tensor,
+                      N: int, H: int) -> torch.Tensor:
+    dev = _require_device(g_feat, rowptr, srcptr, srcperm)
+    L = _lib.load()
+    g_feat = _f32c(g_feat, "g_feat")
+    gx = torch.empty((N, H), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_edge_features_bwd_f32(g_feat.data_ptr(), rowptr.data_ptr(), srcptr.data_ptr(),
+                                                srcperm.data_ptr(), N, H, gx.data_ptr(), _stream(dev)),
+                   "dmet_edge_features_bwd_f32")
+    return gx
+
+
+def segment_max(msg: torch.Tensor, rowptr: torch.Tensor, N: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    dev = _require_device(msg, rowptr)
+    L = _lib.load()
+    msg = _f32c(msg, "msg")
+    H = msg.shape[1]
+    out = torch.empty((N, H), dtype=torch.float32, device=dev)
+    arg = torch.empty((N, H), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_segment_max_f32(msg.data_ptr(), rowptr.data_ptr(), N, H, out.data_ptr(), arg.data_ptr(),
+                                          _stream(dev)), "dmet_segment_max_f32")
+    return out, arg
+
+
+def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, N: int) -> torch.Tensor:
+    dev = _require_device(msg, rowptr)
+    L = _lib.load()
+    msg = _f32c(msg, "msg")
+    H = msg.shape[1]
+    out = torch.empty((N, H), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_segment_sum_f32(msg.data_ptr(), rowptr.data_ptr(), N, H, out.data_ptr(), _stream(dev)),
+                   "dmet_segment_sum_f32")
+    return out
+
+
+def segment_max_bwd(g_out: torch.Tensor, arg: torch.Tensor, rowptr: torch.Tensor, E: int) -> torch.Tensor:
+    dev = _require_device(g_out, arg, rowptr)
+    L = _lib.load()
+    g_out = _f32c(g_out, "g_out")
+    N, H = g_out.shape
+    g_msg = torch.empty((E, H), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_segment_max_bwd_f32(g_out.data_ptr(), arg.data_ptr(), rowptr.data_ptr(), N, H,
+                                              g_msg.data_ptr(), _stream(dev)), "dmet_segment_max_bwd_f32")
+    return g_msg
+
+
+def segment_sum_bwd(g_out: torch.Tensor, rowptr: torch.Tensor, E: int) -> torch.Tensor:
+    dev = _require_device(g_out, rowptr)
+    L = _lib.load()
+    g_out = _f32c(g_out, "g_out")
+    N, H = g_out.shape
+    g_msg = torch.empty((E, H), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_segment_sum_bwd_f32(g_out.data_ptr(), rowptr.data_ptr(), N, H, g_msg.data_ptr(),
+                                              _stream(dev)), "dmet_segment_sum_bwd_f32")
+    return g_msg
+
+
+# ---- K4 --------------------------------------------------------------------------------------------------------
+def met_reduce(w: torch.Tensor, x: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:
+    dev = _require_device(w, x, ptr)
+    L = _lib.load()
+    w = _f32c(w, "w")
+    if x.dtype != torch.float32 or x.dim() != 2 or x.stride(1) != 1:
+        raise TypeError("x must be float32 [N, F>=2] with unit inner stride")
+    B = ptr.numel() - 1
+    met = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_met_reduce_f32(w.data_ptr(), x.data_ptr(), x.stride(0), ptr.data_ptr(), B, met.data_ptr(),
+                                         _stream(dev)), "dmet_met_reduce_f32")
+    return met
+
+
+def met_reduce_bwd(g_met: torch.Tensor, x: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:
+    dev = _require_device(g_met, x, ptr)
+    L = _lib.load()
+    g_met = _f32c(g_met, "g_met")
+    N = x.shape[0]
+    B = ptr.numel() - 1
+    g_w = torch.empty((N,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_met_reduce_bwd_f32(g_met.data_ptr(), x.data_ptr(), x.stride(0), ptr.data_ptr(), B, N,
+                                             g_w.data_ptr(), _stream(dev)), "dmet_met_reduce_bwd_f32")
+    return g_w
+
+
+def segment_sum_1d(src: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:
+    dev = _require_device(src, ptr)
+    L = _lib.load()
+    src = _f32c(src, "src")
+    B = ptr.numel() - 1
+    out = torch.empty((B,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_segment_sum_1d_f32(src.data_ptr(), ptr.data_ptr(), B, out.data_ptr(), _stream(dev)),
+                   "dmet_segment_sum_1d_f32")
+    return out
+
+
+def batch_to_ptr(batch: torch.Tensor, B: int) -> torch.Tensor:
+    dev = _require_device(batch)
+    L = _lib.load()
+    if batch.dtype != torch.int64:
+        batch = batch.to(torch.int64)
+    batch = batch.contiguous()
+    ptr = torch.empty((B + 1,), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_batch_to_ptr(batch.data_ptr(), batch.numel(), B, ptr.data_ptr(), _stream(dev)),
+                   "dmet_batch_to_ptr")
+    return ptr

@@ -1,0 +1,95 @@
+"""Graph builders with the torch_cluster signatures (`knn`, `knn_graph`, `radius_graph`).
+
+Reference call sites (relative to /root/reference): model/graph_met_network.py:63 and
+model/dynamic_reduction_network.py:86,94 (knn_graph); train.py:48, evaluate.py:88, plt_weight.py:122
+(radius_graph).  The kernels are in csrc/knn.hip; this file is argument checking and the int64 `edge_index` view.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _native
+from .graph import NeighborTable, batch_info
+
+MAX_K = 64  # DMET_MAX_K
+
+
+def _check_x(x: torch.Tensor) -> torch.Tensor:
+    if x.dim() == 1:
+        x = x.view(-1, 1)
+    if x.dim() != 2:
+        raise ValueError(f"x must be [N, D], got {tuple(x.shape)}")
+    if x.dtype != torch.float32:
+        raise TypeError(f"x must be float32, got {x.dtype} (kNN distances are defined in fp32, rule R1)")
+    return x
+
+
+def knn_table(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loop: bool = True,
+              num_events: Optional[int] = None) -> NeighborTable:
+    """Fixed-width neighbour table for `x` (row i = the message sources of node i).  loop=False searches k+1
+    and blanks j == i, exactly like upstream's `row != col` mask (a node whose k+1 nearest do not include itself,
+    possible only with >= k+1 duplicates at lower index, keeps all k+1)."""
+    x = _check_x(x)
+    if not isinstance(k, int) or k < 1:
+        raise ValueError(f"k must be a positive int, got {k!r}")
+    kk = k if loop else k + 1
+    if kk > MAX_K:
+        raise ValueError(f"k={k} (searching {kk}) exceeds the supported maximum {MAX_K}")
+    info = batch_info(batch, x.shape[0], x.device, num_events)
+    nbr, dist = _native.knn(x, info.ptr, kk)
+    # dense <=> no -1 entry: needs every event to have >= kk nodes; unknown without a sync, so only the
+    # no-batch single-event case and registered batches with known sizes could claim it.  Stay conservative.
+    dense = False
+    if not loop:
+        self_id = torch.arange(x.shape[0], dtype=torch.int32, device=x.device).view(-1, 1)
+        nbr = torch.where(nbr == self_id, torch.full_like(nbr, -1), nbr)
+    return NeighborTable(nbr, info.ptr, dense=dense, dist=dist)
+
+
+def knn_graph(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loop: bool = False,
+              flow: str = "source_to_target", cosine: bool = False, num_workers: int = 1,
+              batch_size: Optional[int] = None) -> torch.Tensor:
+    """torch_cluster.knn_graph: edge_index[2,E] int64; [0] = neighbour j, [1] = centre i for
+    flow='source_to_target'; edges grouped by ascending i, ascending (distance, j) inside a group."""
+    if cosine:
+        raise NotImplementedError("cosine=True is not on the DeepMETv2 hot path")
+    if flow not in ("source_to_target", "target_to_source"):
+        raise ValueError(f"flow must be 'source_to_target' or 'target_to_source', got {flow!r}")
+    table = knn_table(x, k, batch, loop=loop, num_events=batch_size)
+    return table.edge_index(flow)
+
+
+def knn(x: torch.Tensor, y: torch.Tensor, k: int, batch_x: Optional[torch.Tensor] = None,
+        batch_y: Optional[torch.Tensor] = None, cosine: bool = False, num_workers: int = 1) -> torch.Tensor:
+    """torch_cluster.knn restricted to the self-query form (y is x) that DynamicEdgeConv uses:
+    returns [2,E] with row 0 = query index, row 1 = neighbour index."""
+    if cosine:
+        raise NotImplementedError("cosine=True is not on the DeepMETv2 hot path")
+    if y is not x or (batch_y is not batch_x):
+        raise NotImplementedError("knn(x, y): only the self-query form y is x is implemented (DynamicEdgeConv)")
+    return knn_table(x, k, batch_x, loop=True).edge_index("target_to_source")
+
+
+def radius_table(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None, loop: bool = False,
+                 max_num_neighbors: int = 32, num_events: Optional[int] = None) -> NeighborTable:
+    x = _check_x(x)
+    if x.shape[1] > 8:
+        raise ValueError("radius_graph supports up to 8 coordinates")
+    m = max_num_neighbors if loop else max_num_neighbors + 1
+    info = batch_info(batch, x.shape[0], x.device, num_events)
+    nbr, _cnt = _native.radius(x, info.ptr, r, m)
+    if not loop:
+        self_id = torch.arange(x.shape[0], dtype=torch.int32, device=x.device).view(-1, 1)
+        nbr = torch.where(nbr == self_id, torch.full_like(nbr, -1), nbr)
+    return NeighborTable(nbr, info.ptr, dense=False)
+
+
+def radius_graph(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None, loop: bool = False,
+                 max_num_neighbors: int = 32, flow: str = "source_to_target", num_workers: int = 1,
+                 batch_size: Optional[int] = None) -> torch.Tensor:
+    """torch_cluster.radius_graph (train.py:48 passes r=0.4, loop=True, max_num_neighbors=255)."""
+    if flow not in ("source_to_target", "target_to_source"):
+        raise ValueError(f"flow must be 'source_to_target' or 'target_to_source', got {flow!r}")
+    return radius_table(x, r, batch, loop, max_num_neighbors, batch_size).edge_index(flow)

@@ -1,0 +1,211 @@
+"""EdgeConv / DynamicEdgeConv with the torch_geometric.nn signatures, backed by the HIP kernels.
+
+Reference: `EdgeConv(nn=mesg).jittable()` constructed at /root/reference/model/graph_met_network.py:36-38 and called
+at :65 (`co_conv[0](emb, edge_index)`); the dynamic-kNN alternative the north star targets is the commented line
+:63.  `EdgeConv(nn=convnn, aggr=aggr)` with a multi-layer `nn` and a `.flow` read at
+model/dynamic_reduction_network.py:72-73,86.
+
+The operators own NO parameters or buffers: `nn` is the caller's module and keeps the attribute name `.nn`, so
+`state_dict` keys such as `graphnet.conv_continuous.0.0.nn.0.weight` (shipped checkpoints) load unchanged.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple, Union
+
+import torch
+
+from . import _native
+from .cluster import knn_table
+from .graph import EdgeList, NeighborTable, edge_list_from_edge_index, lookup_graph
+from .scatter import _SegmentMaxRows, _SegmentSumRows
+
+_FUSED_WIDTHS = (32, 64)
+
+
+def _reset(nn_module) -> None:
+    """torch_geometric.nn.inits.reset restated: recurse and call reset_parameters where it exists."""
+    if hasattr(nn_module, "reset_parameters"):
+        nn_module.reset_parameters()
+    elif hasattr(nn_module, "children"):
+        for child in nn_module.children():
+            _reset(child)
+
+
+def _as_fusable_linear(nn_module) -> Optional[torch.nn.Linear]:
+    """`nn` is exactly one Linear(2H -> H') (bare or inside a one-element Sequential), as in
+    model/graph_met_network.py:36: then message+max collapses to the per-node split (csrc/edgeconv.hip)."""
+    lin = None
+    if isinstance(nn_module, torch.nn.Linear):
+        lin = nn_module
+    elif isinstance(nn_module, torch.nn.Sequential) and len(nn_module) == 1 and isinstance(nn_module[0], torch.nn.Linear):
+        lin = nn_module[0]
+    if lin is None or lin.in_features % 2:
+        return None
+    if lin.in_features // 2 not in _FUSED_WIDTHS or lin.out_features not in _FUSED_WIDTHS:
+        return None
+    if lin.weight.dtype != torch.float32:
+        return None
+    return lin
+
+
+class _EdgeConvLinearMax(torch.autograd.Function):
+    """out[i] = max_s (W.[x_i || x_j - x_i] + b), j = nbr[i,s], through P = x.(W1-W2)^T + b, Q = x.W2^T."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, table: NeighborTable):
+        need_grad = any(ctx.needs_input_grad[:3])
+        P, Q = _native.node_linear_split(x, weight, bias)
+        out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad)
+        if need_grad:
+            ctx.save_for_backward(x, weight, arg)
+            ctx.table = table
+            ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, weight, arg = ctx.saved_tensors
+        table: NeighborTable = ctx.table
+        H = x.shape[1]
+        g_out = g_out.contiguous()
+        rev_ptr, rev_pos = table.reverse()
+        gQ = _native.gather_max_bwd(g_out, arg, rev_ptr, rev_pos, table.k)
+        # nodes without any neighbour produced 0 (R3): no gradient reaches P there
+        gP = g_out if table.dense else g_out * (arg != 255).to(g_out.dtype)
+        Wd = weight[:, :H] - weight[:, H:]
+        W2 = weight[:, H:]
+        gx = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.addmm(gP @ Wd, gQ, W2)
+        if ctx.needs_input_grad[1]:
+            gWd = gP.t() @ x
+            gW2 = gQ.t() @ x
+            gW = torch.cat([gWd, gW2 - gWd], dim=1)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gP.sum(0)
+        return gx, gW, gb, None
+
+
+class _EdgeFeatures(torch.autograd.Function):
+    """feat[e] = [x[tgt] || x[src] - x[tgt]] for a by-target grouped edge list."""
+
+    @staticmethod
+    def forward(ctx, x, edges: EdgeList):
+        ctx.edges = edges
+        ctx.shape = x.shape
+        return _native.edge_features(x, edges.src, edges.tgt)
+
+    @staticmethod
+    def backward(ctx, g_feat):
+        edges: EdgeList = ctx.edges
+        srcptr, srcperm = edges.by_source()
+        N, H = ctx.shape
+        return _native.edge_features_bwd(g_feat.contiguous(), edges.rowptr, srcptr, srcperm, N, H), None
+
+
+class EdgeConv(torch.nn.Module):
+    r"""torch_geometric.nn.EdgeConv: :math:`x_i' = \mathrm{aggr}_{j \in N(i)} \; nn([x_i \,\|\, x_j - x_i])`.
+
+    Args mirror PyG: ``nn`` (any callable mapping [*, 2F_in] -> [*, F_out]), ``aggr`` in {'max','add','sum','mean'},
+    ``flow`` keyword.  ``forward(x, edge_index)`` takes a [N,F] tensor (or a pair of identical tensors) and an int64
+    [2,E] edge index.
+    """
+
+    def __init__(self, nn: Callable, aggr: str = "max", **kwargs):
+        super().__init__()
+        flow = kwargs.pop("flow", "source_to_target")
+        kwargs.pop("node_dim", None)
+        if kwargs:
+            raise TypeError(f"unexpected keyword arguments {sorted(kwargs)}")
+        if aggr not in ("max", "add", "sum", "mean"):
+            raise ValueError(f"unsupported aggr {aggr!r}")
+        if flow not in ("source_to_target", "target_to_source"):
+            raise ValueError(f"unsupported flow {flow!r}")
+        self.nn = nn
+        self.aggr = aggr
+        self.flow = flow
+        self.node_dim = 0
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        _reset(self.nn)
+
+    def jittable(self, typing: Optional[str] = None) -> "EdgeConv":
+        """PyG <= 2.4 API (model/graph_met_network.py:38 calls it): nothing to specialise here."""
+        return self
+
+    def message(self, x_i: torch.Tensor, x_j: torch.Tensor) -> torch.Tensor:
+        return self.nn(torch.cat([x_i, x_j - x_i], dim=-1))
+
+    # -- the two execution paths ---------------------------------------------------------------------------
+    def _forward_table(self, x: torch.Tensor, table: NeighborTable) -> torch.Tensor:
+        lin = _as_fusable_linear(self.nn) if self.aggr == "max" else None
+        if lin is not None and x.shape[1] * 2 == lin.in_features:
+            return _EdgeConvLinearMax.apply(x, lin.weight, lin.bias, table)
+        return self._forward_edges(x, table.edge_list())
+
+    def _forward_edges(self, x: torch.Tensor, edges: EdgeList) -> torch.Tensor:
+        N = x.shape[0]
+        if edges.num_edges == 0:
+            probe = self.nn(x.new_zeros((1, 2 * x.shape[1])))
+            return x.new_zeros((N, probe.shape[-1]))
+        feat = _EdgeFeatures.apply(x, edges)
+        msg = self.nn(feat)
+        if msg.dim() != 2 or msg.shape[0] != edges.num_edges:
+            raise ValueError("nn must map [E, 2F] -> [E, F_out]")
+        msg = msg.contiguous()
+        if self.aggr == "max":
+            out, _arg = _SegmentMaxRows.apply(msg, edges.rowptr, N)
+            return out
+        out = _SegmentSumRows.apply(msg, edges.rowptr, N)
+        if self.aggr == "mean":
+            deg = (edges.rowptr[1:] - edges.rowptr[:-1]).clamp(min=1).to(out.dtype).view(-1, 1)
+            out = out / deg
+        return out
+
+    def forward(self, x: Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]], edge_index: torch.Tensor) -> torch.Tensor:
+        if isinstance(x, (tuple, list)):
+            if x[1] is not None and x[1] is not x[0]:
+                raise NotImplementedError("bipartite EdgeConv (x_src is not x_dst) is outside the hot path")
+            x = x[0]
+        if x.dim() != 2:
+            raise ValueError(f"x must be [N, F], got {tuple(x.shape)}")
+        if x.dtype != torch.float32:
+            raise TypeError(f"x must be float32, got {x.dtype}")
+        hit = lookup_graph(edge_index)
+        if hit is not None and hit[1] == self.flow and hit[0].num_nodes == x.shape[0]:
+            return self._forward_table(x, hit[0])
+        return self._forward_edges(x, edge_list_from_edge_index(edge_index, x.shape[0], self.flow))
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}(nn={self.nn})"
+
+
+class DynamicEdgeConv(EdgeConv):
+    r"""torch_geometric.nn.DynamicEdgeConv: the graph is the k nearest neighbours of every node in the CURRENT
+    feature space (self included), rebuilt on every call: ``knn(x, x, k, batch, batch).flip(0)`` upstream."""
+
+    def __init__(self, nn: Callable, k: int, aggr: str = "max", num_workers: int = 1, **kwargs):
+        super().__init__(nn=nn, aggr=aggr, **kwargs)
+        if not isinstance(k, int) or k < 1:
+            raise ValueError(f"k must be a positive int, got {k!r}")
+        self.k = k
+        self.num_workers = num_workers
+
+    def forward(self, x: Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]],
+                batch: Union[None, torch.Tensor, Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+        if isinstance(x, (tuple, list)):
+            if x[1] is not None and x[1] is not x[0]:
+                raise NotImplementedError("bipartite DynamicEdgeConv is outside the hot path")
+            x = x[0]
+        if isinstance(batch, (tuple, list)):
+            batch = batch[0]
+        if x.dim() != 2:
+            raise ValueError("Static graphs not supported in DynamicEdgeConv")  # upstream's message
+        if x.dtype != torch.float32:
+            raise TypeError(f"x must be float32, got {x.dtype}")
+        table = knn_table(x, self.k, batch, loop=True)
+        return self._forward_table(x, table)
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}(nn={self.nn}, k={self.k})"

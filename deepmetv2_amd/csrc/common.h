@@ -1,0 +1,55 @@
+// common.h -- shared helpers of libdmet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dmet.h"
+
+namespace dmet {
+
+constexpr int kWave = 64;        // CDNA wavefront
+constexpr int kNumXcd = 8;       // MI355X: 8 XCDs, blocks are dealt round-robin over them
+constexpr float kKnnSentinel = 1e10f;  // upstream torch_cluster initial best distance
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what);
+
+#define DMET_REQUIRE(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            ::dmet::set_error(__VA_ARGS__);     \
+            return -22;                         \
+        }                                       \
+    } while (0)
+
+#define DMET_LAUNCH_CHECK(name)                                   \
+    do {                                                          \
+        hipError_t e__ = hipGetLastError();                       \
+        if (e__ != hipSuccess) return ::dmet::hip_fail(e__, name); \
+    } while (0)
+
+static inline hipStream_t as_stream(dmet_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Event that owns node i: the b with ptr[b] <= i < ptr[b+1] (empty events are skipped naturally).
+__device__ __forceinline__ int find_event(const int64_t *__restrict__ ptr, int B, int64_t i)
+{
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ptr[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+}  // namespace dmet

@@ -1,0 +1,458 @@
+// edgeconv.hip -- K2/K3: EdgeConv message + aggregation kernels (gfx950).
+//
+// Replaces torch_geometric.nn.EdgeConv.forward = MessagePassing.propagate -> index_select x2 -> cat -> nn ->
+// torch_scatter.scatter(max)   (constructed /root/reference/model/graph_met_network.py:36-38, invoked :65/:63).
+//
+// Fused path (nn == Linear(2H -> H), aggr == 'max', fixed-width neighbour table):
+//     W.[x_i || x_j - x_i] + b  ==  (W1 - W2).x_i + b  +  W2.x_j          (exact algebra; fp32 reassociation only)
+//   node_linear_split : P = x.(W1-W2)^T + b, Q = x.W2^T   per NODE, on the fp32 matrix cores
+//                       (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fmaf chain) -- 16x fewer flops than per edge
+//   gather_max        : out[i] = P[i] + max_s Q[nbr[i,s]]  -- the HBM/L2-bound "gather + scatter_max" kernel
+// Un-fused path (arbitrary nn / arbitrary edge list): edge_features -> user nn -> segment_max / segment_sum.
+#include "common.h"
+
+namespace dmet {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------------
+// node_linear_split: one wavefront computes [32 nodes] x [HOUT] for both P and Q with 32x32x2 fp32 MFMAs.
+// MFMA operand maps (32x32x2): lane l holds A[row l&31][k l>>5], B[k l>>5][col l&31];
+// C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// k-step s, half h  <->  input feature f = s + (HIN/2)*h, so a lane reads HIN/2 CONTIGUOUS floats of its node row.
+// ---------------------------------------------------------------------------------------------------------
+template <int HIN, int HOUT>
+__global__ __launch_bounds__(256) void node_linear_split_kernel(const float *__restrict__ x, int64_t N,
+                                                                 const float *__restrict__ W,
+                                                                 const float *__restrict__ bias,
+                                                                 float *__restrict__ P, float *__restrict__ Q)
+{
+    constexpr int KS = HIN / 2;     // k-steps
+    constexpr int JT = HOUT / 32;   // output column tiles
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t ntiles = (N + 31) / 32;
+
+    // B operands: column j = jt*32 + r of (W1-W2)^T and W2^T for feature f = s + KS*h
+    float wd[JT][KS], w2[JT][KS], bj[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        const float *wrow = W + (int64_t)(jt * 32 + r) * (2 * HIN);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float a = wrow[s + KS * h];
+            const float b2 = wrow[HIN + s + KS * h];
+            wd[jt][s] = a - b2;
+            w2[jt][s] = b2;
+        }
+        bj[jt] = bias ? bias[jt * 32 + r] : 0.0f;
+    }
+
+    for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+        const int64_t node = tile * 32 + r;
+        const int64_t nload = node < N ? node : N - 1;
+        float a[KS];
+        const float4 *src = reinterpret_cast<const float4 *>(x + nload * HIN + KS * h);
+#pragma unroll
+        for (int s = 0; s < KS; s += 4) {
+            const float4 v = src[s / 4];
+            a[s] = v.x; a[s + 1] = v.y; a[s + 2] = v.z; a[s + 3] = v.w;
+        }
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            f32x16 accP, accQ;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { accP[e] = bj[jt]; accQ[e] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                accP = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wd[jt][s], accP, 0, 0, 0);
+                accQ = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w2[jt][s], accQ, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int64_t n = tile * 32 + row;
+                if (n < N) {
+                    P[n * HOUT + jt * 32 + r] = accP[e];
+                    Q[n * HOUT + jt * 32 + r] = accQ[e];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// gather_max (L2-gather form): H/4 lanes per node, each lane owns 4 channels; neighbours' Q rows come from the
+// XCD's L2 (block ids are remapped so one XCD works on a contiguous window of events at a time).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int xcd_swizzle(int bid, int nblk)
+{
+    // bijective remap: blocks sharing an XCD (bid % 8) get one contiguous chunk of the grid
+    const int q = nblk / kNumXcd, rm = nblk % kNumXcd;
+    const int xcd = bid % kNumXcd, idx = bid / kNumXcd;
+    const int base = (xcd < rm) ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q;
+    return base + idx;
+}
+
+template <int H, bool WITH_ARG>
+__global__ __launch_bounds__(256) void gather_max_kernel(const float *__restrict__ P, const float *__restrict__ Q,
+                                                          const int32_t *__restrict__ nbr, int64_t N, int k,
+                                                          float *__restrict__ out, uint8_t *__restrict__ arg)
+{
+    constexpr int LPN = H / 4;               // lanes per node
+    constexpr int NPB = 256 / LPN;           // nodes per block
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int64_t node = (int64_t)bid * NPB + threadIdx.x / LPN;
+    const int c4 = threadIdx.x % LPN;
+    if (node >= N) return;
+    const int32_t *row = nbr + node * k;
+    const float4 *Q4 = reinterpret_cast<const float4 *>(Q);
+    const float ninf = -__builtin_inff();
+    float4 best = make_float4(ninf, ninf, ninf, ninf);
+    int a0 = 255, a1 = 255, a2 = 255, a3 = 255;
+    bool any = false;
+    for (int s0 = 0; s0 < k; s0 += 4) {
+        int32_t j[4];
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) j[u] = (s0 + u < k) ? row[s0 + u] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = (j[u] >= 0) ? Q4[(int64_t)j[u] * LPN + c4] : make_float4(ninf, ninf, ninf, ninf);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            any = any || (j[u] >= 0);
+            if (v[u].x > best.x) { best.x = v[u].x; a0 = s0 + u; }
+            if (v[u].y > best.y) { best.y = v[u].y; a1 = s0 + u; }
+            if (v[u].z > best.z) { best.z = v[u].z; a2 = s0 + u; }
+            if (v[u].w > best.w) { best.w = v[u].w; a3 = s0 + u; }
+        }
+    }
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (any) {
+        const float4 p = reinterpret_cast<const float4 *>(P)[node * LPN + c4];
+        o = make_float4(p.x + best.x, p.y + best.y, p.z + best.z, p.w + best.w);
+    }
+    reinterpret_cast<float4 *>(out)[node * LPN + c4] = o;
+    if (WITH_ARG) {
+        uchar4 a = make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
+        if (!any) a = make_uchar4(255, 255, 255, 255);
+        reinterpret_cast<uchar4 *>(arg)[node * LPN + c4] = a;
+    }
+}
+
+// Backward of gather_max w.r.t. Q: deterministic walk of the reverse index (ascending table position).
+template <int H>
+__global__ __launch_bounds__(256) void gather_max_bwd_kernel(const float *__restrict__ g_out,
+                                                              const uint8_t *__restrict__ arg,
+                                                              const int32_t *__restrict__ rev_ptr,
+                                                              const int32_t *__restrict__ rev_slot, int64_t N,
+                                                              int k, float *__restrict__ gQ)
+{
+    constexpr int LPN = H / 4;
+    constexpr int NPB = 256 / LPN;
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int64_t node = (int64_t)bid * NPB + threadIdx.x / LPN;
+    const int c4 = threadIdx.x % LPN;
+    if (node >= N) return;
+    const int lo = rev_ptr[node], hi = rev_ptr[node + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int rpos = lo; rpos < hi; ++rpos) {
+        const int e = rev_slot[rpos];
+        const int i = e / k;
+        const int s = e - i * k;
+        const uchar4 a = reinterpret_cast<const uchar4 *>(arg)[(int64_t)i * LPN + c4];
+        const float4 g = reinterpret_cast<const float4 *>(g_out)[(int64_t)i * LPN + c4];
+        acc.x += (a.x == s) ? g.x : 0.0f;
+        acc.y += (a.y == s) ? g.y : 0.0f;
+        acc.z += (a.z == s) ? g.z : 0.0f;
+        acc.w += (a.w == s) ? g.w : 0.0f;
+    }
+    reinterpret_cast<float4 *>(gQ)[node * LPN + c4] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// un-fused pieces
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_features_kernel(const float *__restrict__ x,
+                                                             const int32_t *__restrict__ src,
+                                                             const int32_t *__restrict__ tgt, int64_t E, int H,
+                                                             float *__restrict__ feat)
+{
+    const int h4 = H / 4;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t e = gid / h4;
+    const int c4 = (int)(gid - e * h4);
+    if (e >= E) return;
+    const float4 xi = reinterpret_cast<const float4 *>(x)[(int64_t)tgt[e] * h4 + c4];
+    const float4 xj = reinterpret_cast<const float4 *>(x)[(int64_t)src[e] * h4 + c4];
+    float4 *o = reinterpret_cast<float4 *>(feat) + e * (2 * h4);
+    o[c4] = xi;
+    o[h4 + c4] = make_float4(xj.x - xi.x, xj.y - xi.y, xj.z - xi.z, xj.w - xi.w);
+}
+
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void segment_reduce_kernel(const float *__restrict__ msg,
+                                                              const int32_t *__restrict__ rowptr, int64_t N,
+                                                              int H, float *__restrict__ out,
+                                                              int32_t *__restrict__ arg)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = gid / H;
+    const int c = (int)(gid - i * H);
+    if (i >= N) return;
+    const int lo = rowptr[i], hi = rowptr[i + 1];
+    if (IS_MAX) {
+        float best = 0.0f;
+        int a = -1;
+        for (int e = lo; e < hi; ++e) {
+            const float v = msg[(int64_t)e * H + c];
+            if (a < 0 || v > best) { best = v; a = e; }
+        }
+        out[gid] = best;
+        if (arg) arg[gid] = a;
+    } else {
+        float s = 0.0f;
+        for (int e = lo; e < hi; ++e) s += msg[(int64_t)e * H + c];
+        out[gid] = s;
+    }
+}
+
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void segment_reduce_bwd_kernel(const float *__restrict__ g_out,
+                                                                  const int32_t *__restrict__ arg,
+                                                                  const int32_t *__restrict__ rowptr, int64_t N,
+                                                                  int H, float *__restrict__ g_msg)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = gid / H;
+    const int c = (int)(gid - i * H);
+    if (i >= N) return;
+    const int lo = rowptr[i], hi = rowptr[i + 1];
+    const float g = g_out[gid];
+    const int a = IS_MAX ? arg[gid] : 0;
+    for (int e = lo; e < hi; ++e) g_msg[(int64_t)e * H + c] = (!IS_MAX || a == e) ? g : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void edge_features_bwd_kernel(const float *__restrict__ g_feat,
+                                                                 const int32_t *__restrict__ rowptr,
+                                                                 const int32_t *__restrict__ srcptr,
+                                                                 const int32_t *__restrict__ srcperm, int64_t N,
+                                                                 int H, float *__restrict__ gx)
+{
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = gid / H;
+    const int c = (int)(gid - i * H);
+    if (i >= N) return;
+    float s = 0.0f;
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+        const float *g = g_feat + (int64_t)e * (2 * H);
+        s += g[c] - g[H + c];
+    }
+    for (int rp = srcptr[i]; rp < srcptr[i + 1]; ++rp) {
+        const int e = srcperm[rp];
+        s += g_feat[(int64_t)e * (2 * H) + H + c];
+    }
+    gx[gid] = s;
+}
+
+template <int HIN, int HOUT>
+int launch_node_linear(const float *x, int64_t N, const float *W, const float *b, float *P, float *Q,
+                       hipStream_t st)
+{
+    const int64_t ntiles = (N + 31) / 32;
+    int64_t blocks = (ntiles + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((node_linear_split_kernel<HIN, HOUT>), dim3((unsigned)blocks), dim3(256), 0, st, x, N, W, b,
+                       P, Q);
+    DMET_LAUNCH_CHECK("node_linear_split_kernel");
+    return 0;
+}
+
+}  // namespace
+}  // namespace dmet
+
+using namespace dmet;
+
+extern "C" size_t dmet_edgeconv_linear_workspace_bytes(int64_t N, int Hout)
+{
+    if (N <= 0 || Hout <= 0) return 0;
+    return (size_t)N * Hout * sizeof(float) * 2 + 512;
+}
+
+extern "C" int dmet_node_linear_split_f32(const float *x, int64_t N, int Hin, int Hout, const float *W,
+                                          const float *b, float *P, float *Q, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0, "dmet_node_linear_split_f32: N<0");
+    if (N == 0) return 0;
+    DMET_REQUIRE(x && W && P && Q, "dmet_node_linear_split_f32: null pointer");
+    DMET_REQUIRE(aligned16(x) && aligned16(P) && aligned16(Q), "dmet_node_linear_split_f32: pointers must be 16-B aligned");
+    hipStream_t st = as_stream(stream);
+    if (Hin == 32 && Hout == 32) return launch_node_linear<32, 32>(x, N, W, b, P, Q, st);
+    if (Hin == 64 && Hout == 64) return launch_node_linear<64, 64>(x, N, W, b, P, Q, st);
+    if (Hin == 64 && Hout == 32) return launch_node_linear<64, 32>(x, N, W, b, P, Q, st);
+    if (Hin == 32 && Hout == 64) return launch_node_linear<32, 64>(x, N, W, b, P, Q, st);
+    set_error("dmet_node_linear_split_f32: unsupported (Hin,Hout)=(%d,%d); supported: 32/64", Hin, Hout);
+    return -22;
+}
+
+extern "C" int dmet_gather_max_f32(const float *P, const float *Q, const int32_t *nbr, const int64_t *ptr, int B,
+                                   int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream)
+{
+    (void)ptr; (void)B;
+    DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_gather_max_f32: N out of range");
+    DMET_REQUIRE(k >= 1 && k <= 254, "dmet_gather_max_f32: k=%d not in [1,254]", k);
+    if (N == 0) return 0;
+    DMET_REQUIRE(P && Q && nbr && out, "dmet_gather_max_f32: null pointer");
+    DMET_REQUIRE(aligned16(P) && aligned16(Q) && aligned16(out), "dmet_gather_max_f32: pointers must be 16-B aligned");
+    hipStream_t st = as_stream(stream);
+#define DMET_GM(HH)                                                                                             \
+    do {                                                                                                        \
+        constexpr int NPB = 256 / (HH / 4);                                                                     \
+        const int64_t blocks = (N + NPB - 1) / NPB;                                                             \
+        if (arg)                                                                                                \
+            hipLaunchKernelGGL((gather_max_kernel<HH, true>), dim3((unsigned)blocks), dim3(256), 0, st, P, Q,   \
+                               nbr, N, k, out, arg);                                                            \
+        else                                                                                                    \
+            hipLaunchKernelGGL((gather_max_kernel<HH, false>), dim3((unsigned)blocks), dim3(256), 0, st, P, Q,  \
+                               nbr, N, k, out, arg);                                                            \
+    } while (0)
+    if (H == 32) DMET_GM(32);
+    else if (H == 64) DMET_GM(64);
+    else if (H == 128) DMET_GM(128);
+    else if (H == 16) DMET_GM(16);
+    else {
+        set_error("dmet_gather_max_f32: unsupported H=%d (16/32/64/128)", H);
+        return -22;
+    }
+#undef DMET_GM
+    DMET_LAUNCH_CHECK("gather_max_kernel");
+    return 0;
+}
+
+extern "C" int dmet_edgeconv_linear_max_fwd_f32(const float *x, const int32_t *nbr, const int64_t *ptr, int B,
+                                                int64_t N, int k, int Hin, int Hout, const float *W,
+                                                const float *b, float *out, uint8_t *arg, void *ws,
+                                                size_t ws_bytes, dmet_stream_t stream)
+{
+    if (N == 0) return 0;
+    DMET_REQUIRE(ws && ws_bytes >= dmet_edgeconv_linear_workspace_bytes(N, Hout),
+                 "dmet_edgeconv_linear_max_fwd_f32: workspace too small");
+    uintptr_t base = (reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u;
+    float *P = reinterpret_cast<float *>(base);
+    float *Q = P + (size_t)N * Hout;
+    int rc = dmet_node_linear_split_f32(x, N, Hin, Hout, W, b, P, Q, stream);
+    if (rc) return rc;
+    return dmet_gather_max_f32(P, Q, nbr, ptr, B, N, k, Hout, out, arg, stream);
+}
+
+extern "C" int dmet_gather_max_bwd_f32(const float *g_out, const uint8_t *arg, const int32_t *rev_ptr,
+                                       const int32_t *rev_slot, int64_t N, int k, int H, float *gQ,
+                                       dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && k >= 1, "dmet_gather_max_bwd_f32: bad sizes");
+    if (N == 0) return 0;
+    DMET_REQUIRE(g_out && arg && rev_ptr && rev_slot && gQ, "dmet_gather_max_bwd_f32: null pointer");
+    hipStream_t st = as_stream(stream);
+#define DMET_GB(HH)                                                                                         \
+    do {                                                                                                    \
+        constexpr int NPB = 256 / (HH / 4);                                                                 \
+        const int64_t blocks = (N + NPB - 1) / NPB;                                                         \
+        hipLaunchKernelGGL((gather_max_bwd_kernel<HH>), dim3((unsigned)blocks), dim3(256), 0, st, g_out, arg, \
+                           rev_ptr, rev_slot, N, k, gQ);                                                    \
+    } while (0)
+    if (H == 32) DMET_GB(32);
+    else if (H == 64) DMET_GB(64);
+    else if (H == 128) DMET_GB(128);
+    else if (H == 16) DMET_GB(16);
+    else {
+        set_error("dmet_gather_max_bwd_f32: unsupported H=%d", H);
+        return -22;
+    }
+#undef DMET_GB
+    DMET_LAUNCH_CHECK("gather_max_bwd_kernel");
+    return 0;
+}
+
+extern "C" int dmet_edge_features_f32(const float *x, const int32_t *src, const int32_t *tgt, int64_t E, int H,
+                                      float *feat, dmet_stream_t stream)
+{
+    DMET_REQUIRE(E >= 0 && H > 0 && H % 4 == 0, "dmet_edge_features_f32: H=%d must be a positive multiple of 4", H);
+    if (E == 0) return 0;
+    DMET_REQUIRE(x && src && tgt && feat, "dmet_edge_features_f32: null pointer");
+    const int64_t total = E * (H / 4);
+    hipLaunchKernelGGL(edge_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       x, src, tgt, E, H, feat);
+    DMET_LAUNCH_CHECK("edge_features_kernel");
+    return 0;
+}
+
+extern "C" int dmet_segment_max_f32(const float *msg, const int32_t *rowptr, int64_t N, int H, float *out,
+                                    int32_t *arg, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && H > 0, "dmet_segment_max_f32: bad sizes");
+    if (N == 0) return 0;
+    DMET_REQUIRE(rowptr && out, "dmet_segment_max_f32: null pointer");
+    const int64_t total = N * H;
+    hipLaunchKernelGGL((segment_reduce_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), msg, rowptr, N, H, out, arg);
+    DMET_LAUNCH_CHECK("segment_max_kernel");
+    return 0;
+}
+
+extern "C" int dmet_segment_sum_f32(const float *msg, const int32_t *rowptr, int64_t N, int H, float *out,
+                                    dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && H > 0, "dmet_segment_sum_f32: bad sizes");
+    if (N == 0) return 0;
+    DMET_REQUIRE(rowptr && out, "dmet_segment_sum_f32: null pointer");
+    const int64_t total = N * H;
+    hipLaunchKernelGGL((segment_reduce_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), msg, rowptr, N, H, out, (int32_t *)nullptr);
+    DMET_LAUNCH_CHECK("segment_sum_kernel");
+    return 0;
+}
+
+extern "C" int dmet_segment_max_bwd_f32(const float *g_out, const int32_t *arg, const int32_t *rowptr, int64_t N,
+                                        int H, float *g_msg, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && H > 0, "dmet_segment_max_bwd_f32: bad sizes");
+    if (N == 0) return 0;
+    DMET_REQUIRE(g_out && arg && rowptr && g_msg, "dmet_segment_max_bwd_f32: null pointer");
+    const int64_t total = N * H;
+    hipLaunchKernelGGL((segment_reduce_bwd_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), g_out, arg, rowptr, N, H, g_msg);
+    DMET_LAUNCH_CHECK("segment_max_bwd_kernel");
+    return 0;
+}
+
+extern "C" int dmet_segment_sum_bwd_f32(const float *g_out, const int32_t *rowptr, int64_t N, int H,
+                                        float *g_msg, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && H > 0, "dmet_segment_sum_bwd_f32: bad sizes");
+    if (N == 0) return 0;
+    DMET_REQUIRE(g_out && rowptr && g_msg, "dmet_segment_sum_bwd_f32: null pointer");
+    const int64_t total = N * H;
+    hipLaunchKernelGGL((segment_reduce_bwd_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), g_out, (const int32_t *)nullptr, rowptr, N, H, g_msg);
+    DMET_LAUNCH_CHECK("segment_sum_bwd_kernel");
+    return 0;
+}
+
+extern "C" int dmet_edge_features_bwd_f32(const float *g_feat, const int32_t *rowptr, const int32_t *srcptr,
+                                          const int32_t *srcperm, int64_t N, int H, float *gx,
+                                          dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && H > 0, "dmet_edge_features_bwd_f32: bad sizes");
+    if (N == 0) return 0;
+    DMET_REQUIRE(rowptr && srcptr && gx, "dmet_edge_features_bwd_f32: null pointer");
+    const int64_t total = N * H;
+    hipLaunchKernelGGL(edge_features_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       as_stream(stream), g_feat, rowptr, srcptr, srcperm, N, H, gx);
+    DMET_LAUNCH_CHECK("edge_features_bwd_kernel");
+    return 0;
+}

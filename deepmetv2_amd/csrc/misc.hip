@@ -1,0 +1,226 @@
+// misc.hip -- error plumbing, K4 (per-event MET reduction), batch->ptr, reverse index (gfx950).
+#include <stdarg.h>
+#include <string.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+
+#include "common.h"
+
+namespace dmet {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what)
+{
+    set_error("%s: HIP error %d (%s)", what, (int)e, hipGetErrorString(e));
+    return -(1000 + (int)e);
+}
+
+namespace {
+
+// ---- K4: one workgroup per event; lane-strided partials -> wavefront butterfly -> waves summed in order ------
+constexpr int kMetThreads = 256;
+
+template <int NV>
+__global__ __launch_bounds__(kMetThreads) void event_sum_kernel(const float *__restrict__ w,
+                                                                 const float *__restrict__ x, int64_t x_stride,
+                                                                 const int64_t *__restrict__ ptr,
+                                                                 float *__restrict__ out)
+{
+    __shared__ float part[NV][kMetThreads / kWave];
+    const int b = blockIdx.x;
+    const int64_t lo = ptr[b], hi = ptr[b + 1];
+    float s[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) s[v] = 0.0f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += kMetThreads) {
+        if (NV == 2) {
+            const float wi = w[i];
+            s[0] += wi * x[i * x_stride + 0];
+            if (NV > 1) s[NV - 1] += wi * x[i * x_stride + 1];
+        } else {
+            s[0] += w[i];
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) s[v] = wave_sum(s[v]);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) part[v][wv] = s[v];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float t = 0.0f;
+            for (int q = 0; q < kMetThreads / kWave; ++q) t += part[v][q];
+            out[(int64_t)b * NV + v] = t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void met_bwd_kernel(const float *__restrict__ g_met, const float *__restrict__ x,
+                                                       int64_t x_stride, const int64_t *__restrict__ ptr, int B,
+                                                       int64_t N, float *__restrict__ g_w)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int b = find_event(ptr, B, i);
+    g_w[i] = g_met[2 * b] * x[i * x_stride] + g_met[2 * b + 1] * x[i * x_stride + 1];
+}
+
+__global__ __launch_bounds__(256) void batch_to_ptr_kernel(const int64_t *__restrict__ batch, int64_t N, int B,
+                                                            int64_t *__restrict__ ptr)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    // ptr[b] = first i with batch[i] >= b ; written by the thread sitting on each boundary
+    const int64_t prev = (i == 0) ? -1 : batch[i - 1];
+    const int64_t cur = (i == N) ? (int64_t)B : batch[i];
+    for (int64_t b = prev + 1; b <= cur && b <= B; ++b) ptr[b] = i;
+}
+
+// rev_ptr from the sorted source keys: rev_ptr[j] = first sorted position whose key >= j
+__global__ __launch_bounds__(256) void rev_ptr_kernel(const uint32_t *__restrict__ keys_sorted, int64_t E,
+                                                       int64_t N, uint32_t mask, int32_t *__restrict__ rev_ptr)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > E) return;
+    // keys >= N are the "-1 = no neighbour" entries (all ones under the key mask); clamp them to N
+    int64_t prev = (p == 0) ? -1 : (int64_t)(keys_sorted[p - 1] & mask);
+    int64_t cur = (p == E) ? N : (int64_t)(keys_sorted[p] & mask);
+    if (prev > N) prev = N;
+    if (cur > N) cur = N;
+    for (int64_t j = prev + 1; j <= cur; ++j) rev_ptr[j] = (int32_t)p;
+}
+
+inline unsigned bit_length(uint64_t v)
+{
+    unsigned n = 0;
+    while (v) { ++n; v >>= 1; }
+    return n;
+}
+
+}  // namespace
+}  // namespace dmet
+
+using namespace dmet;
+
+extern "C" int dmet_version(void) { return DMET_VERSION; }
+extern "C" const char *dmet_last_error(void) { return g_err; }
+
+extern "C" int dmet_device_available(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n > 0 ? 1 : 0;
+}
+
+extern "C" int dmet_met_reduce_f32(const float *w, const float *x, int64_t x_stride, const int64_t *ptr, int B,
+                                   float *met, dmet_stream_t stream)
+{
+    DMET_REQUIRE(B >= 0 && x_stride >= 2, "dmet_met_reduce_f32: bad sizes (B=%d, x_stride=%lld)", B, (long long)x_stride);
+    if (B == 0) return 0;
+    DMET_REQUIRE(w && x && ptr && met, "dmet_met_reduce_f32: null pointer");
+    hipLaunchKernelGGL((event_sum_kernel<2>), dim3((unsigned)B), dim3(kMetThreads), 0, as_stream(stream), w, x,
+                       x_stride, ptr, met);
+    DMET_LAUNCH_CHECK("met_reduce_kernel");
+    return 0;
+}
+
+extern "C" int dmet_segment_sum_1d_f32(const float *src, const int64_t *ptr, int B, float *out, dmet_stream_t stream)
+{
+    DMET_REQUIRE(B >= 0, "dmet_segment_sum_1d_f32: B<0");
+    if (B == 0) return 0;
+    DMET_REQUIRE(src && ptr && out, "dmet_segment_sum_1d_f32: null pointer");
+    hipLaunchKernelGGL((event_sum_kernel<1>), dim3((unsigned)B), dim3(kMetThreads), 0, as_stream(stream), src,
+                       (const float *)nullptr, (int64_t)0, ptr, out);
+    DMET_LAUNCH_CHECK("segment_sum_1d_kernel");
+    return 0;
+}
+
+extern "C" int dmet_met_reduce_bwd_f32(const float *g_met, const float *x, int64_t x_stride, const int64_t *ptr,
+                                       int B, int64_t N, float *g_w, dmet_stream_t stream)
+{
+    DMET_REQUIRE(B >= 0 && N >= 0 && x_stride >= 2, "dmet_met_reduce_bwd_f32: bad sizes");
+    if (N == 0 || B == 0) return 0;
+    DMET_REQUIRE(g_met && x && ptr && g_w, "dmet_met_reduce_bwd_f32: null pointer");
+    hipLaunchKernelGGL(met_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), g_met, x,
+                       x_stride, ptr, B, N, g_w);
+    DMET_LAUNCH_CHECK("met_bwd_kernel");
+    return 0;
+}
+
+extern "C" int dmet_batch_to_ptr(const int64_t *batch, int64_t N, int B, int64_t *ptr, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && B >= 0, "dmet_batch_to_ptr: bad sizes");
+    DMET_REQUIRE(ptr && (batch || N == 0), "dmet_batch_to_ptr: null pointer");
+    hipLaunchKernelGGL(batch_to_ptr_kernel, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       batch, N, B, ptr);
+    DMET_LAUNCH_CHECK("batch_to_ptr_kernel");
+    return 0;
+}
+
+// ---- reverse index: stable radix sort of the table positions by the source id they hold (rocPRIM) ---------
+static size_t rocprim_sort_bytes(int64_t E, unsigned end_bit)
+{
+    size_t bytes = 0;
+    uint32_t *kin = nullptr, *kout = nullptr;
+    int32_t *vout = nullptr;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, rocprim::counting_iterator<int32_t>(0), vout,
+                                             (size_t)E, 0u, end_bit, (hipStream_t)0);
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return bytes;
+}
+
+extern "C" size_t dmet_reverse_index_workspace_bytes(int64_t M, int64_t num_keys)
+{
+    if (M <= 0 || num_keys <= 0) return 0;
+    size_t sort_bytes = rocprim_sort_bytes(M, bit_length((uint64_t)num_keys));
+    if (sort_bytes == 0) sort_bytes = (size_t)M * 16 + (1u << 20);  // conservative when no device is visible
+    return (size_t)M * sizeof(uint32_t) + sort_bytes + 1024;
+}
+
+extern "C" int dmet_reverse_index(const int32_t *keys, int64_t M, int64_t num_keys, int32_t *rev_ptr,
+                                  int32_t *rev_pos, void *ws, size_t ws_bytes, dmet_stream_t stream)
+{
+    DMET_REQUIRE(M >= 0 && num_keys >= 0, "dmet_reverse_index: bad sizes");
+    DMET_REQUIRE(M < (int64_t)2147483647 && num_keys < (int64_t)2147483647, "dmet_reverse_index: sizes exceed int32");
+    DMET_REQUIRE(rev_ptr, "dmet_reverse_index: null pointer");
+    hipStream_t st = as_stream(stream);
+    if (M == 0) {
+        hipError_t e = hipMemsetAsync(rev_ptr, 0, sizeof(int32_t) * (size_t)(num_keys + 1), st);
+        if (e != hipSuccess) return hip_fail(e, "dmet_reverse_index memset");
+        return 0;
+    }
+    DMET_REQUIRE(keys && rev_pos && ws, "dmet_reverse_index: null pointer");
+    const unsigned end_bit = bit_length((uint64_t)num_keys);  // -1 keeps all ones under the mask and sorts last
+    const uint32_t mask = (end_bit >= 32) ? 0xFFFFFFFFu : ((1u << end_bit) - 1u);
+    uintptr_t base = (reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u;
+    uint32_t *keys_sorted = reinterpret_cast<uint32_t *>(base);
+    void *tmp = reinterpret_cast<void *>((base + (size_t)M * sizeof(uint32_t) + 255u) & ~(uintptr_t)255u);
+    size_t need = rocprim_sort_bytes(M, end_bit);
+    const size_t used = (reinterpret_cast<uintptr_t>(tmp) - reinterpret_cast<uintptr_t>(ws)) + need;
+    DMET_REQUIRE(need > 0 && used <= ws_bytes, "dmet_reverse_index: workspace too small (%zu needed, %zu given)", used,
+                 ws_bytes);
+    hipError_t e = rocprim::radix_sort_pairs(tmp, need, reinterpret_cast<const uint32_t *>(keys), keys_sorted,
+                                             rocprim::counting_iterator<int32_t>(0), rev_pos, (size_t)M, 0u, end_bit,
+                                             st);
+    if (e != hipSuccess) return hip_fail(e, "rocprim::radix_sort_pairs");
+    hipLaunchKernelGGL(rev_ptr_kernel, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, st, keys_sorted, M,
+                       num_keys, mask, rev_ptr);
+    DMET_LAUNCH_CHECK("rev_ptr_kernel");
+    return 0;
+}

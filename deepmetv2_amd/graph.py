@@ -1,0 +1,203 @@
+"""Graph containers shared by the operators: ragged batch info, fixed-width neighbour tables, CSR edge lists.
+
+The PyG-facing API speaks `batch[N]` / `edge_index[2,E]` int64 tensors (the reference's call sites pass exactly
+those: /root/reference/train.py:48-49, model/graph_met_network.py:63-65).  Internally the kernels want `ptr[B+1]`
+and either a fixed-width table nbr[N,k] (what our own kNN / radius kernels emit) or a by-target CSR.  The
+registries below let an `edge_index` produced by `knn_graph` / `radius_graph` find its table again when it is
+handed to `EdgeConv.forward`, so the hot path never re-derives structure from the int64 edge list.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _native
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# batch vector -> (ptr, B)
+# ---------------------------------------------------------------------------------------------------------------
+class BatchInfo:
+    __slots__ = ("ptr", "num_events", "num_nodes")
+
+    def __init__(self, ptr: torch.Tensor, num_events: int, num_nodes: int):
+        self.ptr = ptr
+        self.num_events = num_events
+        self.num_nodes = num_nodes
+
+
+_batch_registry: Dict[int, Tuple[weakref.ref, int, BatchInfo]] = {}
+
+
+def _registry_get(reg, t: torch.Tensor):
+    ent = reg.get(id(t))
+    if ent is None:
+        return None
+    ref, version, val = ent
+    if ref() is t and t._version == version:
+        return val
+    del reg[id(t)]
+    return None
+
+
+def _registry_put(reg, t: torch.Tensor, val) -> None:
+    key = id(t)
+
+    def _drop(_ref, key=key, reg=reg):
+        ent = reg.get(key)
+        if ent is not None and ent[0] is _ref:
+            del reg[key]
+
+    reg[key] = (weakref.ref(t, _drop), t._version, val)
+
+
+def register_batch(batch: torch.Tensor, ptr: torch.Tensor, num_events: int) -> BatchInfo:
+    """Tell the operators the ptr / event count of a batch vector up front (avoids a device->host sync)."""
+    info = BatchInfo(ptr.to(torch.int64).contiguous(), int(num_events), int(batch.numel()))
+    _registry_put(_batch_registry, batch, info)
+    return info
+
+
+def batch_info(batch: Optional[torch.Tensor], num_nodes: int, device: torch.device,
+               num_events: Optional[int] = None) -> BatchInfo:
+    if batch is None:
+        ptr = torch.tensor([0, num_nodes], dtype=torch.int64, device=device)
+        return BatchInfo(ptr, 1, num_nodes)
+    if batch.dim() != 1 or batch.numel() != num_nodes:
+        raise ValueError(f"batch must be 1-D with {num_nodes} entries, got {tuple(batch.shape)}")
+    info = _registry_get(_batch_registry, batch)
+    if info is not None:
+        return info
+    if batch.dtype != torch.int64:
+        raise TypeError(f"batch must be int64 (torch.long), got {batch.dtype}")
+    if num_nodes == 0:
+        return BatchInfo(torch.zeros(1, dtype=torch.int64, device=device), 0, 0)
+    # one host sync, like PyG's own `int(batch.max()) + 1`; sortedness is a documented precondition upstream
+    if num_events is None:
+        last, unsorted = torch.stack([batch[-1], (batch[1:] < batch[:-1]).any().to(batch.dtype)]).tolist()
+        if unsorted:
+            raise ValueError("batch vector must be sorted (torch_cluster / PyG precondition)")
+        num_events = int(last) + 1
+    ptr = _native.batch_to_ptr(batch, num_events)
+    info = BatchInfo(ptr, num_events, num_nodes)
+    _registry_put(_batch_registry, batch, info)
+    return info
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CSR edge list (by target), plus the by-source index for the backward pass
+# ---------------------------------------------------------------------------------------------------------------
+class EdgeList:
+    """Edges grouped by target: tgt[e] == i for rowptr[i] <= e < rowptr[i+1]; src/tgt int32."""
+
+    def __init__(self, src: torch.Tensor, tgt: torch.Tensor, rowptr: torch.Tensor, num_nodes: int,
+                 perm: Optional[torch.Tensor] = None):
+        self.src = src
+        self.tgt = tgt
+        self.rowptr = rowptr
+        self.num_nodes = num_nodes
+        self.num_edges = int(src.numel())
+        self.perm = perm  # position in the caller's edge_index of each grouped edge (None = identity)
+        self._by_source = None
+
+    def by_source(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """srcptr[N+1], srcperm[E]: edges leaving node j, ascending edge position (deterministic backward)."""
+        if self._by_source is None:
+            if self.num_edges == 0:
+                z = torch.zeros(self.num_nodes + 1, dtype=torch.int32, device=self.src.device)
+                self._by_source = (z, torch.zeros(1, dtype=torch.int32, device=self.src.device))
+            else:
+                self._by_source = _reverse_of_column(self.src, self.num_nodes)
+        return self._by_source
+
+
+def _reverse_of_column(col: torch.Tensor, num_nodes: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Stable sort of positions 0..E-1 by col value -> (ptr[num_nodes+1], perm[E]) via the reverse-index kernel."""
+    return _native.reverse_index(col.contiguous(), num_nodes)
+
+
+def edge_list_from_edge_index(edge_index: torch.Tensor, num_nodes: int, flow: str) -> EdgeList:
+    """Generic path for an arbitrary caller-supplied edge_index (radius graphs, to_undirected output...)."""
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
+    if edge_index.dtype != torch.int64:
+        raise TypeError(f"edge_index must be int64 (torch.long), got {edge_index.dtype}")
+    i_row, j_row = (1, 0) if flow == "source_to_target" else (0, 1)
+    tgt64 = edge_index[i_row]
+    src64 = edge_index[j_row]
+    E = tgt64.numel()
+    dev = edge_index.device
+    if E == 0:
+        z = torch.zeros(num_nodes + 1, dtype=torch.int32, device=dev)
+        e = torch.zeros(0, dtype=torch.int32, device=dev)
+        return EdgeList(e, e, z, num_nodes)
+    tgt = tgt64.to(torch.int32).contiguous()
+    src = src64.to(torch.int32).contiguous()
+    # group by target with the stable reverse-index sort (keeps the caller's order inside a group, so "lowest
+    # edge position wins ties" (R4) is preserved); skip the permutation when the list is already grouped.
+    rowptr, perm = _reverse_of_column(tgt, num_nodes)
+    ident = torch.arange(E, dtype=torch.int32, device=dev)
+    if bool((perm[:E] == ident).all()):
+        return EdgeList(src, tgt, rowptr, num_nodes, None)
+    p = perm[:E].to(torch.int64)
+    return EdgeList(src[p].contiguous(), tgt[p].contiguous(), rowptr, num_nodes, perm[:E])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fixed-width neighbour table (what the kNN / radius kernels emit)
+# ---------------------------------------------------------------------------------------------------------------
+class NeighborTable:
+    """nbr[N,k] int32 global node ids, -1 = empty slot.  Row i lists the message SOURCES of target i."""
+
+    def __init__(self, nbr: torch.Tensor, ptr: Optional[torch.Tensor], dense: bool, dist: Optional[torch.Tensor] = None):
+        self.nbr = nbr
+        self.ptr = ptr
+        self.num_nodes, self.k = nbr.shape
+        self.dense = dense          # True: no -1 entries anywhere (every row has exactly k neighbours)
+        self.dist = dist
+        self._rev = None
+        self._edges = None
+        self._edge_index = {}
+
+    def reverse(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._rev is None:
+            self._rev = _native.reverse_index(self.nbr.view(-1), self.num_nodes)
+        return self._rev
+
+    def edge_list(self) -> EdgeList:
+        if self._edges is None:
+            N, k = self.num_nodes, self.k
+            dev = self.nbr.device
+            tgt_all = torch.arange(N, dtype=torch.int32, device=dev).repeat_interleave(k)
+            src_all = self.nbr.reshape(-1)
+            if self.dense:
+                rowptr = torch.arange(0, (N + 1) * k, k, dtype=torch.int32, device=dev)
+                self._edges = EdgeList(src_all, tgt_all, rowptr, N)
+            else:
+                keep = src_all >= 0
+                deg = keep.view(N, k).sum(1, dtype=torch.int32)
+                rowptr = torch.zeros(N + 1, dtype=torch.int32, device=dev)
+                rowptr[1:] = deg.cumsum(0)
+                self._edges = EdgeList(src_all[keep].contiguous(), tgt_all[keep].contiguous(), rowptr, N)
+        return self._edges
+
+    def edge_index(self, flow: str = "source_to_target") -> torch.Tensor:
+        """int64 [2,E] in PyG orientation (R5); registered so EdgeConv can find this table again."""
+        ei = self._edge_index.get(flow)
+        if ei is None:
+            el = self.edge_list()
+            src, tgt = el.src.to(torch.int64), el.tgt.to(torch.int64)
+            ei = torch.stack([src, tgt], 0) if flow == "source_to_target" else torch.stack([tgt, src], 0)
+            self._edge_index[flow] = ei
+            _registry_put(_graph_registry, ei, (self, flow))
+        return ei
+
+
+_graph_registry: Dict[int, Tuple[weakref.ref, int, object]] = {}
+
+
+def lookup_graph(edge_index: torch.Tensor):
+    """(NeighborTable, flow) if this exact edge_index tensor came from knn_graph / radius_graph, else None."""
+    return _registry_get(_graph_registry, edge_index)

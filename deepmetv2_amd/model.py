@@ -1,0 +1,89 @@
+"""The graph-MET model wired onto the HIP operators (rows H1/H2 of SURVEY.md section 8a).
+
+Own counterpart of /root/reference/model/graph_met_network.py:11-69 (`GraphMETNetwork`) and
+/root/reference/model/net.py:38-62 (`Net`, `loss_fn`): same layer structure, same attribute names, hence the same
+`state_dict` keys, so the shipped checkpoints (ckpts_*/best.pth.tar) load with `load_state_dict` unchanged.
+The per-node dense layers are stock torch.nn; the graph convolution, graph build and MET reduction are this
+package's operators.  `graph='dynamic'` rebuilds a kNN graph in the current embedding before every convolution
+(the alternative kept at graph_met_network.py:63); `graph='static'` convolves over the `edge_index` argument
+(graph_met_network.py:65, the active line).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .conv import DynamicEdgeConv, EdgeConv
+from .scatter import met_reduce
+
+PDG_CLASSES = (1, 2, 11, 13, 22, 130, 211)  # graph_met_network.py:45
+
+
+class GraphMETNetwork(nn.Module):
+    def __init__(self, continuous_dim: int, cat_dim: int, output_dim: int = 1, hidden_dim: int = 32,
+                 conv_depth: int = 1, graph: str = "static", k: int = 16):
+        super().__init__()
+        if graph not in ("static", "dynamic"):
+            raise ValueError("graph must be 'static' or 'dynamic'")
+        q, h = hidden_dim // 4, hidden_dim // 2
+        self.graph, self.k = graph, k
+        self.embed_charge = nn.Embedding(3, q)
+        self.embed_pdgid = nn.Embedding(len(PDG_CLASSES), q)
+        self.embed_pv = nn.Embedding(8, q)
+        self.embed_continuous = nn.Sequential(nn.Linear(continuous_dim, h), nn.ELU())
+        self.embed_categorical = nn.Sequential(nn.Linear(3 * q, h), nn.ELU())
+        self.encode_all = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.ELU())
+        self.bn_all = nn.BatchNorm1d(hidden_dim)
+        self.conv_continuous = nn.ModuleList()
+        for _ in range(conv_depth):
+            message = nn.Sequential(nn.Linear(2 * hidden_dim, hidden_dim))
+            conv = DynamicEdgeConv(nn=message, k=k) if graph == "dynamic" else EdgeConv(nn=message).jittable()
+            self.conv_continuous.append(nn.ModuleList([conv, nn.BatchNorm1d(hidden_dim)]))
+        self.output = nn.Sequential(nn.Linear(hidden_dim, h), nn.ELU(), nn.Linear(h, output_dim))
+        self.pdgs = list(PDG_CLASSES)
+
+    def embed(self, x_cont: torch.Tensor, x_cat: torch.Tensor) -> torch.Tensor:
+        """Per-node encoder (graph_met_network.py:48-58): columns of x_cat are (pdgId, charge, fromPV)."""
+        e_cont = self.embed_continuous(x_cont)
+        e_chrg = self.embed_charge(x_cat[:, 1] + 1)
+        e_pv = self.embed_pv(x_cat[:, 2])
+        pdg = x_cat[:, 0].abs()
+        for cls, val in enumerate(self.pdgs):  # sequential remap, kept sequential for unexpected ids
+            pdg = torch.where(pdg == val, torch.full_like(pdg, cls), pdg)
+        e_pdg = self.embed_pdgid(pdg)
+        e_cat = self.embed_categorical(torch.cat([e_chrg, e_pdg, e_pv], dim=1))
+        return self.bn_all(self.encode_all(torch.cat([e_cat, e_cont], dim=1)))
+
+    def forward(self, x_cont, x_cat, edge_index, batch):
+        emb = self.embed(x_cont, x_cat)
+        for conv, norm in self.conv_continuous:
+            msg = conv(emb, batch) if self.graph == "dynamic" else conv(emb, edge_index)
+            emb = emb + norm(msg)
+        return self.output(emb).squeeze(-1)
+
+
+class Net(nn.Module):
+    """net.py:38-47: GraphMETNetwork(output_dim=1, hidden_dim=32, conv_depth=2) followed by a sigmoid."""
+
+    def __init__(self, continuous_dim: int, categorical_dim: int, graph: str = "static", k: int = 16):
+        super().__init__()
+        self.graphnet = GraphMETNetwork(continuous_dim, categorical_dim, output_dim=1, hidden_dim=32,
+                                        conv_depth=2, graph=graph, k=k)
+
+    def forward(self, x_cont, x_cat, edge_index, batch):
+        return torch.sigmoid(self.graphnet(x_cont, x_cat, edge_index, batch))
+
+
+def loss_fn(weights: torch.Tensor, prediction: torch.Tensor, truth: torch.Tensor, batch: torch.Tensor,
+            ptr: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """net.py:49-62 with the two scatter_add calls fused into one MET reduction:
+    0.5 * mean_b((METx + true_px)^2 + (METy + true_py)^2)."""
+    met = met_reduce(weights, prediction, batch, ptr=ptr, num_events=truth.shape[0])
+    return 0.5 * ((met[:, 0] + truth[:, 0]) ** 2 + (met[:, 1] + truth[:, 1]) ** 2).mean()
+
+
+def split_features(x: torch.Tensor):
+    """train.py:42-46: continuous columns 0..7 (puppi included), categorical columns 8..10 as int64."""
+    return x[:, :8], x[:, 8:].long()

@@ -1,0 +1,140 @@
+/*
+ * dmet.h -- C ABI of libdmet_hip.so: the MI355X (gfx950) implementation of the graph operators on the
+ * DeepMETv2 DynamicEdgeConv hot path.
+ *
+ * The reference (DeepMETv2, /root/reference) is pure Python; the kernels it executes for this path live in
+ * the torch_cluster / torch_geometric / torch_scatter wheels.  Each entry point below names the reference
+ * call site (file:line, relative to /root/reference) whose third-party operator it replaces.  The reference
+ * side binds this library with ctypes; deepmetv2_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes.  Every pointer is a DEVICE pointer unless it says "host".
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs no host
+ *    synchronisation, allocates nothing and keeps no global mutable state (re-entrant, graph-capturable).
+ *    Scratch comes from the caller: ask dmet_*_workspace_bytes(), pass `ws`/`ws_bytes`.
+ *  - return value: 0 = ok; < 0 = failure (-EINVAL = -22 for bad arguments, -(1000+hipError_t) for a HIP
+ *    runtime error).  dmet_last_error() returns a thread-local message for the last failure.
+ *  - events (graphs) are the ragged units: event b owns nodes ptr[b] .. ptr[b+1]-1 (int64, B+1 entries).
+ *  - neighbour tables are fixed width: nbr[N, k] int32 GLOBAL node ids, -1 = no neighbour (short events).
+ *  - all floating point is IEEE fp32 unless the name says otherwise.
+ */
+#ifndef DMET_H_
+#define DMET_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *dmet_stream_t; /* hipStream_t */
+
+#define DMET_VERSION 1
+#define DMET_MAX_K 64       /* upstream torch_cluster rejects k > 100; this build supports k <= 64   */
+#define DMET_MAX_KNN_DIM 64 /* feature width of the kNN space (hot path: 32; (eta,phi) graph: 2)      */
+#define DMET_MAX_H 128      /* feature width of EdgeConv inputs/outputs (hot path: 32)                */
+
+int dmet_version(void);
+const char *dmet_last_error(void);
+/* 1 if a HIP device is usable by this process, 0 otherwise (never fails). */
+int dmet_device_available(void);
+
+/* ---- K1: kNN graph build -------------------------------------------------------------------------
+ * replaces torch_cluster.knn_graph / torch_cluster.knn
+ *   call sites: model/graph_met_network.py:63, model/dynamic_reduction_network.py:86,94; inside PyG
+ *   DynamicEdgeConv.forward.
+ * For every node i: the k nodes j of the same event with the smallest squared L2 distance
+ *   d(i,j) = sum_c fmaf(x[j,c]-x[i,c], x[j,c]-x[i,c], acc)  (sequential in c, fp32; rule R1)
+ * ordered by (d, j) ascending; ties keep the lower j (rule R2); candidates at d >= 1e10 are never
+ * selected (upstream sentinel).  Self is a candidate like any other (loop handling is host-side).
+ * nbr[N,k] int32 (required), dist[N,k] fp32 (required; it is also the kernel's running top-k state).
+ * One launch for all ragged events.  1 <= k <= DMET_MAX_K, 1 <= D <= DMET_MAX_KNN_DIM. */
+size_t dmet_knn_workspace_bytes(int64_t N, int B, int D, int k);
+int dmet_knn_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,
+                 float *dist, void *ws, size_t ws_bytes, dmet_stream_t stream);
+
+/* ---- N1: radius graph build ----------------------------------------------------------------------
+ * replaces torch_cluster.radius_graph   call sites: train.py:48, evaluate.py:88, plt_weight.py:122
+ * For every node i: the FIRST max_nbr nodes j (ascending j) of the same event with d(i,j) < r*r
+ * (strict, r*r formed in fp32).  nbr[N,max_nbr] int32 (-1 padded), cnt[N] int32. */
+int dmet_radius_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr,
+                    int32_t *nbr, int32_t *cnt, dmet_stream_t stream);
+
+/* ---- K2+K3 fused: EdgeConv with nn = Linear(2*Hin -> Hout), aggr = 'max', fixed-width table ---------
+ * replaces torch_geometric.nn.EdgeConv(nn=Sequential(Linear(2H,H)), aggr='max').forward
+ *   constructed model/graph_met_network.py:36-38, invoked :65 (static graph) / :63 (dynamic kNN).
+ *   out[i] = max_{s: nbr[i,s]>=0} ( W . [x_i || x_j - x_i] + b ),  j = nbr[i,s];  no neighbour -> 0 (R3)
+ * computed through the exact split  W.[x_i || x_j-x_i] + b = (W1-W2).x_i + b + W2.x_j :
+ *   step 1 (fp32 MFMA):  P[i] = (W1-W2).x_i + b,  Q[i] = W2.x_i           (tables [N,Hout] in ws)
+ *   step 2 (gather+max): out[i] = P[i] + max_s Q[nbr[i,s]],  arg[i,c] = winning slot s (lowest on ties, R4)
+ * W is torch Linear.weight layout [Hout, 2*Hin] row-major; arg[N,Hout] uint8 may be NULL (inference);
+ * arg = 255 marks a node without neighbours.  Hin, Hout multiples of 32, <= DMET_MAX_H; k <= DMET_MAX_K. */
+size_t dmet_edgeconv_linear_workspace_bytes(int64_t N, int Hout);
+int dmet_edgeconv_linear_max_fwd_f32(const float *x, const int32_t *nbr, const int64_t *ptr, int B,
+                                     int64_t N, int k, int Hin, int Hout, const float *W,
+                                     const float *b, float *out, uint8_t *arg, void *ws,
+                                     size_t ws_bytes, dmet_stream_t stream);
+/* The two steps individually (step 2 is "the gather + scatter_max kernel" of BASELINE.json). */
+int dmet_node_linear_split_f32(const float *x, int64_t N, int Hin, int Hout, const float *W,
+                               const float *b, float *P, float *Q, dmet_stream_t stream);
+int dmet_gather_max_f32(const float *P, const float *Q, const int32_t *nbr, const int64_t *ptr, int B,
+                        int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream);
+/* Backward of step 2 w.r.t. Q:  gQ[j,c] = sum over (i,s) with nbr[i,s]==j and arg[i,c]==s of g_out[i,c].
+ * Deterministic (no float atomics): walks the reverse index rev_ptr[N+1] (int32), rev_slot[E] (int32,
+ * entry = i*k+s, ascending inside a row) built by dmet_reverse_index(nbr, N*k, N, ...). */
+int dmet_gather_max_bwd_f32(const float *g_out, const uint8_t *arg, const int32_t *rev_ptr,
+                            const int32_t *rev_slot, int64_t N, int k, int H, float *gQ,
+                            dmet_stream_t stream);
+/* Reverse index: a stable sort of the positions 0..M-1 of an int32 key array by key value.
+ *   rev_ptr[num_keys+1]: rev_pos[rev_ptr[j] .. rev_ptr[j+1]-1] = the positions holding key j, ascending.
+ * Keys outside [0, num_keys) (the -1 "no neighbour" entries) sort last and are not indexed.
+ * For a neighbour table pass keys = nbr, M = N*k, num_keys = N (position = i*k+s). */
+size_t dmet_reverse_index_workspace_bytes(int64_t M, int64_t num_keys);
+int dmet_reverse_index(const int32_t *keys, int64_t M, int64_t num_keys, int32_t *rev_ptr,
+                       int32_t *rev_pos, void *ws, size_t ws_bytes, dmet_stream_t stream);
+
+/* ---- K2 / K3 un-fused: arbitrary `nn`, arbitrary edge lists ------------------------------------------
+ * replaces the PyG MessagePassing.propagate pieces around a user `nn`
+ *   (model/dynamic_reduction_network.py:59-73,86-87: Linear-ELU-Linear-ELU-BN, aggr in {'add','max'}).
+ * Edges are (src[e] -> tgt[e]) int32, grouped by target: rowptr[N+1] int32 with tgt[e]==i for
+ * rowptr[i] <= e < rowptr[i+1].
+ *   edge_features: feat[e] = [ x[tgt[e]] || x[src[e]] - x[tgt[e]] ]                      ([E, 2H])
+ *   segment_max  : out[i,c] = max_e msg[e,c] (empty -> 0), arg[i,c] = winning e (lowest on ties), -1 if empty
+ *   segment_sum  : out[i,c] = sum_e msg[e,c] in ascending e (deterministic)
+ *   segment_max_bwd: g_msg[e,c] = (arg[tgt(e),c]==e) ? g_out[tgt(e),c] : 0
+ *   edge_features_bwd: gx[i] = sum_{e in in(i)} (g_feat[e,:H] - g_feat[e,H:]) + sum_{e in out(i)} g_feat[e,H:]
+ *                      out(i) walked through the by-source index srcptr[N+1], srcperm[E] (ascending e). */
+int dmet_edge_features_f32(const float *x, const int32_t *src, const int32_t *tgt, int64_t E, int H,
+                           float *feat, dmet_stream_t stream);
+int dmet_segment_max_f32(const float *msg, const int32_t *rowptr, int64_t N, int H, float *out,
+                         int32_t *arg, dmet_stream_t stream);
+int dmet_segment_sum_f32(const float *msg, const int32_t *rowptr, int64_t N, int H, float *out,
+                         dmet_stream_t stream);
+int dmet_segment_max_bwd_f32(const float *g_out, const int32_t *arg, const int32_t *rowptr, int64_t N,
+                             int H, float *g_msg, dmet_stream_t stream);
+int dmet_segment_sum_bwd_f32(const float *g_out, const int32_t *rowptr, int64_t N, int H, float *g_msg,
+                             dmet_stream_t stream);
+int dmet_edge_features_bwd_f32(const float *g_feat, const int32_t *rowptr, const int32_t *srcptr,
+                               const int32_t *srcperm, int64_t N, int H, float *gx,
+                               dmet_stream_t stream);
+
+/* ---- K4: per-event MET reduction -------------------------------------------------------------------
+ * replaces the two torch_scatter.scatter_add calls at model/net.py:55-56 (and :132-133):
+ *   met[b,0] = sum_{i in event b} w[i]*x[i*x_stride+0],  met[b,1] = sum w[i]*x[i*x_stride+1]
+ * Deterministic fixed-shape tree (one workgroup per event; lane-strided partials, wavefront shuffle
+ * tree, then waves in order).  bwd: g_w[i] = g_met[b,0]*px_i + g_met[b,1]*py_i. */
+int dmet_met_reduce_f32(const float *w, const float *x, int64_t x_stride, const int64_t *ptr, int B,
+                        float *met, dmet_stream_t stream);
+int dmet_met_reduce_bwd_f32(const float *g_met, const float *x, int64_t x_stride, const int64_t *ptr,
+                            int B, int64_t N, float *g_w, dmet_stream_t stream);
+/* Generic sorted-index form used by the scatter_add(src, batch) drop-in: out[b] = sum_{i in b} src[i]. */
+int dmet_segment_sum_1d_f32(const float *src, const int64_t *ptr, int B, float *out,
+                            dmet_stream_t stream);
+/* ptr[B+1] from a SORTED int64 batch vector (ptr[b] = first i with batch[i] >= b). */
+int dmet_batch_to_ptr(const int64_t *batch, int64_t N, int B, int64_t *ptr, dmet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMET_H_ */

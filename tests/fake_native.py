@@ -1,0 +1,158 @@
+"""TEST INFRASTRUCTURE: an oracle-backed stand-in for deepmetv2_amd._native so that the HOST logic (autograd
+wiring, graph registries, argument checks, DDP sharding) can be exercised in a GPU-less container.
+
+Never shipped or imported by the package: tests install it explicitly with `install(monkeypatch)`.  Every function
+restates the contract of the C-ABI entry point of the same name (include/dmet.h) with plain torch on the CPU.
+"""
+from __future__ import annotations
+
+import torch
+
+from oracle import ref_ops
+
+
+def knn(x, ptr, k):
+    return ref_ops.knn_table(x, ptr, k)
+
+
+def radius(x, ptr, r, max_nbr):
+    import ctypes  # noqa: F401
+    x = x.detach().float().contiguous()
+    N, D = x.shape
+    nbr = torch.empty((N, max_nbr), dtype=torch.int32)
+    cnt = torch.empty((N,), dtype=torch.int32)
+    rc = ref_ops.lib().dmet_oracle_radius_f32(x.data_ptr(), ptr.contiguous().data_ptr(), ptr.numel() - 1, D, float(r),
+                                              max_nbr, nbr.data_ptr(), cnt.data_ptr())
+    assert rc == 0
+    return nbr, cnt
+
+
+def node_linear_split(x, W, b):
+    H = x.shape[1]
+    Wd = W[:, :H] - W[:, H:]
+    P = x @ Wd.t()
+    if b is not None:
+        P = P + b
+    return P.detach(), (x @ W[:, H:].t()).detach()
+
+
+def gather_max(P, Q, nbr, ptr, want_arg):
+    N, H = P.shape
+    k = nbr.shape[1]
+    idx = nbr.long().clamp(min=0)
+    vals = Q[idx]                                             # [N,k,H]
+    vals = torch.where((nbr >= 0).unsqueeze(-1), vals, torch.full_like(vals, float("-inf")))
+    best, arg = vals.max(dim=1)
+    # lowest slot on ties: torch.max returns the first maximal index on CPU
+    first = (vals == best.unsqueeze(1)).float().argmax(dim=1)
+    any_valid = (nbr >= 0).any(dim=1, keepdim=True)
+    out = torch.where(any_valid, P + best, torch.zeros_like(P))
+    arg8 = torch.where(any_valid, first, torch.full_like(first, 255)).to(torch.uint8)
+    return out, (arg8 if want_arg else None)
+
+
+def reverse_index(keys, num_keys):
+    keys = keys.reshape(-1)
+    M = keys.numel()
+    k64 = keys.long()
+    k64 = torch.where((k64 < 0) | (k64 >= num_keys), torch.full_like(k64, num_keys), k64)
+    order = torch.sort(k64, stable=True).indices
+    counts = torch.bincount(k64, minlength=num_keys + 1)[:num_keys]
+    rev_ptr = torch.zeros(num_keys + 1, dtype=torch.int32)
+    rev_ptr[1:] = counts.cumsum(0).int()
+    return rev_ptr, order.int() if M else torch.zeros(1, dtype=torch.int32)
+
+
+def gather_max_bwd(g_out, arg, rev_ptr, rev_slot, k):
+    N, H = g_out.shape
+    gQ = torch.zeros_like(g_out)
+    n_valid = int(rev_ptr[-1])
+    # recover (source j, position e) pairs from the reverse index
+    src = torch.repeat_interleave(torch.arange(N), (rev_ptr[1:] - rev_ptr[:-1]).long())
+    e = rev_slot[:n_valid].long()
+    i, s = e // k, e % k
+    contrib = torch.where(arg[i].long() == s.view(-1, 1), g_out[i], torch.zeros_like(g_out[i]))
+    gQ.index_add_(0, src, contrib)
+    return gQ
+
+
+def edge_features(x, src, tgt):
+    xi, xj = x[tgt.long()], x[src.long()]
+    return torch.cat([xi, xj - xi], dim=1).detach()
+
+
+def edge_features_bwd(g_feat, rowptr, srcptr, srcperm, N, H):
+    E = g_feat.shape[0]
+    tgt = torch.repeat_interleave(torch.arange(N), (rowptr[1:] - rowptr[:-1]).long())
+    src_of = torch.empty(E, dtype=torch.long)
+    src_nodes = torch.repeat_interleave(torch.arange(N), (srcptr[1:] - srcptr[:-1]).long())
+    src_of[srcperm[:E].long()] = src_nodes
+    gx = torch.zeros((N, H), dtype=g_feat.dtype)
+    gx.index_add_(0, tgt, g_feat[:, :H] - g_feat[:, H:])
+    gx.index_add_(0, src_of, g_feat[:, H:])
+    return gx
+
+
+def _tgt_of(rowptr, N):
+    return torch.repeat_interleave(torch.arange(N), (rowptr[1:] - rowptr[:-1]).long())
+
+
+def segment_max(msg, rowptr, N):
+    out, arg = ref_ops.scatter_max(msg.detach(), _tgt_of(rowptr, N), N)
+    E = msg.shape[0]
+    return out, torch.where(arg >= E, torch.full_like(arg, -1), arg).int()
+
+
+def segment_sum(msg, rowptr, N):
+    return ref_ops.scatter_add(msg.detach(), _tgt_of(rowptr, N), dim_size=N)
+
+
+def segment_max_bwd(g_out, arg, rowptr, E):
+    N, H = g_out.shape
+    tgt = _tgt_of(rowptr, N)
+    won = arg.long()[tgt] == torch.arange(E).view(-1, 1)
+    return torch.where(won, g_out[tgt], torch.zeros((E, H), dtype=g_out.dtype))
+
+
+def segment_sum_bwd(g_out, rowptr, E):
+    return g_out[_tgt_of(rowptr, g_out.shape[0])].clone()
+
+
+def met_reduce(w, x, ptr):
+    B = ptr.numel() - 1
+    batch = torch.repeat_interleave(torch.arange(B), ptr.diff())
+    met = torch.zeros((B, 2), dtype=torch.float32)
+    met.index_add_(0, batch, w.detach().view(-1, 1) * x[:, :2])
+    return met
+
+
+def met_reduce_bwd(g_met, x, ptr):
+    B = ptr.numel() - 1
+    batch = torch.repeat_interleave(torch.arange(B), ptr.diff())
+    return g_met[batch, 0] * x[:, 0] + g_met[batch, 1] * x[:, 1]
+
+
+def segment_sum_1d(src, ptr):
+    B = ptr.numel() - 1
+    batch = torch.repeat_interleave(torch.arange(B), ptr.diff())
+    return torch.zeros(B, dtype=src.dtype).index_add_(0, batch, src.detach())
+
+
+def batch_to_ptr(batch, B):
+    return ref_ops.batch_to_ptr(batch, batch.numel(), B)
+
+
+_NAMES = ["knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
+          "edge_features_bwd", "segment_max", "segment_sum", "segment_max_bwd", "segment_sum_bwd", "met_reduce",
+          "met_reduce_bwd", "segment_sum_1d", "batch_to_ptr"]
+
+
+def install(monkeypatch=None):
+    """Replace deepmetv2_amd._native's entry points by the CPU stand-ins (for the duration of a test)."""
+    import deepmetv2_amd._native as nat
+    g = globals()
+    for n in _NAMES:
+        if monkeypatch is not None:
+            monkeypatch.setattr(nat, n, g[n])
+        else:
+            setattr(nat, n, g[n])

@@ -1,0 +1,81 @@
+"""Host logic on the CPU: the same checks as tests/test_gpu_parity.py, with deepmetv2_amd._native replaced by the
+oracle-backed stand-in of tests/fake_native.py (test infrastructure).  Exercises autograd wiring, registries, the
+PyG-shaped argument handling and error behaviour without a GPU; the HIP kernels themselves are only tested by -m gpu.
+"""
+import pytest
+import torch
+
+import test_gpu_parity as P
+from fake_native import install
+
+CPU = torch.device("cpu")
+
+
+@pytest.fixture(autouse=True)
+def _fake(monkeypatch):
+    install(monkeypatch)
+
+
+@pytest.mark.parametrize("sizes,D,k", [([40, 3, 0, 90], 8, 6), ([1, 2], 3, 4)])
+def test_knn(sizes, D, k):
+    P.test_knn_bit_exact(CPU, sizes, D, k)
+
+
+@pytest.mark.parametrize("loop", [True, False])
+@pytest.mark.parametrize("flow", ["source_to_target", "target_to_source"])
+def test_knn_graph(loop, flow):
+    P.test_knn_graph_edge_index(CPU, loop, flow)
+
+
+def test_radius():
+    P.test_radius_graph(CPU)
+
+
+@pytest.mark.parametrize("sizes,H,k", [([50, 1, 0, 70], 32, 8), ([30, 40], 64, 5)])
+def test_fused(sizes, H, k):
+    P.test_dynamic_edgeconv_fused_fwd_bwd(CPU, sizes, H, k)
+
+
+@pytest.mark.parametrize("aggr", ["max", "add", "mean"])
+def test_generic(aggr):
+    P.test_edgeconv_generic_nn_irregular_graph(CPU, aggr)
+
+
+def test_static_radius():
+    P.test_edgeconv_static_graph_from_radius(CPU)
+
+
+def test_ties():
+    P.test_max_ties_and_empty_rows(CPU)
+
+
+def test_full_model():
+    P.test_full_model_train_step_matches_oracle(CPU)
+
+
+def test_product_refuses_cpu_tensors():
+    """Without the stand-in the product path must fail loudly on CPU tensors (no silent fallback)."""
+    import importlib
+
+    import deepmetv2_amd._native as nat
+    importlib.reload(nat)
+    with pytest.raises(RuntimeError, match="non-GPU tensor"):
+        nat.knn(torch.randn(4, 2), torch.tensor([0, 4]), 2)
+
+
+def test_edgeconv_api_surface():
+    import deepmetv2_amd as dm
+    lin = torch.nn.Sequential(torch.nn.Linear(64, 32))
+    conv = dm.EdgeConv(nn=lin).jittable()
+    assert conv.nn is lin and conv.aggr == "max" and conv.flow == "source_to_target"
+    assert list(conv.state_dict().keys()) == ["nn.0.weight", "nn.0.bias"]      # owns nothing of its own
+    dyn = dm.DynamicEdgeConv(lin, k=16)
+    assert dyn.k == 16 and list(dyn.state_dict().keys()) == ["nn.0.weight", "nn.0.bias"]
+    with pytest.raises(ValueError):
+        dm.EdgeConv(lin, aggr="median")
+    with pytest.raises(NotImplementedError):
+        dm.knn_graph(torch.zeros(4, 2), 2, cosine=True)
+    with pytest.raises(ValueError, match="sorted"):
+        dm.knn_graph(torch.zeros(4, 2), 2, torch.tensor([0, 1, 0, 1]))
+    with pytest.raises(ValueError):
+        dm.knn_graph(torch.zeros(4, 2), 100)
