@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- events/s of the DeepMETv2 DynamicEdgeConv hot path on MI355X (BASELINE.json metric).
+
+A "step" = one full training step (the sequence of /root/reference/train.py:40-52: zero_grad, feature split, model
+forward with a kNN graph rebuilt in the embedding before each of the 2 EdgeConv layers, loss, backward, gradient
+all-reduce when N>1, AdamW step) over one batch of synthetic events resident in HBM.  Workload at N=1 is
+BASELINE.json configs[1]: 64 events x 4500 PF candidates x 11 features, k=16, fp32; for N>1 every rank gets its own
+64 events (weak scaling, batch = 64*N events as in configs[3]).
+
+Prints ONE JSON line on rank 0.  Launch for N>1:
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+FP32_VALU_PEAK_TFLOPS = 157.3
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--events-per-gpu", type=int, default=64)
+    ap.add_argument("--nodes", type=int, default=4500)
+    ap.add_argument("--k", type=int, default=16)
+    ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-events", type=int, default=0, help="0 = one event per host core (max 16)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, seed: int):
+    """The same training step on the host cores through the CPU oracle (PyG-shaped, un-fused restatement of the
+    reference's operators; kind 'port' -- PyG itself is not installable here), on a bounded sample of events."""
+    import torch
+
+    from deepmetv2_amd import synth
+    from oracle import ref_model, ref_ops
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n_ev = args.cpu_sample_events or max(2, min(16, cores))
+    x, y, batch, ptr = synth.make_events([args.nodes] * n_ev, seed=seed)
+    torch.manual_seed(0)
+    model = ref_model.RefNet(8, 3, graph="dynamic", k=args.k).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+
+    def step():
+        opt.zero_grad()
+        w = model(x[:, :8], x[:, 8:].long(), None, batch)
+        loss = ref_ops.loss_fn(w, x, y, batch)
+        if args.mode == "train":
+            loss.backward()
+            opt.step()
+        return float(loss)
+
+    step()  # warm-up (builds the C oracle, pages in)
+    reps, t0 = 0, time.perf_counter()
+    while reps < 2 or (time.perf_counter() - t0 < 8.0 and reps < 10):
+        step()
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": n_ev / dt, "unit": "events/s", "cores": cores, "kind": "port",
+            "sample": f"{n_ev} events x {args.nodes} nodes, k={args.k}, 2 layers, {args.mode} step, {reps} reps "
+                      f"({dt:.2f} s/step); oracle/ref_model.py + C kNN (OpenMP over events) on {cores} threads"}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU path in the product)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import _native, synth
+    from deepmetv2_amd.model import Net, loss_fn, split_features
+    from deepmetv2_amd.parallel import FlatModule, GradSync, train_step
+
+    B, n, k = args.events_per_gpu, args.nodes, args.k
+    x, y, batch, ptr = synth.make_events([n] * B, seed=1234 + rank, device=dev)
+    dm.register_batch(batch, ptr, B)
+    N = x.shape[0]
+
+    torch.manual_seed(0)
+    model = Net(8, 3, graph="dynamic", k=k).to(dev)
+    flat = FlatModule(model)
+    sync = GradSync(flat)
+    sync.broadcast_state(0)
+    opt = torch.optim.AdamW([flat.flat_param], lr=1e-3)
+
+    if args.mode == "train":
+        model.train()
+
+        def step():
+            return train_step(model, flat, sync, opt, x, y, batch, ptr)
+    else:
+        model.eval()
+
+        def step():
+            with torch.no_grad():
+                xc, xk = split_features(x)
+                w = model(xc, xk, None, batch)
+                return dm.met_reduce(w, x, ptr=ptr)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    _native.timer.enabled = True
+    _native.timer.reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _native.timer.enabled = False
+    ksum = _native.timer.summary()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        events = B * world * args.steps
+        # roofline of the north-star kernel: fused gather + max (algorithmic bytes per node, SURVEY 8d / BASELINE.md:
+        # own P row H*4 + neighbour ids k*4 + output row H*4 [+ arg H*1 when training; the table says H*4, we
+        # store the winning slot in one byte])
+        H = 32
+        per_node = H * 4 + k * 4 + H * 4 + (H if args.mode == "train" else 0)
+        alg_bytes = per_node * N
+        roof = None
+        if "gather_max" in ksum:
+            ms = ksum["gather_max"][1]
+            ach = alg_bytes / (ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_gather_max.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"kernel": "gather_max_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(ms * 1e3, 2),
+                    "launches": ksum["gather_max"][0]}
+        kernels = {}
+        for name, (cnt, ms) in sorted(ksum.items()):
+            kernels[name] = {"launches": cnt, "avg_us": round(ms * 1e3, 2)}
+        if "knn" in ksum:
+            flops = 3.0 * B * n * n * 32           # sub, mul, add per (query, candidate, feature); D = 32
+            tf = flops / (ksum["knn"][1] * 1e-3) / 1e12
+            kernels["knn"].update({"bound": "fp32_valu", "achieved_tflops": round(tf, 2),
+                                   "peak_tflops": FP32_VALU_PEAK_TFLOPS, "frac": round(tf / FP32_VALU_PEAK_TFLOPS, 4)})
+        out = {
+            "metric": "events/sec (4.5k PF cands, k=16)", "value": round(events / elapsed, 1), "unit": "events/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {B} events/GPU x {n} PF candidates x 11 features, k={k}, "
+                                   f"2 DynamicEdgeConv layers (kNN rebuilt per layer in the 32-d embedding), fp32, "
+                                   f"{args.mode} step", "events_per_gpu": B, "nodes_per_event": n, "k": k,
+                       "global_batch": B * world, "mode": args.mode, "parallelism": f"dp{world}"},
+            "roofline": roof, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, seed=1234)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

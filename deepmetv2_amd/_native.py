@@ -42,6 +42,38 @@ def _ws(nbytes: int, dev: torch.device) -> torch.Tensor:
     return torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=dev)
 
 
+class KernelTimer:
+    """Optional HIP-event bracket around named native calls, recorded on the stream the kernel is launched on
+    (bench.py turns it on for the roofline figure; costs two event records per call, no synchronisation)."""
+
+    def __init__(self):
+        self.enabled = False
+        self._pending = {}
+
+    def reset(self) -> None:
+        self._pending = {}
+
+    def record(self, name: str, dev: torch.device):
+        if not self.enabled:
+            return None
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record(torch.cuda.current_stream(dev))
+        self._pending.setdefault(name, []).append((a, b))
+        return b
+
+    def summary(self) -> dict:
+        """{name: (launches, mean_ms)} -- call after a device synchronise."""
+        out = {}
+        for name, pairs in self._pending.items():
+            ts = [a.elapsed_time(b) for a, b in pairs]
+            out[name] = (len(ts), sum(ts) / max(len(ts), 1))
+        return out
+
+
+timer = KernelTimer()
+
+
 # ---- K1 ------------------------------------------------------------------------------------------------------
 def knn(x: torch.Tensor, ptr: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """nbr[N,k] int32 (global ids, -1 padded), dist[N,k] fp32."""
@@ -56,9 +88,12 @@ def knn(x: torch.Tensor, ptr: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch
     dist = torch.empty((N, k), dtype=torch.float32, device=dev)
     nb = L.dmet_knn_workspace_bytes(N, B, D, k)
     ws = _ws(nb, dev)
+    _t = timer.record('knn', dev)
     with torch.cuda.device(dev):
         _lib.check(L.dmet_knn_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, k, nbr.data_ptr(), dist.data_ptr(),
                                   ws.data_ptr(), ws.numel(), _stream(dev)), "dmet_knn_f32")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
     return nbr, dist
 
 
@@ -87,9 +122,12 @@ def node_linear_split(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor
         raise ValueError(f"W must be [Hout, 2*Hin] = [*, {2 * Hin}], got {tuple(W.shape)}")
     PQ = torch.empty((2, N, Hout), dtype=torch.float32, device=dev)
     bp = _f32c(b, "b").data_ptr() if b is not None else None
+    _t = timer.record('node_linear_split', dev)
     with torch.cuda.device(dev):
         _lib.check(L.dmet_node_linear_split_f32(x.data_ptr(), N, Hin, Hout, W.data_ptr(), bp, PQ[0].data_ptr(),
                                                 PQ[1].data_ptr(), _stream(dev)), "dmet_node_linear_split_f32")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
     return PQ[0], PQ[1]
 
 
@@ -101,11 +139,14 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
     k = nbr.shape[1]
     out = torch.empty((N, H), dtype=torch.float32, device=dev)
     arg = torch.empty((N, H), dtype=torch.uint8, device=dev) if want_arg else None
+    _t = timer.record('gather_max', dev)
     with torch.cuda.device(dev):
         _lib.check(L.dmet_gather_max_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(),
                                          ptr.data_ptr() if ptr is not None else None,
                                          (ptr.numel() - 1) if ptr is not None else 0, N, k, H, out.data_ptr(),
                                          arg.data_ptr() if want_arg else None, _stream(dev)), "dmet_gather_max_f32")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
     return out, arg
 
 
@@ -116,10 +157,13 @@ def gather_max_bwd(g_out: torch.Tensor, arg: torch.Tensor, rev_ptr: torch.Tensor
     g_out = _f32c(g_out, "g_out")
     N, H = g_out.shape
     gQ = torch.empty((N, H), dtype=torch.float32, device=dev)
+    _t = timer.record('gather_max_bwd', dev)
     with torch.cuda.device(dev):
         _lib.check(L.dmet_gather_max_bwd_f32(g_out.data_ptr(), arg.data_ptr(), rev_ptr.data_ptr(),
                                              rev_slot.data_ptr(), N, k, H, gQ.data_ptr(), _stream(dev)),
                    "dmet_gather_max_bwd_f32")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
     return gQ
 
 
@@ -132,10 +176,13 @@ def reverse_index(keys: torch.Tensor, num_keys: int) -> Tuple[torch.Tensor, torc
     M = keys.numel()
     rev_ptr = torch.empty((num_keys + 1,), dtype=torch.int32, device=dev)
     rev_pos = torch.empty((max(M, 1),), dtype=torch.int32, device=dev)
+    _t = timer.record('reverse_index', dev)
     with torch.cuda.device(dev):
         ws = _ws(L.dmet_reverse_index_workspace_bytes(M, num_keys), dev)
         _lib.check(L.dmet_reverse_index(keys.data_ptr(), M, num_keys, rev_ptr.data_ptr(), rev_pos.data_ptr(),
                                         ws.data_ptr(), ws.numel(), _stream(dev)), "dmet_reverse_index")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
     return rev_ptr, rev_pos
 
 
@@ -224,9 +271,12 @@ def met_reduce(w: torch.Tensor, x: torch.Tensor, ptr: torch.Tensor) -> torch.Ten
         raise TypeError("x must be float32 [N, F>=2] with unit inner stride")
     B = ptr.numel() - 1
     met = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    _t = timer.record('met_reduce', dev)
     with torch.cuda.device(dev):
         _lib.check(L.dmet_met_reduce_f32(w.data_ptr(), x.data_ptr(), x.stride(0), ptr.data_ptr(), B, met.data_ptr(),
                                          _stream(dev)), "dmet_met_reduce_f32")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
     return met
 
 

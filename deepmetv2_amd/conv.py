@@ -140,7 +140,7 @@ class EdgeConv(torch.nn.Module):
     # -- the two execution paths ---------------------------------------------------------------------------
     def _forward_table(self, x: torch.Tensor, table: NeighborTable) -> torch.Tensor:
         lin = _as_fusable_linear(self.nn) if self.aggr == "max" else None
-        if lin is not None and x.shape[1] * 2 == lin.in_features:
+        if lin is not None and x.shape[1] * 2 == lin.in_features and table.k <= 255:  # arg slot is uint8
             return _EdgeConvLinearMax.apply(x, lin.weight, lin.bias, table)
         return self._forward_edges(x, table.edge_list())
 

@@ -305,7 +305,7 @@ extern "C" int dmet_gather_max_f32(const float *P, const float *Q, const int32_t
 {
     (void)ptr; (void)B;
     DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_gather_max_f32: N out of range");
-    DMET_REQUIRE(k >= 1 && k <= 254, "dmet_gather_max_f32: k=%d not in [1,254]", k);
+    DMET_REQUIRE(k >= 1 && k <= 255, "dmet_gather_max_f32: k=%d not in [1,255] (arg is uint8, 255 = none)", k);
     if (N == 0) return 0;
     DMET_REQUIRE(P && Q && nbr && out, "dmet_gather_max_f32: null pointer");
     DMET_REQUIRE(aligned16(P) && aligned16(Q) && aligned16(out), "dmet_gather_max_f32: pointers must be 16-B aligned");

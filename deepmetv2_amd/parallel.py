@@ -1,0 +1,112 @@
+"""Data parallelism over events: one process per GPU, a single flat gradient all-reduce per step (RCCL over xGMI).
+
+The reference is single-process (train.py:72); events are independent graphs (neighbourhoods never cross the
+`batch` boundaries, MET is per event), so the batch shards with no exchange in forward.  The whole model has 6 641
+parameters: the per-step collective is ONE all-reduce of a 26.6 KB fp32 buffer, latency-bound, so there is no
+bucketing or overlap machinery -- parameters and gradients live in two flat buffers and the collective runs on
+the flat gradient right after backward.  BatchNorm statistics stay per rank.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(num_items: int, rank: int, world: int) -> range:
+    """Contiguous block of items for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(num_items, world)
+    lo = rank * base + min(rank, rem)
+    return range(lo, lo + base + (1 if rank < rem else 0))
+
+
+def balanced_shards(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Ragged events: greedy longest-first assignment by cost (kNN cost ~ n_b^2), deterministic."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads = [0.0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda w: (loads[w], w))
+        out[r].append(i)
+        loads[r] += costs[i]
+    return [sorted(s) for s in out]
+
+
+class FlatModule:
+    """Re-homes every parameter (and its gradient) of `module` into two contiguous fp32 buffers.
+
+    `flat_param` / `flat_grad` alias the module's parameters, so one optimizer tensor, one zero_() and one
+    all_reduce() cover the whole model.  Parameter names/shapes (state_dict) are unchanged.
+    """
+
+    def __init__(self, module: torch.nn.Module):
+        self.module = module
+        params = [p for p in module.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("module has no trainable parameters")
+        dev, dt = params[0].device, params[0].dtype
+        total = sum(p.numel() for p in params)
+        self.flat_param = torch.nn.Parameter(torch.empty(total, device=dev, dtype=dt))
+        self.flat_param.grad = torch.zeros(total, device=dev, dtype=dt)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                self.flat_param.data[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat_param.data[off:off + n].view_as(p)
+                p.grad = self.flat_param.grad[off:off + n].view_as(p)
+                off += n
+        self.params = params
+        self.numel = total
+
+    @property
+    def flat_grad(self) -> torch.Tensor:
+        return self.flat_param.grad
+
+    def zero_grad(self) -> None:
+        self.flat_param.grad.zero_()
+
+    def buffers(self) -> List[torch.Tensor]:
+        return [b for b in self.module.buffers()]
+
+
+class GradSync:
+    """DDP semantics for a FlatModule: broadcast parameters+buffers from rank 0 once, then average gradients."""
+
+    def __init__(self, flat: FlatModule, group: Optional[dist.ProcessGroup] = None):
+        self.flat = flat
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+    def broadcast_state(self, src: int = 0) -> None:
+        if self.world == 1:
+            return
+        dist.broadcast(self.flat.flat_param.data, src=src, group=self.group)
+        for b in self.flat.buffers():
+            dist.broadcast(b, src=src, group=self.group)
+
+    def average_gradients(self) -> None:
+        """Loss is a mean over the rank's events; with equal events per rank the mean of rank-gradients is the
+        gradient of the global mean (model/net.py:60)."""
+        if self.world == 1:
+            return
+        dist.all_reduce(self.flat.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.flat_grad.div_(self.world)
+
+
+def train_step(model: torch.nn.Module, flat: FlatModule, sync: GradSync, optimizer: torch.optim.Optimizer,
+               x: torch.Tensor, y: torch.Tensor, batch: torch.Tensor, ptr: Optional[torch.Tensor] = None,
+               edge_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One training step, the sequence of /root/reference/train.py:40-52:
+    zero_grad -> split features -> model -> loss_fn -> backward -> (all-reduce) -> optimizer.step."""
+    from .model import loss_fn, split_features
+
+    flat.zero_grad()
+    x_cont, x_cat = split_features(x)
+    weights = model(x_cont, x_cat, edge_index, batch)
+    loss = loss_fn(weights, x, y, batch, ptr=ptr)
+    loss.backward()
+    sync.average_gradients()
+    optimizer.step()
+    return loss.detach()
