@@ -9,7 +9,8 @@ import os
 import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libdmet_hip.so")
+# DMET_HIP_LIB lets a developer A/B an experimental build of the same ABI (tools/); the default is the in-tree .so
+LIB_PATH = os.environ.get("DMET_HIP_LIB") or os.path.join(_PKG_DIR, "libdmet_hip.so")
 
 _lock = threading.Lock()
 _lib = None

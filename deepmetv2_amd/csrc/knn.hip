@@ -5,30 +5,43 @@
 //   R1  d(i,j) = chain of fmaf(diff, diff, acc) over the feature index, fp32, diff = x[j,c]-x[i,c]
 //   R2  top-k by (d, j) lexicographic order == upstream's strict-'>' insertion in ascending j
 //
-// Work decomposition (fp32-VALU bound: 2 VALU ops per (query, candidate, feature)):
-//   * one 64-lane wavefront per workgroup; every lane OWNS TQ query nodes whose features sit in registers;
-//   * candidate rows of the event are staged into LDS in tiles and read back as wave-uniform (broadcast)
-//     ds_read_b128, so one LDS read feeds 64*TQ lanes-queries (TQ = 2 keeps the LDS pipe at ~50%);
-//   * selection is deferred: a lane whose distance beats its current k-th best appends (d, j) to its private
-//     LDS queue; when any lane's queue is nearly full the whole wave drains its queues into the sorted top-k
-//     lists, which live in an L2-resident global workspace between drains (keeps VGPRs for the distance loop);
-//   * queries are assigned by global node index, so a wavefront may straddle two events: it then sweeps the
-//     union of their candidate ranges and masks per lane (taken only by boundary wavefronts).
+// The kernel is fp32-VALU bound (a subtract and an fma per (query, candidate, feature); the difference form
+// cannot go to the matrix cores without changing the rounding).  Measured on MI355X (tools/valu_micro.hip) this
+// instruction mix saturates at ~75-80 TFLOP/s (3 flop per element) and needs packed math plus >= 3 wavefronts per
+// SIMD to get there, which shapes the design:
+//   * one 64-lane wavefront per workgroup; every lane OWNS 2 query nodes whose features sit in registers as
+//     float2 pairs, so the inner loop is v_pk_add_f32 / v_pk_fma_f32 (each half is an exact IEEE op: same bits);
+//   * candidate rows are staged into LDS in tiles and read back as wave-uniform (broadcast) ds_read_b128; two
+//     candidates are in flight per iteration (two independent fma chains per lane);
+//   * selection is deferred: a lane whose distance beats its current k-th best appends (d, j) to its private LDS
+//     queue; when any lane's queue is nearly full the whole wave drains its queues into the sorted top-k lists,
+//     which live in an L2-resident global workspace between drains (keeps VGPRs for the distance loop);
+//   * queries are assigned by global node index, so a wavefront may straddle two events: it then sweeps the union
+//     of their candidate ranges and masks per lane (taken only by boundary wavefronts);
+//   * load balance: all query tiles cost the same, so with T tiles on S SIMDs the last (T mod S) tiles would leave
+//     most of the chip idle for a whole sweep.  Those tail tiles are split over the candidate range into `split`
+//     sub-sweeps (separate workgroups, dispatched last) whose partial top-k lists a small merge kernel combines.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dmet {
 namespace {
 
-constexpr int kTileC = 32;   // candidates per LDS tile
-constexpr int kQMax = 12;    // per-lane pending queue capacity
+typedef float f2 __attribute__((ext_vector_type(2)));
 
-template <int DP, int KP, int TQ>
+constexpr int kTileC = 32;   // candidates per LDS tile
+constexpr int kQMax = 8;     // per-lane pending queue capacity
+constexpr int kMaxSplit = 8; // tail tiles are split into at most this many candidate sub-sweeps
+
+template <int DP, int TQ>
 struct KnnShared {
-    float4 tile[(kTileC + 2) * DP / 4];  // +2 rows: the pipelined sweep reads up to two rows ahead
+    float4 tile[(kTileC + 1) * DP / 4];  // +1 row kept at +inf: the paired sweep reads one row past the tile's last
     uint2 queue[TQ][kQMax][kWave];
 };
 
-// Drain lane-private queue `qslot` into the sorted list of the lane's query (list kept in ws between drains).
+// Drain a lane-private queue into the sorted list of the lane's query (list kept in ws between drains).
+// Returns the lane's new admission threshold (its k-th best distance).
 template <int KP>
 __device__ __attribute__((noinline)) float drain_queue(const uint2 (*queue)[kWave], int lane, int cnt, bool fresh,
                                                        bool valid, float *__restrict__ ld,
@@ -78,198 +91,428 @@ __device__ __attribute__((noinline)) float drain_queue(const uint2 (*queue)[kWav
             *reinterpret_cast<int4 *>(lj + p) = make_int4(j[p], j[p + 1], j[p + 2], j[p + 3]);
         }
     }
-    return d[KP - 1];  // the new k-th best = the lane's new admission threshold
+    return d[KP - 1];
+}
+
+#ifdef DMET_KNN_STAMP
+// experiment only (tools/knn_trace.hip): per-workgroup start/end realtime stamps and hardware placement
+__device__ unsigned long long g_knn_stamps[1 << 16][4];
+#endif
+
+// Device-side launch plan (no host synchronisation): tiles never straddle events, so tile -> event needs a prefix.
+struct KnnPlan {
+    int total_tiles;   // sum_b ceil(n_b / tile_queries)
+    int n_full;        // tiles 0..n_full-1 sweep their whole event in one workgroup
+    int split;         // tiles n_full.. are cut into `split` candidate sub-sweeps each (tail balancing)
+    int pad;
+};
+
+struct KnnArgs {
+    const float *x;
+    const int64_t *ptr;
+    int B;
+    int64_t N;
+    int D, k;
+    int32_t *nbr;
+    float *dist;
+    float *wsd;            // [N][KP] running lists of whole-sweep tiles
+    int32_t *wsj;
+    const KnnPlan *plan;
+    const int32_t *tile_ptr;  // [B+1] exclusive prefix of per-event tile counts
+    float *psd;            // [(tile-n_full)*tile_queries + slot][split][KP] partial lists of split tiles
+    int32_t *psj;
+};
+
+// One workgroup: per-event tile counts -> exclusive prefix, then the tail-splitting plan for `simds` SIMDs:
+// whole sweeps for the largest multiple of the SIMD count, the remaining tiles cut into sub-sweeps.
+__global__ __launch_bounds__(256) void knn_plan_kernel(const int64_t *__restrict__ ptr, int B, int tile_queries,
+                                                        int simds, int32_t *__restrict__ tile_ptr,
+                                                        KnnPlan *__restrict__ plan)
+{
+    __shared__ int part[256];
+    const int tid = threadIdx.x;
+    const int chunk = (B + 255) / 256;
+    const int lo = min(B, tid * chunk), hi = min(B, lo + chunk);
+    int sum = 0;
+    for (int b = lo; b < hi; ++b) sum += (int)((ptr[b + 1] - ptr[b] + tile_queries - 1) / tile_queries);
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        const int tiles = run;
+        int n_full = tiles, split = 1;
+        if (tiles > simds) {
+            const int full = (tiles / simds) * simds;
+            const int rem = tiles - full;
+            if (rem > 0) {
+                int f = simds / rem;
+                if (f > kMaxSplit) f = kMaxSplit;
+                if (f >= 2) { n_full = full; split = f; }
+            }
+        }
+        plan->total_tiles = tiles; plan->n_full = n_full; plan->split = split; plan->pad = 0;
+        tile_ptr[B] = tiles;
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int b = lo; b < hi; ++b) {
+        tile_ptr[b] = run;
+        run += (int)((ptr[b + 1] - ptr[b] + tile_queries - 1) / tile_queries);
+    }
+}
+
+// Event that owns tile t: the b with tile_ptr[b] <= t < tile_ptr[b+1] (events without tiles are skipped).
+__device__ __forceinline__ int find_tile_event(const int32_t *__restrict__ tile_ptr, int B, int t)
+{
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tile_ptr[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Global -> registers copy of one candidate tile (cntc rows of DP floats; missing rows become +inf).
+template <int DP, bool EXACT_D, int NLD>
+__device__ __forceinline__ void load_tile(float4 (&pf)[NLD], const float *__restrict__ x, int D, int c0, int cntc,
+                                          int lane)
+{
+    const float inf = __builtin_inff();
+    if (EXACT_D) {
+        const float4 *g = reinterpret_cast<const float4 *>(x + (int64_t)c0 * DP);
+        const int n4 = cntc * (DP / 4);
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int idx = lane + m * kWave;
+            pf[m] = (idx < n4) ? g[idx] : make_float4(inf, inf, inf, inf);
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int flat = (lane + m * kWave) * 4 + e;
+                const int c = flat / DP, dd = flat - c * DP;
+                v[e] = (c < cntc) ? ((dd < D) ? x[(int64_t)(c0 + c) * D + dd] : 0.0f) : inf;
+            }
+            pf[m] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
 }
 
 template <int DP, int KP, int TQ, bool EXACT_D>
-__global__ __launch_bounds__(kWave, 2) void knn_kernel(const float *__restrict__ x,
-                                                     const int64_t *__restrict__ ptr, int B, int64_t N, int D,
-                                                     int k, int32_t *__restrict__ nbr,
-                                                     float *__restrict__ dist, float *__restrict__ wsd,
-                                                     int32_t *__restrict__ wsj)
+__global__ __launch_bounds__(kWave, 3) void knn_kernel(const KnnArgs a)
 {
-    __shared__ KnnShared<DP, KP, TQ> sh;
+    __shared__ KnnShared<DP, TQ> sh;
+#ifdef DMET_KNN_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < (1 << 16)) {
+        g_knn_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_knn_stamps[blockIdx.x][2] = hwid;
+        g_knn_stamps[blockIdx.x][3] = xcc;
+        g_knn_stamps[blockIdx.x][1] = 0;
+    }
+#endif
+    const float *__restrict__ x = a.x;
+    const int64_t *__restrict__ ptr = a.ptr;
     const int lane = threadIdx.x;
-    const int64_t q_first = (int64_t)blockIdx.x * (kWave * TQ);
-    if (q_first >= N) return;
-    const int64_t q_last = min(N, q_first + kWave * TQ) - 1;
+    const int D = a.D;
+    constexpr int QT = kWave * TQ;  // queries per tile
 
-    // wave-uniform candidate range = union of the events this wavefront's queries live in
-    const int b_first = find_event(ptr, B, q_first);
-    const int b_last = find_event(ptr, B, q_last);
-    const int clo = (int)ptr[b_first];
-    const int chi = (int)ptr[b_last + 1];
-    const bool single = (b_first == b_last);
+    // which (query tile, candidate sub-sweep) is this workgroup?  (plan lives in device memory)
+    const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
+    int tile = blockIdx.x, sub = 0, nsub = 1;
+    if ((int)blockIdx.x >= n_full) {
+        const int r = blockIdx.x - n_full;
+        tile = n_full + r / split;
+        sub = r % split;
+        nsub = split;
+    }
+    if (tile >= total) return;
+    const int ev = find_tile_event(a.tile_ptr, a.B, tile);
+    const int ev_lo = (int)ptr[ev], ev_hi = (int)ptr[ev + 1];
+    const int q_first = ev_lo + (tile - a.tile_ptr[ev]) * QT;
 
-    float q[TQ][DP];
-    int64_t qi[TQ];
+    // candidate range = the tile's own event (or one chunk of it for a split tile)
+    int clo = ev_lo, chi = ev_hi;
+    if (nsub > 1) {
+        const int chunk = (((chi - clo) + nsub - 1) / nsub + 1) & ~1;  // even: candidate pairs never straddle chunks
+        clo = min(chi, clo + sub * chunk);
+        chi = min(chi, clo + chunk);
+    }
+
+    int qi[TQ];
     bool valid[TQ];
-    int lo[TQ], hi[TQ];
     float tau[TQ];
     int cnt[TQ];
+    float *ld[TQ];
+    int32_t *lj[TQ];
+    f2 q2[(TQ == 2) ? DP : 1];
+    float q1[(TQ == 1) ? DP : 1];
 #pragma unroll
     for (int t = 0; t < TQ; ++t) {
         qi[t] = q_first + t * kWave + lane;
-        valid[t] = qi[t] < N;
-        const int64_t qq = valid[t] ? qi[t] : q_last;
-        if (single) { lo[t] = clo; hi[t] = chi; }
-        else { const int b = find_event(ptr, B, qq); lo[t] = (int)ptr[b]; hi[t] = (int)ptr[b + 1]; }
-        if (!valid[t]) { lo[t] = 0; hi[t] = 0; }
-        if (EXACT_D) {
+        valid[t] = qi[t] < ev_hi;
+        const int64_t qq = valid[t] ? qi[t] : ev_lo;
 #pragma unroll
-            for (int c = 0; c < DP; c += 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(x + qq * DP + c);
-                q[t][c] = v.x; q[t][c + 1] = v.y; q[t][c + 2] = v.z; q[t][c + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < DP; ++c) q[t][c] = (c < D) ? x[qq * D + c] : 0.0f;
+        for (int c = 0; c < DP; ++c) {
+            float v;
+            if (EXACT_D) v = x[qq * DP + c]; else v = (c < D) ? x[qq * D + c] : 0.0f;
+            if (TQ == 2) { if (t == 0) q2[c].x = v; else q2[c].y = v; }
+            else q1[c] = v;
         }
-        tau[t] = kKnnSentinel;
+        tau[t] = valid[t] ? kKnnSentinel : -1.0f;  // a distance is never < -1: idle lanes admit nothing
         cnt[t] = 0;
+        if (nsub == 1) {
+            ld[t] = a.wsd + qq * KP;
+            lj[t] = a.wsj + qq * KP;
+        } else {
+            const int64_t slot = (int64_t)(tile - n_full) * QT + t * kWave + lane;
+            ld[t] = a.psd + (slot * nsub + sub) * KP;
+            lj[t] = a.psj + (slot * nsub + sub) * KP;
+        }
     }
     unsigned fresh = (1u << TQ) - 1u;  // wave-uniform: list of slot t not yet written to ws
 
-    constexpr int kLd4 = kTileC * DP / 4;            // float4s per tile
+    constexpr int kLd4 = kTileC * DP / 4;  // float4s per tile
     constexpr int kLdPerLane = (kLd4 + kWave - 1) / kWave;
+    const float inf = __builtin_inff();
+    const float4 inf4 = make_float4(inf, inf, inf, inf);
+    // row kTileC is a permanent +inf row: the paired sweep may read one row past a full tile, and rows past a
+    // partial tile are filled with +inf too, so such candidates get d = +inf and are never admitted
+    for (int i = lane; i < DP / 4; i += kWave) sh.tile[kLd4 + i] = inf4;
 
+    float4 pf[kLdPerLane];  // next tile, prefetched into registers while the current one is swept
+#pragma unroll
+    for (int m = 0; m < kLdPerLane; ++m) pf[m] = inf4;
+    if (clo < chi) load_tile<DP, EXACT_D, kLdPerLane>(pf, x, D, clo, min(kTileC, chi - clo), lane);
 
     for (int c0 = clo; c0 < chi; c0 += kTileC) {
         const int cntc = min(kTileC, chi - c0);
         __syncthreads();  // every lane is done reading the previous tile
-        if (EXACT_D) {
-            const float4 *g = reinterpret_cast<const float4 *>(x + (int64_t)c0 * DP);
-            const int n4 = cntc * (DP / 4);
 #pragma unroll
-            for (int m = 0; m < kLdPerLane; ++m) {
-                const int idx = lane + m * kWave;
-                if (idx < kLd4) sh.tile[idx] = (idx < n4) ? g[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        } else {
-            float *tl = reinterpret_cast<float *>(sh.tile);
-            for (int e = lane; e < kTileC * DP; e += kWave) {
-                const int c = e / DP, dd = e - c * DP;
-                tl[e] = (c < cntc && dd < D) ? x[(int64_t)(c0 + c) * D + dd] : 0.0f;
-            }
+        for (int m = 0; m < kLdPerLane; ++m) {
+            const int idx = lane + m * kWave;
+            if (idx < kLd4) sh.tile[idx] = pf[m];
         }
         __syncthreads();
+        if (c0 + kTileC < chi)
+            load_tile<DP, EXACT_D, kLdPerLane>(pf, x, D, c0 + kTileC, min(kTileC, chi - c0 - kTileC), lane);
 
-        // software-pipelined sweep: candidate rows A (cc) and B (cc+1) alternate between two register sets
-        float4 rowA[DP / 4], rowB[DP / 4];
-#pragma unroll
-        for (int c4 = 0; c4 < DP / 4; ++c4) rowA[c4] = sh.tile[c4];
         for (int cc = 0; cc < cntc; cc += 2) {
-            float accA[TQ], accB[TQ];
+            float dA[TQ], dB[TQ];
+            if (TQ == 2) {
+                f2 accA = {0.0f, 0.0f}, accB = {0.0f, 0.0f};
 #pragma unroll
-            for (int c4 = 0; c4 < DP / 4; ++c4) rowB[c4] = sh.tile[(cc + 1) * (DP / 4) + c4];  // broadcast reads
-#pragma unroll
-            for (int t = 0; t < TQ; ++t) accA[t] = 0.0f;
-#pragma unroll
-            for (int c4 = 0; c4 < DP / 4; ++c4) {
-#pragma unroll
-                for (int t = 0; t < TQ; ++t) {
-                    float df;
-                    df = rowA[c4].x - q[t][4 * c4 + 0]; accA[t] = __builtin_fmaf(df, df, accA[t]);
-                    df = rowA[c4].y - q[t][4 * c4 + 1]; accA[t] = __builtin_fmaf(df, df, accA[t]);
-                    df = rowA[c4].z - q[t][4 * c4 + 2]; accA[t] = __builtin_fmaf(df, df, accA[t]);
-                    df = rowA[c4].w - q[t][4 * c4 + 3]; accA[t] = __builtin_fmaf(df, df, accA[t]);
+                for (int c4 = 0; c4 < DP / 4; ++c4) {
+                    const float4 v = sh.tile[cc * (DP / 4) + c4];        // wave-uniform address: LDS broadcast
+                    const float4 w = sh.tile[(cc + 1) * (DP / 4) + c4];
+                    f2 df;
+                    df = (f2){v.x, v.x} - q2[4 * c4 + 0]; accA = __builtin_elementwise_fma(df, df, accA);
+                    df = (f2){w.x, w.x} - q2[4 * c4 + 0]; accB = __builtin_elementwise_fma(df, df, accB);
+                    df = (f2){v.y, v.y} - q2[4 * c4 + 1]; accA = __builtin_elementwise_fma(df, df, accA);
+                    df = (f2){w.y, w.y} - q2[4 * c4 + 1]; accB = __builtin_elementwise_fma(df, df, accB);
+                    df = (f2){v.z, v.z} - q2[4 * c4 + 2]; accA = __builtin_elementwise_fma(df, df, accA);
+                    df = (f2){w.z, w.z} - q2[4 * c4 + 2]; accB = __builtin_elementwise_fma(df, df, accB);
+                    df = (f2){v.w, v.w} - q2[4 * c4 + 3]; accA = __builtin_elementwise_fma(df, df, accA);
+                    df = (f2){w.w, w.w} - q2[4 * c4 + 3]; accB = __builtin_elementwise_fma(df, df, accB);
                 }
-            }
+                dA[0] = accA.x; dB[0] = accB.x;
+                dA[TQ - 1] = accA.y; dB[TQ - 1] = accB.y;
+            } else {
+                float accA = 0.0f, accB = 0.0f;
 #pragma unroll
-            for (int c4 = 0; c4 < DP / 4; ++c4) rowA[c4] = sh.tile[(cc + 2) * (DP / 4) + c4];
-#pragma unroll
-            for (int t = 0; t < TQ; ++t) accB[t] = 0.0f;
-#pragma unroll
-            for (int c4 = 0; c4 < DP / 4; ++c4) {
-#pragma unroll
-                for (int t = 0; t < TQ; ++t) {
+                for (int c4 = 0; c4 < DP / 4; ++c4) {
+                    const float4 v = sh.tile[cc * (DP / 4) + c4];
+                    const float4 w = sh.tile[(cc + 1) * (DP / 4) + c4];
                     float df;
-                    df = rowB[c4].x - q[t][4 * c4 + 0]; accB[t] = __builtin_fmaf(df, df, accB[t]);
-                    df = rowB[c4].y - q[t][4 * c4 + 1]; accB[t] = __builtin_fmaf(df, df, accB[t]);
-                    df = rowB[c4].z - q[t][4 * c4 + 2]; accB[t] = __builtin_fmaf(df, df, accB[t]);
-                    df = rowB[c4].w - q[t][4 * c4 + 3]; accB[t] = __builtin_fmaf(df, df, accB[t]);
+                    df = v.x - q1[4 * c4 + 0]; accA = __builtin_fmaf(df, df, accA);
+                    df = w.x - q1[4 * c4 + 0]; accB = __builtin_fmaf(df, df, accB);
+                    df = v.y - q1[4 * c4 + 1]; accA = __builtin_fmaf(df, df, accA);
+                    df = w.y - q1[4 * c4 + 1]; accB = __builtin_fmaf(df, df, accB);
+                    df = v.z - q1[4 * c4 + 2]; accA = __builtin_fmaf(df, df, accA);
+                    df = w.z - q1[4 * c4 + 2]; accB = __builtin_fmaf(df, df, accB);
+                    df = v.w - q1[4 * c4 + 3]; accA = __builtin_fmaf(df, df, accA);
+                    df = w.w - q1[4 * c4 + 3]; accB = __builtin_fmaf(df, df, accB);
                 }
+                dA[0] = accA; dB[0] = accB;
             }
-            // selection; a row past the event's end (odd tail / tile padding) has j >= hi and never passes
 #pragma unroll
             for (int t = 0; t < TQ; ++t) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int j = c0 + cc + u;
-                    const float dj = u ? accB[t] : accA[t];
+                    const float dj = u ? dB[t] : dA[t];
                     bool pass = dj < tau[t];
-                    if (single) pass = pass && (j < hi[t]);
-                    else pass = pass && (j >= lo[t]) && (j < hi[t]);
+#ifdef DMET_KNN_NOSELECT
+                    pass = pass && (dj < -1.0f);   // experiment: distance sweep only
+#endif
                     if (pass) {
-                        sh.queue[t][cnt[t]][lane] = make_uint2(__float_as_uint(dj), (unsigned)j);
+                        sh.queue[t][cnt[t]][lane] = make_uint2(__float_as_uint(dj), (unsigned)(c0 + cc + u));
                         cnt[t]++;
                     }
                 }
                 if (__any(cnt[t] > kQMax - 2)) {
-                    const int64_t qq = valid[t] ? qi[t] : 0;
-                    tau[t] = drain_queue<KP>(sh.queue[t], lane, cnt[t], (fresh >> t) & 1u, valid[t], wsd + qq * KP,
-                                             wsj + qq * KP);
+                    tau[t] = drain_queue<KP>(sh.queue[t], lane, cnt[t], (fresh >> t) & 1u, valid[t], ld[t], lj[t]);
+                    if (!valid[t]) tau[t] = -1.0f;
                     cnt[t] = 0;
                     fresh &= ~(1u << t);
                 }
             }
         }
     }
-
-    // final drain + output of the first k entries
+#ifdef DMET_KNN_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < (1 << 16)) g_knn_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    // final drain; whole-sweep tiles also emit the first k entries
 #pragma unroll
     for (int t = 0; t < TQ; ++t) {
-        const int64_t qq = valid[t] ? qi[t] : 0;
-        tau[t] = drain_queue<KP>(sh.queue[t], lane, cnt[t], (fresh >> t) & 1u, valid[t], wsd + qq * KP,
-                                 wsj + qq * KP);
-        if (valid[t]) {
-            if (k == KP) {
+        (void)drain_queue<KP>(sh.queue[t], lane, cnt[t], (fresh >> t) & 1u, valid[t], ld[t], lj[t]);
+        if (valid[t] && nsub == 1) {
+            const int64_t qq = qi[t];
+            if (a.k == KP) {
 #pragma unroll
                 for (int p = 0; p < KP; p += 4) {
-                    *reinterpret_cast<float4 *>(dist + qq * KP + p) =
-                        *reinterpret_cast<const float4 *>(wsd + qq * KP + p);
-                    *reinterpret_cast<int4 *>(nbr + qq * KP + p) =
-                        *reinterpret_cast<const int4 *>(wsj + qq * KP + p);
+                    *reinterpret_cast<float4 *>(a.dist + qq * KP + p) = *reinterpret_cast<const float4 *>(ld[t] + p);
+                    *reinterpret_cast<int4 *>(a.nbr + qq * KP + p) = *reinterpret_cast<const int4 *>(lj[t] + p);
                 }
             } else {
-                for (int p = 0; p < k; ++p) {
-                    dist[qq * k + p] = wsd[qq * KP + p];
-                    nbr[qq * k + p] = wsj[qq * KP + p];
+                for (int p = 0; p < a.k; ++p) {
+                    a.dist[qq * a.k + p] = ld[t][p];
+                    a.nbr[qq * a.k + p] = lj[t][p];
                 }
             }
         }
     }
 }
 
+// Merge the `split` sorted partial lists of every query of the split tiles: k steps of a `split`-way merge by
+// (d, j); sentinels (1e10, -1) sort last.  One lane per query slot of the tail tiles (worst-case grid).
+template <int KP>
+__global__ __launch_bounds__(256) void knn_merge_kernel(const KnnArgs a, int tile_queries)
+{
+    const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
+    if (split <= 1) return;
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int tile = n_full + (int)(slot / tile_queries);
+    if (tile >= total) return;
+    const int ev = find_tile_event(a.tile_ptr, a.B, tile);
+    const int64_t qi = a.ptr[ev] + (int64_t)(tile - a.tile_ptr[ev]) * tile_queries + (slot % tile_queries);
+    if (qi >= a.ptr[ev + 1]) return;
+    const float *pd = a.psd + slot * split * KP;
+    const int32_t *pj = a.psj + slot * split * KP;
+    int head[kMaxSplit];
+#pragma unroll
+    for (int s = 0; s < kMaxSplit; ++s) head[s] = 0;
+    for (int p = 0; p < a.k; ++p) {
+        float bd = kKnnSentinel;
+        int32_t bj = -1;
+        int bs = -1;
+#pragma unroll
+        for (int s = 0; s < kMaxSplit; ++s) {
+            if (s < split && head[s] < KP) {
+                const float d = pd[s * KP + head[s]];
+                const int32_t j = pj[s * KP + head[s]];
+                if (j >= 0 && (bs < 0 || d < bd || (d == bd && j < bj))) { bd = d; bj = j; bs = s; }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < kMaxSplit; ++s) head[s] += (s == bs) ? 1 : 0;
+        a.dist[qi * a.k + p] = bd;
+        a.nbr[qi * a.k + p] = bj;
+    }
+}
+
+int num_simds()
+{
+    static int cached = 0;
+    if (cached == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            cached = cus * 4;
+        else
+            cached = 1024;
+    }
+    return cached;
+}
+
+inline int padded_k(int k) { return k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : 64; }
+constexpr int kMaxSimds = 4096;  // workspace bound for the split (tail) tiles: fewer than `simds` tiles
+
+struct KnnWorkspace {
+    KnnPlan *plan;
+    int32_t *tile_ptr;
+    float *wsd;
+    int32_t *wsj;
+    float *psd;
+    int32_t *psj;
+    size_t bytes;
+};
+
+inline KnnWorkspace carve_workspace(void *ws, int64_t N, int B, int KP)
+{
+    KnnWorkspace w;
+    uintptr_t p = (reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u;
+    auto take = [&](size_t nbytes) { uintptr_t r = p; p = (p + nbytes + 255u) & ~(uintptr_t)255u; return r; };
+    size_t split_q = (size_t)kMaxSimds * 128;
+    if ((size_t)N + 128 < split_q) split_q = (size_t)N + 128;
+    w.plan = reinterpret_cast<KnnPlan *>(take(sizeof(KnnPlan)));
+    w.tile_ptr = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
+    w.wsd = reinterpret_cast<float *>(take(sizeof(float) * (size_t)N * KP));
+    w.wsj = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)N * KP));
+    w.psd = reinterpret_cast<float *>(take(sizeof(float) * split_q * kMaxSplit * KP));
+    w.psj = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * split_q * kMaxSplit * KP));
+    w.bytes = (size_t)(p - reinterpret_cast<uintptr_t>(ws));
+    return w;
+}
+
 template <int DP, int KP>
 int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr, float *dist,
-               float *wsd, int32_t *wsj, hipStream_t st)
+               const KnnWorkspace &w, hipStream_t st)
 {
     constexpr int TQ = (DP <= 32) ? 2 : 1;
-    const int64_t per_block = kWave * TQ;
-    const int64_t blocks = (N + per_block - 1) / per_block;
-    if (D == DP && aligned16(x)) {
-        hipLaunchKernelGGL((knn_kernel<DP, KP, TQ, true>), dim3((unsigned)blocks), dim3(kWave), 0, st, x, ptr, B, N,
-                           D, k, nbr, dist, wsd, wsj);
-    } else {
-        hipLaunchKernelGGL((knn_kernel<DP, KP, TQ, false>), dim3((unsigned)blocks), dim3(kWave), 0, st, x, ptr, B,
-                           N, D, k, nbr, dist, wsd, wsj);
-    }
+    constexpr int QT = kWave * TQ;
+    int simds = num_simds();
+    if (simds > kMaxSimds) simds = kMaxSimds;
+    hipLaunchKernelGGL(knn_plan_kernel, dim3(1), dim3(256), 0, st, ptr, B, QT, simds, w.tile_ptr, w.plan);
+    DMET_LAUNCH_CHECK("knn_plan_kernel");
+    KnnArgs a{x, ptr, B, N, D, k, nbr, dist, w.wsd, w.wsj, w.plan, w.tile_ptr, w.psd, w.psj};
+    // worst-case grid (the plan is on the device): every event adds at most one partial tile, and splitting the
+    // fewer-than-`simds` tail tiles adds fewer than `simds` workgroups; surplus workgroups exit at once
+    const int64_t tiles_max = (N + QT - 1) / QT + B;
+    const int64_t blocks = tiles_max + simds;
+    unsigned dyn = 0;
+#ifdef DMET_KNN_EXPERIMENT
+    if (const char *e = getenv("DMET_KNN_EXTRA_LDS")) dyn = (unsigned)atoi(e);
+#endif
+    if (D == DP && aligned16(x))
+        hipLaunchKernelGGL((knn_kernel<DP, KP, TQ, true>), dim3((unsigned)blocks), dim3(kWave), dyn, st, a);
+    else
+        hipLaunchKernelGGL((knn_kernel<DP, KP, TQ, false>), dim3((unsigned)blocks), dim3(kWave), dyn, st, a);
     DMET_LAUNCH_CHECK("knn_kernel");
+    if (tiles_max > simds) {  // only then can the plan have split anything
+        const int64_t slots = (int64_t)simds * QT;
+        hipLaunchKernelGGL((knn_merge_kernel<KP>), dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, a, QT);
+        DMET_LAUNCH_CHECK("knn_merge_kernel");
+    }
     return 0;
 }
 
 template <int DP>
 int dispatch_k(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr, float *dist,
-               float *wsd, int32_t *wsj, hipStream_t st)
+               void *ws, hipStream_t st)
 {
-    if (k <= 8) return launch_knn<DP, 8>(x, ptr, B, N, D, k, nbr, dist, wsd, wsj, st);
-    if (k <= 16) return launch_knn<DP, 16>(x, ptr, B, N, D, k, nbr, dist, wsd, wsj, st);
-    if (k <= 32) return launch_knn<DP, 32>(x, ptr, B, N, D, k, nbr, dist, wsd, wsj, st);
-    return launch_knn<DP, 64>(x, ptr, B, N, D, k, nbr, dist, wsd, wsj, st);
+    const int KP = padded_k(k);
+    const KnnWorkspace w = carve_workspace(ws, N, B, KP);
+    if (k <= 8) return launch_knn<DP, 8>(x, ptr, B, N, D, k, nbr, dist, w, st);
+    if (k <= 16) return launch_knn<DP, 16>(x, ptr, B, N, D, k, nbr, dist, w, st);
+    if (k <= 32) return launch_knn<DP, 32>(x, ptr, B, N, D, k, nbr, dist, w, st);
+    return launch_knn<DP, 64>(x, ptr, B, N, D, k, nbr, dist, w, st);
 }
-
-inline int padded_k(int k) { return k <= 8 ? 8 : k <= 16 ? 16 : k <= 32 ? 32 : 64; }
 
 // ---- radius graph (N1): first max_nbr candidates in ascending index with d < r^2 ------------------------
 // One lane per query, candidates broadcast from LDS exactly as above; no selection state beyond a counter.
@@ -330,32 +573,27 @@ using namespace dmet;
 
 extern "C" size_t dmet_knn_workspace_bytes(int64_t N, int B, int D, int k)
 {
-    (void)B; (void)D;
-    if (N <= 0 || k <= 0 || k > DMET_MAX_K) return 0;
-    const size_t per = (size_t)padded_k(k) * (sizeof(float) + sizeof(int32_t));
-    return (size_t)N * per + 256;
+    (void)D;
+    if (N <= 0 || B < 0 || k <= 0 || k > DMET_MAX_K) return 0;
+    return carve_workspace(nullptr, N, B, padded_k(k)).bytes + 512;
 }
 
 extern "C" int dmet_knn_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,
                             float *dist, void *ws, size_t ws_bytes, dmet_stream_t stream)
 {
-    DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_knn_f32: N=%lld out of range", (long long)N);
+    DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647 - 4096, "dmet_knn_f32: N=%lld out of range", (long long)N);
     DMET_REQUIRE(B >= 0, "dmet_knn_f32: B=%d", B);
     DMET_REQUIRE(k >= 1 && k <= DMET_MAX_K, "dmet_knn_f32: k=%d not in [1,%d]", k, DMET_MAX_K);
     DMET_REQUIRE(D >= 1 && D <= DMET_MAX_KNN_DIM, "dmet_knn_f32: D=%d not in [1,%d]", D, DMET_MAX_KNN_DIM);
     if (N == 0 || B == 0) return 0;
     DMET_REQUIRE(x && ptr && nbr && dist && ws, "dmet_knn_f32: null pointer");
     DMET_REQUIRE(ws_bytes >= dmet_knn_workspace_bytes(N, B, D, k), "dmet_knn_f32: workspace too small");
-    const int KP = padded_k(k);
-    uintptr_t base = (reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u;
-    float *wsd = reinterpret_cast<float *>(base);
-    int32_t *wsj = reinterpret_cast<int32_t *>(base + (size_t)N * KP * sizeof(float));
     hipStream_t st = as_stream(stream);
-    if (D <= 4) return dispatch_k<4>(x, ptr, B, N, D, k, nbr, dist, wsd, wsj, st);
-    if (D <= 8) return dispatch_k<8>(x, ptr, B, N, D, k, nbr, dist, wsd, wsj, st);
-    if (D <= 16) return dispatch_k<16>(x, ptr, B, N, D, k, nbr, dist, wsd, wsj, st);
-    if (D <= 32) return dispatch_k<32>(x, ptr, B, N, D, k, nbr, dist, wsd, wsj, st);
-    return dispatch_k<64>(x, ptr, B, N, D, k, nbr, dist, wsd, wsj, st);
+    if (D <= 4) return dispatch_k<4>(x, ptr, B, N, D, k, nbr, dist, ws, st);
+    if (D <= 8) return dispatch_k<8>(x, ptr, B, N, D, k, nbr, dist, ws, st);
+    if (D <= 16) return dispatch_k<16>(x, ptr, B, N, D, k, nbr, dist, ws, st);
+    if (D <= 32) return dispatch_k<32>(x, ptr, B, N, D, k, nbr, dist, ws, st);
+    return dispatch_k<64>(x, ptr, B, N, D, k, nbr, dist, ws, st);
 }
 
 extern "C" int dmet_radius_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr,
