@@ -316,3 +316,38 @@ def batch_to_ptr(batch: torch.Tensor, B: int) -> torch.Tensor:
         _lib.check(L.dmet_batch_to_ptr(batch.data_ptr(), batch.numel(), B, ptr.data_ptr(), _stream(dev)),
                    "dmet_batch_to_ptr")
     return ptr
+
+
+# ---- dense-layer weight gradients (N3, first piece) ---------------------------------------------------------------
+def xty(A: torch.Tensor, Bm: torch.Tensor) -> torch.Tensor:
+    """C[Ha,Hb] = A^T @ B for A[N,Ha], B[N,Hb] (Ha,Hb <= 64), deterministic."""
+    dev = _require_device(A, Bm)
+    L = _lib.load()
+    A = _f32c(A, "A"); Bm = _f32c(Bm, "B")
+    N, Ha = A.shape
+    Hb = Bm.shape[1]
+    C = torch.empty((Ha, Hb), dtype=torch.float32, device=dev)
+    _t = timer.record("xty", dev)
+    with torch.cuda.device(dev):
+        ws = _ws(L.dmet_xty_workspace_bytes(N, Ha, Hb), dev)
+        _lib.check(L.dmet_xty_f32(A.data_ptr(), Bm.data_ptr(), N, Ha, Hb, C.data_ptr(), ws.data_ptr(), ws.numel(),
+                                  _stream(dev)), "dmet_xty_f32")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
+    return C
+
+
+def onehot_xty(index: torch.Tensor, Bm: torch.Tensor, num_rows: int) -> torch.Tensor:
+    """C[R,Hb] = onehot(index)^T @ B: the weight gradient of an Embedding with R rows."""
+    dev = _require_device(index, Bm)
+    L = _lib.load()
+    if index.dtype != torch.int64:
+        raise TypeError("index must be int64")
+    index = index.contiguous(); Bm = _f32c(Bm, "B")
+    N, Hb = Bm.shape
+    C = torch.empty((num_rows, Hb), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _ws(L.dmet_xty_workspace_bytes(N, num_rows, Hb), dev)
+        _lib.check(L.dmet_onehot_xty_f32(index.data_ptr(), Bm.data_ptr(), N, num_rows, Hb, C.data_ptr(), ws.data_ptr(),
+                                         ws.numel(), _stream(dev)), "dmet_onehot_xty_f32")
+    return C

@@ -78,8 +78,8 @@ class _EdgeConvLinearMax(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.addmm(gP @ Wd, gQ, W2)
         if ctx.needs_input_grad[1]:
-            gWd = gP.t() @ x
-            gW2 = gQ.t() @ x
+            gWd = _native.xty(gP.contiguous(), x)
+            gW2 = _native.xty(gQ, x)
             gW = torch.cat([gWd, gW2 - gWd], dim=1)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gP.sum(0)

@@ -1,0 +1,58 @@
+"""Per-node dense layers with deterministic HIP weight-gradient kernels (first piece of SURVEY.md row N3).
+
+`linear` / `embedding` compute exactly what torch.nn.functional.linear / embedding compute in forward (library GEMM /
+index_select -- plumbing); only the backward differs: the tall-skinny weight gradients go through csrc/dense.hip
+instead of a library GEMM / a sort-based scatter.  Modules keep their torch.nn.Linear / Embedding parameters (same
+state_dict); these functions are called with those parameters.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _native
+
+
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gw = _native.xty(g, x) if ctx.needs_input_grad[1] else None
+        gb = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb
+
+
+class _Embedding(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, index, weight):
+        ctx.save_for_backward(index)
+        ctx.rows = weight.shape[0]
+        return weight.index_select(0, index)
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        return None, _native.onehot_xty(index, g.contiguous(), ctx.rows)
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x @ weight^T + bias for x[N,in] (in,out <= 64)."""
+    if x.dim() != 2 or weight.shape[0] > 64 or weight.shape[1] > 64 or x.dtype != torch.float32:
+        return torch.nn.functional.linear(x, weight, bias)
+    return _Linear.apply(x, weight, bias)
+
+
+def embedding(index: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """weight[index] for a small table (rows, width <= 64)."""
+    if weight.shape[0] > 64 or weight.shape[1] > 64 or index.dim() != 1:
+        return torch.nn.functional.embedding(index, weight)
+    return _Embedding.apply(index, weight)

@@ -15,10 +15,18 @@ from typing import Optional
 import torch
 from torch import nn
 
+from . import dense
 from .conv import DynamicEdgeConv, EdgeConv
 from .scatter import met_reduce
 
 PDG_CLASSES = (1, 2, 11, 13, 22, 130, 211)  # graph_met_network.py:45
+
+
+def _run(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """Apply a Sequential, routing its Linear members through dense.linear (same forward, HIP weight-grad kernel)."""
+    for layer in seq:
+        x = dense.linear(x, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(x)
+    return x
 
 
 class GraphMETNetwork(nn.Module):
@@ -46,22 +54,22 @@ class GraphMETNetwork(nn.Module):
 
     def embed(self, x_cont: torch.Tensor, x_cat: torch.Tensor) -> torch.Tensor:
         """Per-node encoder (graph_met_network.py:48-58): columns of x_cat are (pdgId, charge, fromPV)."""
-        e_cont = self.embed_continuous(x_cont)
-        e_chrg = self.embed_charge(x_cat[:, 1] + 1)
-        e_pv = self.embed_pv(x_cat[:, 2])
+        e_cont = _run(self.embed_continuous, x_cont)
+        e_chrg = dense.embedding(x_cat[:, 1] + 1, self.embed_charge.weight)
+        e_pv = dense.embedding(x_cat[:, 2], self.embed_pv.weight)
         pdg = x_cat[:, 0].abs()
         for cls, val in enumerate(self.pdgs):  # sequential remap, kept sequential for unexpected ids
             pdg = torch.where(pdg == val, torch.full_like(pdg, cls), pdg)
-        e_pdg = self.embed_pdgid(pdg)
-        e_cat = self.embed_categorical(torch.cat([e_chrg, e_pdg, e_pv], dim=1))
-        return self.bn_all(self.encode_all(torch.cat([e_cat, e_cont], dim=1)))
+        e_pdg = dense.embedding(pdg, self.embed_pdgid.weight)
+        e_cat = _run(self.embed_categorical, torch.cat([e_chrg, e_pdg, e_pv], dim=1))
+        return self.bn_all(_run(self.encode_all, torch.cat([e_cat, e_cont], dim=1)))
 
     def forward(self, x_cont, x_cat, edge_index, batch):
         emb = self.embed(x_cont, x_cat)
         for conv, norm in self.conv_continuous:
             msg = conv(emb, batch) if self.graph == "dynamic" else conv(emb, edge_index)
             emb = emb + norm(msg)
-        return self.output(emb).squeeze(-1)
+        return _run(self.output, emb).squeeze(-1)
 
 
 class Net(nn.Module):

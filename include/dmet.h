@@ -134,6 +134,18 @@ int dmet_segment_sum_1d_f32(const float *src, const int64_t *ptr, int B, float *
 /* ptr[B+1] from a SORTED int64 batch vector (ptr[b] = first i with batch[i] >= b). */
 int dmet_batch_to_ptr(const int64_t *batch, int64_t N, int B, int64_t *ptr, dmet_stream_t stream);
 
+/* ---- N3 (first piece): weight gradients of the per-node dense layers ----------------------------------
+ * The layers around the graph operators (model/graph_met_network.py:15-32,41-44) are tiny per-node Linear /
+ * Embedding modules over N ~ 3e5 nodes; autograd's weight gradients for them are tall-skinny reductions
+ *   C[Ha,Hb] = A^T B,  A = grad_out[N,Ha], B = input[N,Hb]        (torch Linear.weight layout [out,in])
+ *   C[R,Hb]  = onehot(index[N])^T B                                (torch Embedding.weight gradient)
+ * computed deterministically (fixed row ranges per wavefront, partials summed in order), Ha,Hb,R <= 64. */
+size_t dmet_xty_workspace_bytes(int64_t N, int Ha, int Hb);
+int dmet_xty_f32(const float *A, const float *B, int64_t N, int Ha, int Hb, float *C, void *ws,
+                 size_t ws_bytes, dmet_stream_t stream);
+int dmet_onehot_xty_f32(const int64_t *index, const float *B, int64_t N, int R, int Hb, float *C, void *ws,
+                        size_t ws_bytes, dmet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,9 +142,17 @@ def batch_to_ptr(batch, B):
     return ref_ops.batch_to_ptr(batch, batch.numel(), B)
 
 
+def xty(A, Bm):
+    return (A.detach().t() @ Bm.detach()).contiguous()
+
+
+def onehot_xty(index, Bm, num_rows):
+    return torch.zeros((num_rows, Bm.shape[1]), dtype=Bm.dtype).index_add_(0, index, Bm.detach())
+
+
 _NAMES = ["knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
           "edge_features_bwd", "segment_max", "segment_sum", "segment_max_bwd", "segment_sum_bwd", "met_reduce",
-          "met_reduce_bwd", "segment_sum_1d", "batch_to_ptr"]
+          "met_reduce_bwd", "segment_sum_1d", "batch_to_ptr", "xty", "onehot_xty"]
 
 
 def install(monkeypatch=None):

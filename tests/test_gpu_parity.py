@@ -231,6 +231,44 @@ def test_full_model_train_step_matches_oracle(dev):
                                    msg=lambda m, n=n: f"{n}: {m}")
 
 
+@pytest.mark.parametrize("N,Ha,Hb", [(1, 1, 16), (1000, 16, 8), (4097, 32, 32), (70001, 16, 24), (5000, 64, 33)])
+def test_dense_weight_grad_kernels(dev, N, Ha, Hb):
+    """csrc/dense.hip: A^T B and onehot(index)^T B vs an fp64 reference; deterministic run to run."""
+    from deepmetv2_amd import _native
+    g = torch.Generator().manual_seed(N)
+    A, Bm = torch.randn(N, Ha, generator=g), torch.randn(N, Hb, generator=g)
+    ref = (A.double().t() @ Bm.double())
+    got = _native.xty(A.to(dev), Bm.to(dev))
+    tol = 1e-5 * float((A.abs().double().t() @ Bm.abs().double()).max())
+    assert float((got.cpu().double() - ref).abs().max()) <= tol
+    assert torch.equal(got, _native.xty(A.to(dev), Bm.to(dev)))
+    R = min(Ha, 8)
+    idx = torch.randint(0, R, (N,), generator=g)
+    ref2 = torch.zeros(R, Hb, dtype=torch.float64).index_add_(0, idx, Bm.double())
+    got2 = _native.onehot_xty(idx.to(dev), Bm.to(dev), R)
+    assert float((got2.cpu().double() - ref2).abs().max()) <= 1e-5 * max(1.0, float(ref2.abs().max()))
+
+
+def test_dense_linear_embedding_autograd(dev):
+    from deepmetv2_amd import dense
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3000, 24, generator=g)
+    W, b = torch.randn(16, 24, generator=g), torch.randn(16, generator=g)
+    tab = torch.randn(7, 8, generator=g)
+    idx = torch.randint(0, 7, (3000,), generator=g)
+    outs = []
+    for d in (torch.device("cpu"), dev):
+        xx, WW, bb, tt = (t.clone().to(d).requires_grad_(True) for t in (x, W, b, tab))
+        if d.type == "cpu":
+            y = torch.nn.functional.linear(xx, WW, bb).tanh().sum() + (torch.nn.functional.embedding(idx, tt) ** 2).sum()
+        else:
+            y = dense.linear(xx, WW, bb).tanh().sum() + (dense.embedding(idx.to(d), tt) ** 2).sum()
+        y.backward()
+        outs.append([t.grad.cpu() for t in (xx, WW, bb, tt)])
+    for a, r in zip(outs[1], outs[0]):
+        torch.testing.assert_close(a, r, rtol=1e-4, atol=1e-4 * max(1.0, float(r.abs().max())))
+
+
 def test_ops_fail_loudly_without_gpu_tensor(dev):
     import deepmetv2_amd as dm
     with pytest.raises(RuntimeError, match="non-GPU tensor"):
