@@ -40,6 +40,22 @@ def parse_args():
     return ap.parse_args()
 
 
+def usable_cores() -> int:
+    """Host cores this process may really use: min(affinity mask, cgroup cpu.max quota, cpu_count)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(args, seed: int):
     """The same training step on the host cores through the CPU oracle (PyG-shaped, un-fused restatement of the
     reference's operators; kind 'port' -- PyG itself is not installable here), on a bounded sample of events."""
@@ -48,8 +64,9 @@ def cpu_baseline(args, seed: int):
     from deepmetv2_amd import synth
     from oracle import ref_model, ref_ops
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     n_ev = args.cpu_sample_events or max(2, min(16, cores))
     x, y, batch, ptr = synth.make_events([args.nodes] * n_ev, seed=seed)
     torch.manual_seed(0)

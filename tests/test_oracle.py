@@ -1,0 +1,179 @@
+"""CPU tests of the ORACLE itself: known answers for the restated rules R1-R6, the C code
+against an independent Python-loop restatement, and the committed golden fixtures (tests/golden/, written by
+oracle/gen_golden.py).  PARITY UNPINNED by the reference (no upstream tests / vectors exist); G4 is the exception:
+it was produced by the reference's own model code."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_model, ref_ops
+
+
+def _g(golden_dir, name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+# ---- known answers -----------------------------------------------------------------------------------------------
+def test_r1_distance_is_sequential_fmaf():
+    # 3 features chosen so that fused vs unfused and reordered sums differ in the last bit
+    x = torch.tensor([[0.0, 0.0, 0.0], [1.0 + 2 ** -12, 3.0 - 2 ** -11, 1e-4]], dtype=torch.float32)
+    nbr, dist = ref_ops.knn_table(x, torch.tensor([0, 2]), 2)
+    a = np.float32(0.0)
+    for c in range(3):
+        d = np.float32(x[1, c].item())
+        a = np.float32(ref_ops._fmaf(float(d), float(d), float(a)))
+    assert dist[0, 1].item() == float(a) and nbr[0].tolist() == [0, 1]
+
+
+def test_r2_ties_lower_index_first_and_sentinel():
+    x = torch.tensor([[0.0], [1.0], [-1.0], [1.0], [5e5]])            # |x0-x1| == |x0-x2| == |x0-x3|
+    nbr, dist = ref_ops.knn_table(x, torch.tensor([0, 5]), 4)
+    assert nbr[0].tolist() == [0, 1, 2, 3]                              # ties in ascending index
+    assert nbr[1].tolist() == [1, 3, 0, 2]                              # duplicate 3 right after self
+    # distance >= 1e10 is never selected (upstream sentinel): 5e5^2 = 2.5e11
+    assert nbr[0].tolist().count(4) == 0 and ref_ops.knn_table(x, torch.tensor([0, 5]), 5)[0][0, 4].item() == -1
+
+
+def test_knn_graph_orientation_loop_and_short_events():
+    x = torch.tensor([[0.0], [1.0], [3.0], [10.0], [11.0]])
+    batch = torch.tensor([0, 0, 0, 1, 1])
+    ei = ref_ops.knn_graph(x, 2, batch, loop=False)
+    assert ei.tolist() == [[1, 2, 0, 2, 1, 0, 4, 3], [0, 0, 1, 1, 2, 2, 3, 4]]     # [0]=source j, [1]=target i
+    ei2 = ref_ops.knn_graph(x, 2, batch, loop=False, flow="target_to_source")
+    assert torch.equal(ei2, ei.flip(0))
+    ei3 = ref_ops.knn_graph(x, 3, batch, loop=True)                     # event 1 has 2 < k nodes: 2 edges per node
+    assert (ei3[1] == 3).sum() == 2 and (ei3[1] == 0).sum() == 3
+    with pytest.raises(ValueError):
+        ref_ops.knn_graph(x, 2, torch.tensor([0, 1, 0, 1, 1]))
+
+
+def test_radius_first_in_index_order_strict():
+    x = torch.tensor([[0.0, 0.0], [0.3, 0.0], [0.4, 0.0], [0.1, 0.0], [0.2, 0.0]])
+    ei = ref_ops.radius_graph(x, 0.4, None, loop=True, max_num_neighbors=3)
+    assert ei[0][ei[1] == 0].tolist() == [0, 1, 3]                      # 2 is at exactly r (strict <), cap at 3
+    ei = ref_ops.radius_graph(x, 0.4, None, loop=False, max_num_neighbors=3)
+    assert ei[0][ei[1] == 0].tolist() == [1, 3, 4]
+
+
+def test_r3_r4_max_empty_and_ties():
+    src = torch.tensor([[1.0, 5.0], [1.0, 5.0], [0.5, 7.0], [2.0, 2.0]], requires_grad=True)
+    out, arg = ref_ops.scatter_max(src, torch.tensor([0, 0, 0, 3]), 5)
+    assert out.tolist() == [[1.0, 7.0], [0.0, 0.0], [0.0, 0.0], [2.0, 2.0], [0.0, 0.0]]
+    assert arg.tolist() == [[0, 2], [4, 4], [4, 4], [3, 3], [4, 4]]
+    out.sum().backward()
+    assert src.grad.tolist() == [[1.0, 0.0], [0.0, 0.0], [0.0, 1.0], [1.0, 1.0]]
+
+
+def test_edge_conv_matches_hand_computation():
+    x = torch.tensor([[1.0, 2.0], [3.0, 5.0], [0.0, 1.0]])
+    ei = torch.tensor([[1, 2, 0], [0, 0, 1]])                          # edges 1->0, 2->0, 0->1 ; node 2 isolated
+    lin = torch.nn.Linear(4, 1, bias=True)
+    with torch.no_grad():
+        lin.weight.copy_(torch.tensor([[1.0, 10.0, 100.0, 1000.0]])); lin.bias.fill_(0.5)
+    out = ref_ops.edge_conv(x, ei, lin)
+    m10 = 1 + 20 + 100 * 2 + 1000 * 3 + 0.5
+    m20 = 1 + 20 + 100 * (-1) + 1000 * (-1) + 0.5
+    m01 = 3 + 50 + 100 * (-2) + 1000 * (-3) + 0.5
+    assert out.view(-1).tolist() == [max(m10, m20), m01, 0.0]
+
+
+def test_met_and_loss():
+    x = torch.tensor([[1.0, 2.0, 0, 0], [3.0, -1.0, 0, 0], [0.5, 0.5, 0, 0]])
+    w = torch.tensor([0.5, 1.0, 0.25])
+    met = ref_ops.met_sums_f64(w, x, torch.tensor([0, 2, 3]))
+    assert met.tolist() == [[3.5, 0.0], [0.125, 0.125]]
+    y = torch.tensor([[1.0, 1.0], [0.0, 0.0]])
+    loss = ref_ops.loss_fn(w, x, y, torch.tensor([0, 0, 1]))
+    assert abs(loss.item() - 0.5 * (((4.5 ** 2 + 1.0) + (0.125 ** 2 * 2)) / 2)) < 1e-6
+
+
+# ---- C vs independent restatement --------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,k", [(1, 1), (3, 4), (8, 7)])
+def test_c_oracle_equals_python_loops(D, k):
+    g = torch.Generator().manual_seed(D * 10 + k)
+    x = torch.randn(41, D, generator=g)
+    x[5] = x[20]; x[30:] = torch.round(x[30:])
+    ptr = torch.tensor([0, 17, 17, 18, 41])
+    assert torch.equal(ref_ops.knn_table(x, ptr, k)[0], ref_ops.knn_table_pyloops(x, ptr, k))
+
+
+# ---- golden fixtures ----------------------------------------------------------------------------------------------
+def test_golden_g1_g2_g3_knn(golden_dir):
+    for name, k, key in [("g1_config1.npz", 8, "nbr"), ("g2_ties.npz", 16, "nbr16"), ("g3_ragged.npz", 16, "nbr")]:
+        G = _g(golden_dir, name)
+        nbr, dist = ref_ops.knn_table(G["x"], G["ptr"], k)
+        assert torch.equal(nbr, G[key])
+    G = _g(golden_dir, "g2_ties.npz")
+    assert torch.equal(ref_ops.knn_graph(G["x"], 4, G["batch"], loop=False), G["ei_k4_noloop"])
+
+
+def test_golden_g1_edgeconv(golden_dir):
+    G = _g(golden_dir, "g1_config1.npz")
+    ei = ref_ops.knn_graph(G["x"], 8, None, loop=True)
+    for tag in ("seeded", "trained"):
+        lin = torch.nn.Linear(64, 32)
+        with torch.no_grad():
+            lin.weight.copy_(G[f"W_{tag}"]); lin.bias.copy_(G[f"b_{tag}"])
+        out = ref_ops.edge_conv(G["x"], ei, lin)
+        torch.testing.assert_close(out.detach(), G[f"out_{tag}"], rtol=0, atol=0)
+
+
+def test_golden_g6_radius(golden_dir):
+    G = _g(golden_dir, "g6_radius.npz")
+    ei = ref_ops.radius_graph(G["etaphi"], 0.4, G["batch"], loop=True, max_num_neighbors=255)
+    assert torch.equal(ei.int(), G["ei_r04_loop_255"])
+
+
+def _load_ckpt(golden_dir):
+    return {k.replace("__", "."): v for k, v in _g(golden_dir, "g4_checkpoint_dytt_best.npz").items()}
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_wiring_matches_reference_model_run(golden_dir, mode):
+    """G4 was produced by the reference's own model/net.py code: the oracle restatement must reproduce it."""
+    G = _g(golden_dir, "g4_reference_model.npz")
+    model = ref_model.RefNet(8, 3, graph="static")
+    model.load_state_dict(_load_ckpt(golden_dir))
+    getattr(model, mode)()
+    x, y, batch = G["x"], G["y"], G["batch"]
+    w = model(x[:, :8], x[:, 8:].long(), G["edge_index"].long(), batch)
+    loss = ref_ops.loss_fn(w, x, y, batch)
+    loss.backward()
+    torch.testing.assert_close(w.detach(), G[f"weights_{mode}"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(loss.detach(), G[f"loss_{mode}"], rtol=1e-6, atol=0)
+    torch.testing.assert_close(model.graphnet.conv_continuous[0][0].nn[0].weight.grad, G[f"grad_conv0_weight_{mode}"],
+                               rtol=1e-4, atol=1e-4 * float(G[f"grad_conv0_weight_{mode}"].abs().max()))
+
+
+def test_reference_checkpoints_load_into_product_model(golden_dir):
+    """Drop-in contract: same state_dict keys/shapes as ckpts_dytt/best.pth.tar (23 parameter tensors, 6641 params)."""
+    from deepmetv2_amd.model import Net
+    sd = _load_ckpt(golden_dir)
+    for graph in ("static", "dynamic"):
+        model = Net(8, 3, graph=graph)
+        assert list(model.state_dict().keys()) == list(sd.keys())
+        model.load_state_dict(sd)
+    assert sum(p.numel() for p in model.parameters()) == 6641
+    ref = "/root/reference/ckpts_znunu/last.pth.tar"
+    if os.path.exists(ref):  # the real files, when the reference tree is present (never on the GPU box)
+        model.load_state_dict(torch.load(ref, map_location="cpu", weights_only=True)["state_dict"])
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_product_model_host_path_matches_reference_model_run(golden_dir, mode, monkeypatch):
+    """The product's model/host code (HIP calls replaced by the CPU stand-in) against the reference's own run."""
+    from fake_native import install
+    install(monkeypatch)
+    from deepmetv2_amd.model import Net, loss_fn, split_features
+    G = _g(golden_dir, "g4_reference_model.npz")
+    model = Net(8, 3, graph="static")
+    model.load_state_dict(_load_ckpt(golden_dir))
+    getattr(model, mode)()
+    x, y, batch = G["x"], G["y"], G["batch"]
+    w = model(*split_features(x), G["edge_index"].long(), batch)
+    loss = loss_fn(w, x, y, batch)
+    loss.backward()
+    torch.testing.assert_close(w.detach(), G[f"weights_{mode}"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(loss.detach(), G[f"loss_{mode}"], rtol=1e-4, atol=1e-3)
