@@ -5,6 +5,7 @@ Every function requires ROCm device tensors and raises otherwise -- there is no 
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -73,6 +74,10 @@ class KernelTimer:
 
 timer = KernelTimer()
 
+# which form of the gather+max kernel the fused EdgeConv uses: "l2" (gather from the XCD's L2, any event size) or
+# "lds" (per-event slice of Q resident in LDS)
+GATHER_MAX_FORM = os.environ.get("DMET_GATHER_MAX_FORM", "l2")
+
 
 # ---- K1 ------------------------------------------------------------------------------------------------------
 def knn(x: torch.Tensor, ptr: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -140,11 +145,12 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
     out = torch.empty((N, H), dtype=torch.float32, device=dev)
     arg = torch.empty((N, H), dtype=torch.uint8, device=dev) if want_arg else None
     _t = timer.record('gather_max', dev)
+    use_lds = GATHER_MAX_FORM == "lds" and ptr is not None and H % 8 == 0
+    fn = L.dmet_gather_max_lds_f32 if use_lds else L.dmet_gather_max_f32
     with torch.cuda.device(dev):
-        _lib.check(L.dmet_gather_max_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(),
-                                         ptr.data_ptr() if ptr is not None else None,
-                                         (ptr.numel() - 1) if ptr is not None else 0, N, k, H, out.data_ptr(),
-                                         arg.data_ptr() if want_arg else None, _stream(dev)), "dmet_gather_max_f32")
+        _lib.check(fn(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), ptr.data_ptr() if ptr is not None else None,
+                      (ptr.numel() - 1) if ptr is not None else 0, N, k, H, out.data_ptr(),
+                      arg.data_ptr() if want_arg else None, _stream(dev)), "dmet_gather_max_f32")
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))
     return out, arg

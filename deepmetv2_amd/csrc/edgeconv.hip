@@ -9,6 +9,8 @@
 //                       (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fmaf chain) -- 16x fewer flops than per edge
 //   gather_max        : out[i] = P[i] + max_s Q[nbr[i,s]]  -- the HBM/L2-bound "gather + scatter_max" kernel
 // Un-fused path (arbitrary nn / arbitrary edge list): edge_features -> user nn -> segment_max / segment_sum.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dmet {
@@ -141,6 +143,122 @@ __global__ __launch_bounds__(256) void gather_max_kernel(const float *__restrict
         uchar4 a = make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
         if (!any) a = make_uchar4(255, 255, 255, 255);
         reinterpret_cast<uchar4 *>(arg)[node * LPN + c4] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// gather_max (LDS-resident form): one workgroup per (event, 8-channel slice).  The slice of Q for the whole event
+// (n_b x 32 B, 144 KB at 4500 nodes) is staged in the CU's 160 KB LDS once; the k neighbour rows of every node are
+// then gathered from LDS instead of L2.  Global traffic per workgroup is pure streaming: Q slice, neighbour ids,
+// P slice in; out (+arg) slice out.  The H/8 slice workgroups of one event get block ids 8 apart, i.e. land on
+// one XCD together (speed only), so the 128-B lines they share are fetched into that XCD's L2 once.
+// Events too large for the LDS budget fall back to gathering from global memory inside the same kernel.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSliceC = 8;                         // channels per slice
+constexpr int kLdsGatherThreads = 1024;
+constexpr int kLdsGatherBytes = 160 * 1024;        // whole LDS of a gfx950 CU
+constexpr int kLdsGatherRows = kLdsGatherBytes / (kSliceC * 4);  // 5120 nodes per event fit
+
+template <int K4>
+__device__ __forceinline__ void load_ids(const int32_t *__restrict__ row, int k, bool vec, int4 (&ids)[K4])
+{
+#pragma unroll
+    for (int q = 0; q < K4; ++q) {
+        if (vec) ids[q] = *reinterpret_cast<const int4 *>(row + 4 * q);
+        else {
+            ids[q].x = (4 * q + 0 < k) ? row[4 * q + 0] : -1;
+            ids[q].y = (4 * q + 1 < k) ? row[4 * q + 1] : -1;
+            ids[q].z = (4 * q + 2 < k) ? row[4 * q + 2] : -1;
+            ids[q].w = (4 * q + 3 < k) ? row[4 * q + 3] : -1;
+        }
+    }
+}
+
+// K4 = number of int4 id loads per node (k <= 4*K4): ids of the NEXT node and its P slice are prefetched while the
+// current node's rows are gathered from LDS, and the Q slice is staged with all of a thread's loads in flight.
+template <bool WITH_ARG, int K4, int GML_MODE = 0>
+__global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
+    const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ nbr,
+    const int64_t *__restrict__ ptr, int B, int k, int H, float *__restrict__ out, uint8_t *__restrict__ arg)
+{
+    __shared__ __attribute__((aligned(16))) float4 qs[kLdsGatherRows * 2];   // [n_b][2] float4 = 8 channels/node
+    constexpr int RPI = kLdsGatherThreads / 2;                                // rows per iteration (2 lanes per node)
+    const int nsl = H / kSliceC;
+    // block -> (event, slice): slices of one event are 8 blocks apart (same XCD under round-robin placement)
+    const int grp = blockIdx.x / (kNumXcd * nsl), rem = blockIdx.x % (kNumXcd * nsl);
+    const int b = grp * kNumXcd + (rem % kNumXcd);
+    const int sl = rem / kNumXcd;
+    if (b >= B) return;
+    const int lo = (int)ptr[b], hi = (int)ptr[b + 1];
+    const int n = hi - lo;
+    if (n <= 0) return;
+    const bool in_lds = n <= kLdsGatherRows;
+    const int h4 = H / 4;                       // float4s per full row
+    const float4 *Q4 = reinterpret_cast<const float4 *>(Q);
+    const float4 *P4 = reinterpret_cast<const float4 *>(P);
+    const int half = threadIdx.x & 1;
+    const int r0 = threadIdx.x >> 1;
+    const int col4 = sl * 2 + half;             // float4 column of this lane inside a full row
+    const float ninf = -__builtin_inff();
+    const bool vec_ids = (k == 4 * K4) ;        // rows of ids are int4-aligned (nbr is 16-B aligned, k % 4 == 0)
+
+    // stage the Q slice with LDS-DMA (global_load_lds_dwordx4: per-lane source address, LDS destination =
+    // wave-uniform base + lane*16, no registers, every chunk of the wave in flight at once); 32 rows per chunk
+    if (in_lds && GML_MODE != 1) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int nchunk = (n + 31) / 32;
+        for (int c = wave; c < nchunk; c += kLdsGatherThreads / 64) {
+            int row = 32 * c + (lane >> 1);
+            row = min(row, n - 1);   // tail lanes re-read the last row; their LDS rows are never gathered
+            const float4 *src = Q4 + (int64_t)(lo + row) * h4 + sl * 2 + (lane & 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(qs + 64 * c), 16, 0, 0);
+        }
+    }
+    // first node's ids and P slice
+    int4 ids[K4];
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 < n) { load_ids<K4>(nbr + (int64_t)(lo + r0) * k, k, vec_ids, ids); pv = P4[(int64_t)(lo + r0) * h4 + col4]; }
+    __builtin_amdgcn_s_waitcnt(0);   // LDS-DMA is counted by vmcnt and is not covered by the barrier itself
+    __syncthreads();
+
+    for (int r = r0; r < n; r += RPI) {
+        const int64_t node = lo + r;
+        int4 cur[K4];
+#pragma unroll
+        for (int q = 0; q < K4; ++q) cur[q] = ids[q];
+        const float4 p = pv;
+        if (r + RPI < n) { load_ids<K4>(nbr + (int64_t)(lo + r + RPI) * k, k, vec_ids, ids); pv = P4[(int64_t)(lo + r + RPI) * h4 + col4]; }
+        float4 best = make_float4(ninf, ninf, ninf, ninf);
+        int a0 = 255, a1 = 255, a2 = 255, a3 = 255;
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < (GML_MODE == 2 ? 0 : K4); ++q) {
+            const int j[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j[u] < 0) v[u] = make_float4(ninf, ninf, ninf, ninf);
+                else if (in_lds) v[u] = qs[(j[u] - lo) * 2 + half];
+                else v[u] = Q4[(int64_t)j[u] * h4 + col4];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                any = any || (j[u] >= 0);
+                if (v[u].x > best.x) { best.x = v[u].x; a0 = 4 * q + u; }
+                if (v[u].y > best.y) { best.y = v[u].y; a1 = 4 * q + u; }
+                if (v[u].z > best.z) { best.z = v[u].z; a2 = 4 * q + u; }
+                if (v[u].w > best.w) { best.w = v[u].w; a3 = 4 * q + u; }
+            }
+        }
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (any) o = make_float4(p.x + best.x, p.y + best.y, p.z + best.z, p.w + best.w);
+        reinterpret_cast<float4 *>(out)[node * h4 + col4] = o;
+        if (WITH_ARG) {
+            uchar4 a = make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
+            if (!any) a = make_uchar4(255, 255, 255, 255);
+            reinterpret_cast<uchar4 *>(arg)[node * h4 + col4] = a;
+        }
     }
 }
 
@@ -331,6 +449,49 @@ extern "C" int dmet_gather_max_f32(const float *P, const float *Q, const int32_t
     }
 #undef DMET_GM
     DMET_LAUNCH_CHECK("gather_max_kernel");
+    return 0;
+}
+
+extern "C" int dmet_gather_max_lds_f32(const float *P, const float *Q, const int32_t *nbr, const int64_t *ptr, int B,
+                                       int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_gather_max_lds_f32: N out of range");
+    DMET_REQUIRE(k >= 1 && k <= 255, "dmet_gather_max_lds_f32: k=%d not in [1,255]", k);
+    DMET_REQUIRE(H >= kSliceC && H % kSliceC == 0 && H <= DMET_MAX_H, "dmet_gather_max_lds_f32: H=%d must be a multiple of %d", H,
+                 kSliceC);
+    if (N == 0 || B == 0) return 0;
+    DMET_REQUIRE(P && Q && nbr && ptr && out, "dmet_gather_max_lds_f32: null pointer");
+    DMET_REQUIRE(aligned16(P) && aligned16(Q) && aligned16(out) && aligned16(nbr),
+                 "dmet_gather_max_lds_f32: pointers must be 16-B aligned");
+    const int nsl = H / kSliceC;
+    const int64_t groups = (B + kNumXcd - 1) / kNumXcd;
+    const int64_t blocks = groups * kNumXcd * nsl;
+    hipStream_t st = as_stream(stream);
+#define DMET_GML(K4_)                                                                                          \
+    do {                                                                                                       \
+        if (arg)                                                                                               \
+            hipLaunchKernelGGL((gather_max_lds_kernel<true, K4_>), dim3((unsigned)blocks),                     \
+                               dim3(kLdsGatherThreads), 0, st, P, Q, nbr, ptr, B, k, H, out, arg);             \
+        else                                                                                                   \
+            hipLaunchKernelGGL((gather_max_lds_kernel<false, K4_>), dim3((unsigned)blocks),                    \
+                               dim3(kLdsGatherThreads), 0, st, P, Q, nbr, ptr, B, k, H, out, arg);             \
+    } while (0)
+#ifdef DMET_KNN_EXPERIMENT
+    if (const char *e = arg ? getenv("DMET_GML_MODE") : nullptr) {
+        const int m = atoi(e);
+        if (m == 1) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 1>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, ptr, B, k, H, out, arg);
+        else if (m == 2) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 2>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, ptr, B, k, H, out, arg);
+        else DMET_GML(4);
+        DMET_LAUNCH_CHECK("gather_max_lds_kernel");
+        return 0;
+    }
+#endif
+    if (k <= 8) DMET_GML(2);
+    else if (k <= 16) DMET_GML(4);
+    else if (k <= 32) DMET_GML(8);
+    else return dmet_gather_max_f32(P, Q, nbr, ptr, B, N, k, H, out, arg, stream);  // wide tables: L2 form
+#undef DMET_GML
+    DMET_LAUNCH_CHECK("gather_max_lds_kernel");
     return 0;
 }
 

@@ -33,6 +33,50 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int kTileC = 32;   // candidates per LDS tile
 constexpr int kQMax = 8;     // per-lane pending queue capacity
 constexpr int kMaxSplit = 8; // tail tiles are split into at most this many candidate sub-sweeps
+constexpr int kWavesPerGroup = 4;  // independent wavefronts per workgroup (one per SIMD of the CU)
+
+// LDS hand-off between the lanes of ONE wavefront: LDS requests of a wave execute in order, so only the compiler
+// has to be kept from moving accesses across this point (no workgroup barrier: the group's waves are independent).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Four features x two candidates (A, B) x the lane's two queries in ONE asm block of 8 v_pk_add_f32 + 8 v_pk_fma_f32.
+//   v_pk_add_f32 t, cand_pair, q  op_sel -> (c, c) + (-q.x, -q.y): the candidate feature is the low or high half of a
+//   register pair, broadcast to both result halves with op_sel/op_sel_hi; the query pair is negated with neg_lo/neg_hi
+//   (c + (-q) is the same IEEE result as c - q).
+// Why asm: hipcc materialises every broadcast pair with v_mov (49 extra VALU per 128 useful ones) and serialises the
+// fma chains behind the packed-fp32 RAW wait state; here each accumulator's chain stays in feature order (R1) and
+// dependent packed ops are always separated by an independent one.
+#define DMET_PKSUB_LO " op_sel:[0,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#define DMET_PKSUB_HI " op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+__device__ __forceinline__ void pk_dist_step4(f2 &accA, f2 &accB, f2 vxy, f2 vzw, f2 wxy, f2 wzw, f2 q0, f2 q1, f2 q2,
+                                              f2 q3)
+{
+    f2 t0, t1, t2, t3;
+    asm("v_pk_add_f32 %[t0], %[vxy], %[q0]" DMET_PKSUB_LO
+        "v_pk_add_f32 %[t1], %[wxy], %[q0]" DMET_PKSUB_LO
+        "v_pk_add_f32 %[t2], %[vxy], %[q1]" DMET_PKSUB_HI
+        "v_pk_add_f32 %[t3], %[wxy], %[q1]" DMET_PKSUB_HI
+        "v_pk_fma_f32 %[a], %[t0], %[t0], %[a]\n\t"
+        "v_pk_fma_f32 %[b], %[t1], %[t1], %[b]\n\t"
+        "v_pk_add_f32 %[t0], %[vzw], %[q2]" DMET_PKSUB_LO
+        "v_pk_add_f32 %[t1], %[wzw], %[q2]" DMET_PKSUB_LO
+        "v_pk_fma_f32 %[a], %[t2], %[t2], %[a]\n\t"
+        "v_pk_fma_f32 %[b], %[t3], %[t3], %[b]\n\t"
+        "v_pk_add_f32 %[t2], %[vzw], %[q3]" DMET_PKSUB_HI
+        "v_pk_add_f32 %[t3], %[wzw], %[q3]" DMET_PKSUB_HI
+        "v_pk_fma_f32 %[a], %[t0], %[t0], %[a]\n\t"
+        "v_pk_fma_f32 %[b], %[t1], %[t1], %[b]\n\t"
+        "v_pk_fma_f32 %[a], %[t2], %[t2], %[a]\n\t"
+        "v_pk_fma_f32 %[b], %[t3], %[t3], %[b]"
+        : [a] "+v"(accA), [b] "+v"(accB), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+        : [vxy] "v"(vxy), [vzw] "v"(vzw), [wxy] "v"(wxy), [wzw] "v"(wzw), [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2),
+          [q3] "v"(q3));
+}
 
 template <int DP, int TQ>
 struct KnnShared {
@@ -203,31 +247,37 @@ __device__ __forceinline__ void load_tile(float4 (&pf)[NLD], const float *__rest
 }
 
 template <int DP, int KP, int TQ, bool EXACT_D>
-__global__ __launch_bounds__(kWave, 3) void knn_kernel(const KnnArgs a)
+__global__ __launch_bounds__(kWave * kWavesPerGroup, 3) void knn_kernel(const KnnArgs a)
 {
-    __shared__ KnnShared<DP, TQ> sh;
+    // A workgroup is kWavesPerGroup INDEPENDENT wavefronts (one work item each, no workgroup barrier): the hardware
+    // spreads a workgroup's waves over the CU's 4 SIMDs, so each SIMD receives one item of every resident workgroup
+    // and whole-sweep and sub-sweep items mix evenly per SIMD (single-wave workgroups left some SIMDs with 3 whole
+    // sweeps: measured 3.1 ms stragglers against a 2.4 ms median).
+    __shared__ KnnShared<DP, TQ> sh_all[kWavesPerGroup];
+    KnnShared<DP, TQ> &sh = sh_all[threadIdx.x >> 6];
+    const int item = blockIdx.x * kWavesPerGroup + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
 #ifdef DMET_KNN_STAMP
-    if (threadIdx.x == 0 && blockIdx.x < (1 << 16)) {
-        g_knn_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && item < (1 << 16)) {
+        g_knn_stamps[item][0] = __builtin_amdgcn_s_memrealtime();
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_knn_stamps[blockIdx.x][2] = hwid;
-        g_knn_stamps[blockIdx.x][3] = xcc;
-        g_knn_stamps[blockIdx.x][1] = 0;
+        g_knn_stamps[item][2] = hwid;
+        g_knn_stamps[item][3] = xcc;
+        g_knn_stamps[item][1] = 0;
     }
 #endif
     const float *__restrict__ x = a.x;
     const int64_t *__restrict__ ptr = a.ptr;
-    const int lane = threadIdx.x;
     const int D = a.D;
     constexpr int QT = kWave * TQ;  // queries per tile
 
-    // which (query tile, candidate sub-sweep) is this workgroup?  (plan lives in device memory)
+    // which (query tile, candidate sub-sweep) is this wavefront?  (plan lives in device memory)
     const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
-    int tile = blockIdx.x, sub = 0, nsub = 1;
-    if ((int)blockIdx.x >= n_full) {
-        const int r = blockIdx.x - n_full;
+    int tile = item, sub = 0, nsub = 1;
+    if (item >= n_full) {
+        const int r = item - n_full;
         tile = n_full + r / split;
         sub = r % split;
         nsub = split;
@@ -293,13 +343,13 @@ __global__ __launch_bounds__(kWave, 3) void knn_kernel(const KnnArgs a)
 
     for (int c0 = clo; c0 < chi; c0 += kTileC) {
         const int cntc = min(kTileC, chi - c0);
-        __syncthreads();  // every lane is done reading the previous tile
+        wave_sync();  // every lane is done reading the previous tile
 #pragma unroll
         for (int m = 0; m < kLdPerLane; ++m) {
             const int idx = lane + m * kWave;
             if (idx < kLd4) sh.tile[idx] = pf[m];
         }
-        __syncthreads();
+        wave_sync();
         if (c0 + kTileC < chi)
             load_tile<DP, EXACT_D, kLdPerLane>(pf, x, D, c0 + kTileC, min(kTileC, chi - c0 - kTileC), lane);
 
@@ -311,15 +361,9 @@ __global__ __launch_bounds__(kWave, 3) void knn_kernel(const KnnArgs a)
                 for (int c4 = 0; c4 < DP / 4; ++c4) {
                     const float4 v = sh.tile[cc * (DP / 4) + c4];        // wave-uniform address: LDS broadcast
                     const float4 w = sh.tile[(cc + 1) * (DP / 4) + c4];
-                    f2 df;
-                    df = (f2){v.x, v.x} - q2[4 * c4 + 0]; accA = __builtin_elementwise_fma(df, df, accA);
-                    df = (f2){w.x, w.x} - q2[4 * c4 + 0]; accB = __builtin_elementwise_fma(df, df, accB);
-                    df = (f2){v.y, v.y} - q2[4 * c4 + 1]; accA = __builtin_elementwise_fma(df, df, accA);
-                    df = (f2){w.y, w.y} - q2[4 * c4 + 1]; accB = __builtin_elementwise_fma(df, df, accB);
-                    df = (f2){v.z, v.z} - q2[4 * c4 + 2]; accA = __builtin_elementwise_fma(df, df, accA);
-                    df = (f2){w.z, w.z} - q2[4 * c4 + 2]; accB = __builtin_elementwise_fma(df, df, accB);
-                    df = (f2){v.w, v.w} - q2[4 * c4 + 3]; accA = __builtin_elementwise_fma(df, df, accA);
-                    df = (f2){w.w, w.w} - q2[4 * c4 + 3]; accB = __builtin_elementwise_fma(df, df, accB);
+                    const f2 vxy = {v.x, v.y}, vzw = {v.z, v.w}, wxy = {w.x, w.y}, wzw = {w.z, w.w};
+                    pk_dist_step4(accA, accB, vxy, vzw, wxy, wzw, q2[4 * c4 + 0], q2[4 * c4 + 1], q2[4 * c4 + 2],
+                                  q2[4 * c4 + 3]);
                 }
                 dA[0] = accA.x; dB[0] = accB.x;
                 dA[TQ - 1] = accA.y; dB[TQ - 1] = accB.y;
@@ -365,7 +409,7 @@ __global__ __launch_bounds__(kWave, 3) void knn_kernel(const KnnArgs a)
         }
     }
 #ifdef DMET_KNN_STAMP
-    if (threadIdx.x == 0 && blockIdx.x < (1 << 16)) g_knn_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && item < (1 << 16)) g_knn_stamps[item][1] = __builtin_amdgcn_s_memrealtime();
 #endif
     // final drain; whole-sweep tiles also emit the first k entries
 #pragma unroll
@@ -484,15 +528,15 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     // worst-case grid (the plan is on the device): every event adds at most one partial tile, and splitting the
     // fewer-than-`simds` tail tiles adds fewer than `simds` workgroups; surplus workgroups exit at once
     const int64_t tiles_max = (N + QT - 1) / QT + B;
-    const int64_t blocks = tiles_max + simds;
+    const int64_t blocks = (tiles_max + simds + kWavesPerGroup - 1) / kWavesPerGroup;
     unsigned dyn = 0;
 #ifdef DMET_KNN_EXPERIMENT
     if (const char *e = getenv("DMET_KNN_EXTRA_LDS")) dyn = (unsigned)atoi(e);
 #endif
     if (D == DP && aligned16(x))
-        hipLaunchKernelGGL((knn_kernel<DP, KP, TQ, true>), dim3((unsigned)blocks), dim3(kWave), dyn, st, a);
+        hipLaunchKernelGGL((knn_kernel<DP, KP, TQ, true>), dim3((unsigned)blocks), dim3(kWave * kWavesPerGroup), dyn, st, a);
     else
-        hipLaunchKernelGGL((knn_kernel<DP, KP, TQ, false>), dim3((unsigned)blocks), dim3(kWave), dyn, st, a);
+        hipLaunchKernelGGL((knn_kernel<DP, KP, TQ, false>), dim3((unsigned)blocks), dim3(kWave * kWavesPerGroup), dyn, st, a);
     DMET_LAUNCH_CHECK("knn_kernel");
     if (tiles_max > simds) {  // only then can the plan have split anything
         const int64_t slots = (int64_t)simds * QT;

@@ -80,6 +80,11 @@ int dmet_node_linear_split_f32(const float *x, int64_t N, int Hin, int Hout, con
                                const float *b, float *P, float *Q, dmet_stream_t stream);
 int dmet_gather_max_f32(const float *P, const float *Q, const int32_t *nbr, const int64_t *ptr, int B,
                         int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream);
+/* Same contract, LDS-resident form: one workgroup per (event, 8-channel slice) stages that slice of Q for the
+ * whole event in the CU's 160 KB LDS (events up to 5120 nodes; larger events gather from global memory inside the
+ * same kernel).  Needs ptr/B and H % 8 == 0.  The faster form for events of a few thousand nodes. */
+int dmet_gather_max_lds_f32(const float *P, const float *Q, const int32_t *nbr, const int64_t *ptr, int B,
+                            int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream);
 /* Backward of step 2 w.r.t. Q:  gQ[j,c] = sum over (i,s) with nbr[i,s]==j and arg[i,c]==s of g_out[i,c].
  * Deterministic (no float atomics): walks the reverse index rev_ptr[N+1] (int32), rev_slot[E] (int32,
  * entry = i*k+s, ascending inside a row) built by dmet_reverse_index(nbr, N*k, N, ...). */
