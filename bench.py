@@ -35,6 +35,7 @@ def parse_args():
     ap.add_argument("--nodes", type=int, default=4500)
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-events", type=int, default=0, help="0 = one event per host core (max 16)")
     return ap.parse_args()
@@ -105,11 +106,14 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU path in the product)"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import deepmetv2_amd as dm
     from deepmetv2_amd import _native, synth
