@@ -35,6 +35,8 @@ def parse_args():
     ap.add_argument("--nodes", type=int, default=4500)
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--ragged", type=int, nargs=2, metavar=("LO", "HI"), default=None,
+                    help="BASELINE configs[4]: event sizes drawn uniformly from [LO, HI] (seeded) instead of --nodes")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-events", type=int, default=0, help="0 = one event per host core (max 16)")
@@ -121,7 +123,8 @@ def main():
     from deepmetv2_amd.parallel import FlatModule, GradSync, train_step
 
     B, n, k = args.events_per_gpu, args.nodes, args.k
-    x, y, batch, ptr = synth.make_events([n] * B, seed=1234 + rank, device=dev)
+    sizes = [n] * B if args.ragged is None else synth.ragged_sizes(B, args.ragged[0], args.ragged[1], seed=1234 + rank)
+    x, y, batch, ptr = synth.make_events(sizes, seed=1234 + rank, device=dev)
     dm.register_batch(batch, ptr, B)
     N = x.shape[0]
 
@@ -195,7 +198,7 @@ def main():
         for name, (cnt, ms) in sorted(ksum.items()):
             kernels[name] = {"launches": cnt, "avg_us": round(ms * 1e3, 2)}
         if "knn" in ksum:
-            flops = 3.0 * B * n * n * 32           # sub, mul, add per (query, candidate, feature); D = 32
+            flops = 3.0 * sum(sz * sz for sz in sizes) * 32   # sub, mul, add per (query, candidate, feature); D = 32
             tf = flops / (ksum["knn"][1] * 1e-3) / 1e12
             kernels["knn"].update({"bound": "fp32_valu", "achieved_tflops": round(tf, 2),
                                    "peak_tflops": FP32_VALU_PEAK_TFLOPS, "frac": round(tf / FP32_VALU_PEAK_TFLOPS, 4)})
@@ -206,7 +209,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {B} events/GPU x {n} PF candidates x 11 features, k={k}, "
                                    f"2 DynamicEdgeConv layers (kNN rebuilt per layer in the 32-d embedding), fp32, "
-                                   f"{args.mode} step", "events_per_gpu": B, "nodes_per_event": n, "k": k,
+                                   f"{args.mode} step", "events_per_gpu": B, "nodes_per_event": n if args.ragged is None else f"U[{args.ragged[0]},{args.ragged[1]}]", "k": k,
                        "global_batch": B * world, "mode": args.mode, "parallelism": f"dp{world}"},
             "roofline": roof, "kernels": kernels,
         }

@@ -146,6 +146,66 @@ __global__ __launch_bounds__(256) void gather_max_kernel(const float *__restrict
     }
 }
 
+// Deep-MLP variant for k == 4*K4 (the kNN tables: k = 8/16/32): the kernel above is latency bound (ids -> 4 gathers
+// -> compare, 4 rows in flight per lane); here a lane loads all of its node's ids as int4 and has up to 16 row
+// gathers in flight before the compare chain starts.  Same results (same compare order).
+template <int H, bool WITH_ARG, int K4>
+__global__ __launch_bounds__(256) void gather_max_mlp_kernel(const float *__restrict__ P,
+                                                              const float *__restrict__ Q,
+                                                              const int32_t *__restrict__ nbr, int64_t N,
+                                                              float *__restrict__ out, uint8_t *__restrict__ arg)
+{
+    constexpr int LPN = H / 4;               // lanes per node
+    constexpr int NPB = 256 / LPN;           // nodes per block
+    constexpr int BATCH = (K4 < 4) ? K4 : 4; // int4 groups (= 4 rows each) gathered together
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int64_t node = (int64_t)bid * NPB + threadIdx.x / LPN;
+    const int c4 = threadIdx.x % LPN;
+    if (node >= N) return;
+    const int4 *row4 = reinterpret_cast<const int4 *>(nbr + node * (4 * K4));
+    const float4 *Q4 = reinterpret_cast<const float4 *>(Q);
+    int4 idv[K4];
+#pragma unroll
+    for (int q = 0; q < K4; ++q) idv[q] = row4[q];
+    const float4 p = reinterpret_cast<const float4 *>(P)[node * LPN + c4];
+    const float ninf = -__builtin_inff();
+    float4 best = make_float4(ninf, ninf, ninf, ninf);
+    int a0 = 255, a1 = 255, a2 = 255, a3 = 255;
+    bool any = false;
+#pragma unroll
+    for (int q0 = 0; q0 < K4; q0 += BATCH) {
+        float4 v[BATCH][4];
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) {
+            const int j[4] = {idv[q0 + q].x, idv[q0 + q].y, idv[q0 + q].z, idv[q0 + q].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                v[q][u] = (j[u] >= 0) ? Q4[(int64_t)j[u] * LPN + c4] : make_float4(ninf, ninf, ninf, ninf);
+        }
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) {
+            const int j[4] = {idv[q0 + q].x, idv[q0 + q].y, idv[q0 + q].z, idv[q0 + q].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = 4 * (q0 + q) + u;
+                any = any || (j[u] >= 0);
+                if (v[q][u].x > best.x) { best.x = v[q][u].x; a0 = s; }
+                if (v[q][u].y > best.y) { best.y = v[q][u].y; a1 = s; }
+                if (v[q][u].z > best.z) { best.z = v[q][u].z; a2 = s; }
+                if (v[q][u].w > best.w) { best.w = v[q][u].w; a3 = s; }
+            }
+        }
+    }
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (any) o = make_float4(p.x + best.x, p.y + best.y, p.z + best.z, p.w + best.w);
+    reinterpret_cast<float4 *>(out)[node * LPN + c4] = o;
+    if (WITH_ARG) {
+        uchar4 a = make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
+        if (!any) a = make_uchar4(255, 255, 255, 255);
+        reinterpret_cast<uchar4 *>(arg)[node * LPN + c4] = a;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // gather_max (LDS-resident form): one workgroup per (event, 8-channel slice).  The slice of Q for the whole event
 // (n_b x 32 B, 144 KB at 4500 nodes) is staged in the CU's 160 KB LDS once; the k neighbour rows of every node are
@@ -439,7 +499,24 @@ extern "C" int dmet_gather_max_f32(const float *P, const float *Q, const int32_t
             hipLaunchKernelGGL((gather_max_kernel<HH, false>), dim3((unsigned)blocks), dim3(256), 0, st, P, Q,  \
                                nbr, N, k, out, arg);                                                            \
     } while (0)
-    if (H == 32) DMET_GM(32);
+    if (H == 32 && (k == 8 || k == 16 || k == 32) && aligned16(nbr)) {
+        // the kNN tables of the hot path: deep-MLP variant
+        const int64_t blocks = (N + 31) / 32;
+#define DMET_GMM(K4_)                                                                                          \
+        do {                                                                                                   \
+            if (arg)                                                                                           \
+                hipLaunchKernelGGL((gather_max_mlp_kernel<32, true, K4_>), dim3((unsigned)blocks), dim3(256),  \
+                                   0, st, P, Q, nbr, N, out, arg);                                             \
+            else                                                                                               \
+                hipLaunchKernelGGL((gather_max_mlp_kernel<32, false, K4_>), dim3((unsigned)blocks), dim3(256), \
+                                   0, st, P, Q, nbr, N, out, arg);                                             \
+        } while (0)
+        if (k == 8) DMET_GMM(2);
+        else if (k == 16) DMET_GMM(4);
+        else DMET_GMM(8);
+#undef DMET_GMM
+    }
+    else if (H == 32) DMET_GM(32);
     else if (H == 64) DMET_GM(64);
     else if (H == 128) DMET_GM(128);
     else if (H == 16) DMET_GM(16);

@@ -9,18 +9,19 @@
 // cannot go to the matrix cores without changing the rounding).  Measured on MI355X (tools/valu_micro.hip) this
 // instruction mix saturates at ~75-80 TFLOP/s (3 flop per element) and needs packed math plus >= 3 wavefronts per
 // SIMD to get there, which shapes the design:
-//   * one 64-lane wavefront per workgroup; every lane OWNS 2 query nodes whose features sit in registers as
-//     float2 pairs, so the inner loop is v_pk_add_f32 / v_pk_fma_f32 (each half is an exact IEEE op: same bits);
+//   * a work item = one 64-lane wavefront (workgroups are 4 independent wavefronts); every lane OWNS 2 query nodes
+//     whose features sit in registers as float2 pairs, so the inner loop is v_pk_add_f32 / v_pk_fma_f32 (each half
+//     is an exact IEEE op: same bits);
 //   * candidate rows are staged into LDS in tiles and read back as wave-uniform (broadcast) ds_read_b128; two
 //     candidates are in flight per iteration (two independent fma chains per lane);
 //   * selection is deferred: a lane whose distance beats its current k-th best appends (d, j) to its private LDS
 //     queue; when any lane's queue is nearly full the whole wave drains its queues into the sorted top-k lists,
 //     which live in an L2-resident global workspace between drains (keeps VGPRs for the distance loop);
-//   * queries are assigned by global node index, so a wavefront may straddle two events: it then sweeps the union
-//     of their candidate ranges and masks per lane (taken only by boundary wavefronts);
-//   * load balance: all query tiles cost the same, so with T tiles on S SIMDs the last (T mod S) tiles would leave
-//     most of the chip idle for a whole sweep.  Those tail tiles are split over the candidate range into `split`
-//     sub-sweeps (separate workgroups, dispatched last) whose partial top-k lists a small merge kernel combines.
+//   * query tiles never straddle events (a straddling wavefront would sweep two events: a 2x straggler); the
+//     tile -> event map is a device-side plan (no host sync), events ordered longest first;
+//   * load balance: with T tiles on S SIMDs the last (T mod S) tiles would leave most of the chip idle for a whole
+//     sweep.  Those tail tiles are split over the candidate range into `split` sub-sweeps (dispatched last) whose
+//     partial top-k lists a small merge kernel combines.
 #include <stdlib.h>
 
 #include "common.h"
@@ -162,23 +163,45 @@ struct KnnArgs {
     float *wsd;            // [N][KP] running lists of whole-sweep tiles
     int32_t *wsj;
     const KnnPlan *plan;
-    const int32_t *tile_ptr;  // [B+1] exclusive prefix of per-event tile counts
+    const int32_t *order;     // [B] events longest first
+    const int32_t *tile_ptr;  // [B+1] exclusive prefix of per-position tile counts
     float *psd;            // [(tile-n_full)*tile_queries + slot][split][KP] partial lists of split tiles
     int32_t *psj;
 };
 
-// One workgroup: per-event tile counts -> exclusive prefix, then the tail-splitting plan for `simds` SIMDs:
-// whole sweeps for the largest multiple of the SIMD count, the remaining tiles cut into sub-sweeps.
+// One workgroup: events ordered LONGEST FIRST (a tile of an n-node event costs n candidates, so big events go out
+// first and the split tail consists of the smallest ones), per-position tile counts -> exclusive prefix, then the
+// tail-splitting plan for `simds` SIMDs: whole sweeps for the largest multiple of the SIMD count, the remaining
+// tiles cut into sub-sweeps.  order[p] = event at position p; tile_ptr is indexed by position.
+constexpr int kMaxSortedEvents = 4096;  // beyond this the O(B^2) ranking is skipped (identity order)
+
 __global__ __launch_bounds__(256) void knn_plan_kernel(const int64_t *__restrict__ ptr, int B, int tile_queries,
-                                                        int simds, int32_t *__restrict__ tile_ptr,
-                                                        KnnPlan *__restrict__ plan)
+                                                        int simds, int32_t *__restrict__ order,
+                                                        int32_t *__restrict__ tile_ptr, KnnPlan *__restrict__ plan)
 {
     __shared__ int part[256];
     const int tid = threadIdx.x;
+    if (B <= kMaxSortedEvents) {
+        for (int b = tid; b < B; b += 256) {
+            const int64_t nb = ptr[b + 1] - ptr[b];
+            int rank = 0;
+            for (int c = 0; c < B; ++c) {
+                const int64_t nc = ptr[c + 1] - ptr[c];
+                rank += (nc > nb || (nc == nb && c < b)) ? 1 : 0;
+            }
+            order[rank] = b;
+        }
+    } else {
+        for (int b = tid; b < B; b += 256) order[b] = b;
+    }
+    __syncthreads();
     const int chunk = (B + 255) / 256;
     const int lo = min(B, tid * chunk), hi = min(B, lo + chunk);
     int sum = 0;
-    for (int b = lo; b < hi; ++b) sum += (int)((ptr[b + 1] - ptr[b] + tile_queries - 1) / tile_queries);
+    for (int p = lo; p < hi; ++p) {
+        const int b = order[p];
+        sum += (int)((ptr[b + 1] - ptr[b] + tile_queries - 1) / tile_queries);
+    }
     part[tid] = sum;
     __syncthreads();
     if (tid == 0) {
@@ -200,13 +223,14 @@ __global__ __launch_bounds__(256) void knn_plan_kernel(const int64_t *__restrict
     }
     __syncthreads();
     int run = part[tid];
-    for (int b = lo; b < hi; ++b) {
-        tile_ptr[b] = run;
+    for (int p = lo; p < hi; ++p) {
+        const int b = order[p];
+        tile_ptr[p] = run;
         run += (int)((ptr[b + 1] - ptr[b] + tile_queries - 1) / tile_queries);
     }
 }
 
-// Event that owns tile t: the b with tile_ptr[b] <= t < tile_ptr[b+1] (events without tiles are skipped).
+// Position (in the longest-first order) that owns tile t: the p with tile_ptr[p] <= t < tile_ptr[p+1].
 __device__ __forceinline__ int find_tile_event(const int32_t *__restrict__ tile_ptr, int B, int t)
 {
     int lo = 0, hi = B;
@@ -283,9 +307,10 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 3) void knn_kernel(const Kn
         nsub = split;
     }
     if (tile >= total) return;
-    const int ev = find_tile_event(a.tile_ptr, a.B, tile);
+    const int pos = find_tile_event(a.tile_ptr, a.B, tile);
+    const int ev = a.order[pos];
     const int ev_lo = (int)ptr[ev], ev_hi = (int)ptr[ev + 1];
-    const int q_first = ev_lo + (tile - a.tile_ptr[ev]) * QT;
+    const int q_first = ev_lo + (tile - a.tile_ptr[pos]) * QT;
 
     // candidate range = the tile's own event (or one chunk of it for a split tile)
     int clo = ev_lo, chi = ev_hi;
@@ -443,8 +468,9 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const KnnArgs a, int til
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int tile = n_full + (int)(slot / tile_queries);
     if (tile >= total) return;
-    const int ev = find_tile_event(a.tile_ptr, a.B, tile);
-    const int64_t qi = a.ptr[ev] + (int64_t)(tile - a.tile_ptr[ev]) * tile_queries + (slot % tile_queries);
+    const int pos = find_tile_event(a.tile_ptr, a.B, tile);
+    const int ev = a.order[pos];
+    const int64_t qi = a.ptr[ev] + (int64_t)(tile - a.tile_ptr[pos]) * tile_queries + (slot % tile_queries);
     if (qi >= a.ptr[ev + 1]) return;
     const float *pd = a.psd + slot * split * KP;
     const int32_t *pj = a.psj + slot * split * KP;
@@ -489,6 +515,7 @@ constexpr int kMaxSimds = 4096;  // workspace bound for the split (tail) tiles: 
 
 struct KnnWorkspace {
     KnnPlan *plan;
+    int32_t *order;
     int32_t *tile_ptr;
     float *wsd;
     int32_t *wsj;
@@ -505,6 +532,7 @@ inline KnnWorkspace carve_workspace(void *ws, int64_t N, int B, int KP)
     size_t split_q = (size_t)kMaxSimds * 128;
     if ((size_t)N + 128 < split_q) split_q = (size_t)N + 128;
     w.plan = reinterpret_cast<KnnPlan *>(take(sizeof(KnnPlan)));
+    w.order = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
     w.tile_ptr = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
     w.wsd = reinterpret_cast<float *>(take(sizeof(float) * (size_t)N * KP));
     w.wsj = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)N * KP));
@@ -522,9 +550,9 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     constexpr int QT = kWave * TQ;
     int simds = num_simds();
     if (simds > kMaxSimds) simds = kMaxSimds;
-    hipLaunchKernelGGL(knn_plan_kernel, dim3(1), dim3(256), 0, st, ptr, B, QT, simds, w.tile_ptr, w.plan);
+    hipLaunchKernelGGL(knn_plan_kernel, dim3(1), dim3(256), 0, st, ptr, B, QT, simds, w.order, w.tile_ptr, w.plan);
     DMET_LAUNCH_CHECK("knn_plan_kernel");
-    KnnArgs a{x, ptr, B, N, D, k, nbr, dist, w.wsd, w.wsj, w.plan, w.tile_ptr, w.psd, w.psj};
+    KnnArgs a{x, ptr, B, N, D, k, nbr, dist, w.wsd, w.wsj, w.plan, w.order, w.tile_ptr, w.psd, w.psj};
     // worst-case grid (the plan is on the device): every event adds at most one partial tile, and splitting the
     // fewer-than-`simds` tail tiles adds fewer than `simds` workgroups; surplus workgroups exit at once
     const int64_t tiles_max = (N + QT - 1) / QT + B;

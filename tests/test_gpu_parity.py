@@ -71,6 +71,27 @@ def test_knn_full_size_event_property(dev):
     assert bool(((nbr >= 4500) == (torch.arange(9000).view(-1, 1) >= 4500)).all())  # never crosses events
 
 
+def test_knn_ragged_config5_full_size(dev):
+    """BASELINE configs[4]: 64 events of 500..8000 nodes, k=16.  Full oracle on the smallest and the largest event,
+    structural properties (self first, sorted, never crosses events) on all 270k nodes."""
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import synth
+    from oracle import ref_ops
+    sizes = synth.ragged_sizes(64, 500, 8000, seed=99)
+    x, batch, ptr = _ragged(sizes, 32, seed=55)
+    N = x.shape[0]
+    t = dm.knn_table(x.to(dev), 16, batch.to(dev), loop=True, num_events=64)
+    nbr, dist = t.nbr.cpu(), t.dist.cpu()
+    assert torch.equal(nbr[:, 0], torch.arange(N, dtype=torch.int32))
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all())
+    lo, hi = ptr[batch].view(-1, 1), ptr[batch + 1].view(-1, 1)
+    assert bool(((nbr >= lo) & (nbr < hi)).all())
+    for b in (int(torch.tensor(sizes).argmin()), int(torch.tensor(sizes).argmax())):
+        s, e = int(ptr[b]), int(ptr[b + 1])
+        ref, dref = ref_ops.knn_table(x[s:e], torch.tensor([0, e - s]), 16)
+        assert torch.equal(nbr[s:e], ref + s) and torch.equal(dist[s:e], dref)
+
+
 def test_radius_graph(dev):
     import deepmetv2_amd as dm
     from oracle import ref_ops
