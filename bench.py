@@ -35,6 +35,9 @@ def parse_args():
     ap.add_argument("--nodes", type=int, default=4500)
     ap.add_argument("--k", type=int, default=16)
     ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16 = BASELINE configs[2]: edge-MLP dense layer on the bf16 matrix cores, bf16 Q table "
+                         "(kNN, max, MET and the backward stay fp32)")
     ap.add_argument("--ragged", type=int, nargs=2, metavar=("LO", "HI"), default=None,
                     help="BASELINE configs[4]: event sizes drawn uniformly from [LO, HI] (seeded) instead of --nodes")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -129,7 +132,7 @@ def main():
     N = x.shape[0]
 
     torch.manual_seed(0)
-    model = Net(8, 3, graph="dynamic", k=k).to(dev)
+    model = Net(8, 3, graph="dynamic", k=k, edge_dtype=torch.bfloat16 if args.dtype == "bf16" else None).to(dev)
     flat = FlatModule(model)
     sync = GradSync(flat)
     sync.broadcast_state(0)
@@ -177,7 +180,7 @@ def main():
         # own P row H*4 + neighbour ids k*4 + output row H*4 [+ arg H*1 when training; the table says H*4, we
         # store the winning slot in one byte])
         H = 32
-        per_node = H * 4 + k * 4 + H * 4 + (H if args.mode == "train" else 0)
+        per_node = H * 4 + k * 4 + H * 4 + (H if args.mode == "train" else 0)   # same definition for both dtypes
         alg_bytes = per_node * N
         roof = None
         if "gather_max" in ksum:
@@ -206,9 +209,9 @@ def main():
             "metric": "events/sec (4.5k PF cands, k=16)", "value": round(events / elapsed, 1), "unit": "events/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: {B} events/GPU x {n} PF candidates x 11 features, k={k}, "
-                                   f"2 DynamicEdgeConv layers (kNN rebuilt per layer in the 32-d embedding), fp32, "
+                                   f"2 DynamicEdgeConv layers (kNN rebuilt per layer in the 32-d embedding), {'fp32' if args.dtype == 'f32' else 'bf16 edge-MLP on MFMA (configs[2])'}, "
                                    f"{args.mode} step", "events_per_gpu": B, "nodes_per_event": n if args.ragged is None else f"U[{args.ragged[0]},{args.ragged[1]}]", "k": k,
                        "global_batch": B * world, "mode": args.mode, "parallelism": f"dp{world}"},
             "roofline": roof, "kernels": kernels,

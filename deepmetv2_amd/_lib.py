@@ -30,6 +30,8 @@ SIGNATURES = {
     "dmet_node_linear_split_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dmet_gather_max_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "dmet_gather_max_lds_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
+    "dmet_node_linear_split_bf16": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dmet_gather_max_bf16q": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "dmet_gather_max_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
     "dmet_reverse_index_workspace_bytes": (_sz, [_i64, _i64]),
     "dmet_reverse_index": (_i, [_vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),

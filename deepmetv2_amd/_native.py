@@ -156,6 +156,41 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
     return out, arg
 
 
+def node_linear_split_bf16(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """bf16-MFMA variant: P fp32 [N,H], Q as bf16 [N,H] (gathered table)."""
+    dev = _require_device(x, W, b)
+    L = _lib.load()
+    x = _f32c(x, "x"); W = _f32c(W, "W")
+    N, Hin = x.shape
+    Hout = W.shape[0]
+    P = torch.empty((N, Hout), dtype=torch.float32, device=dev)
+    Qh = torch.empty((N, Hout), dtype=torch.bfloat16, device=dev)
+    bp = _f32c(b, "b").data_ptr() if b is not None else None
+    _t = timer.record('node_linear_split', dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_node_linear_split_bf16(x.data_ptr(), N, Hin, Hout, W.data_ptr(), bp, P.data_ptr(),
+                                                 Qh.data_ptr(), _stream(dev)), "dmet_node_linear_split_bf16")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
+    return P, Qh
+
+
+def gather_max_bf16q(P: torch.Tensor, Qh: torch.Tensor, nbr: torch.Tensor, want_arg: bool):
+    dev = _require_device(P, Qh, nbr)
+    L = _lib.load()
+    N, H = P.shape
+    k = nbr.shape[1]
+    out = torch.empty((N, H), dtype=torch.float32, device=dev)
+    arg = torch.empty((N, H), dtype=torch.uint8, device=dev) if want_arg else None
+    _t = timer.record('gather_max', dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_gather_max_bf16q(P.data_ptr(), Qh.data_ptr(), nbr.data_ptr(), N, k, H, out.data_ptr(),
+                                           arg.data_ptr() if want_arg else None, _stream(dev)), "dmet_gather_max_bf16q")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
+    return out, arg
+
+
 def gather_max_bwd(g_out: torch.Tensor, arg: torch.Tensor, rev_ptr: torch.Tensor, rev_slot: torch.Tensor,
                    k: int) -> torch.Tensor:
     dev = _require_device(g_out, arg, rev_ptr, rev_slot)

@@ -52,10 +52,16 @@ class _EdgeConvLinearMax(torch.autograd.Function):
     """out[i] = max_s (W.[x_i || x_j - x_i] + b), j = nbr[i,s], through P = x.(W1-W2)^T + b, Q = x.W2^T."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, table: NeighborTable):
+    def forward(ctx, x, weight, bias, table: NeighborTable, bf16: bool = False):
         need_grad = any(ctx.needs_input_grad[:3])
-        P, Q = _native.node_linear_split(x, weight, bias)
-        out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad)
+        if bf16:
+            # BASELINE configs[2]: dense layer on the bf16 matrix cores, bf16 Q table (half the gathered bytes);
+            # max / add / backward stay fp32 (straight-through over the bf16 roundings)
+            P, Qh = _native.node_linear_split_bf16(x, weight, bias)
+            out, arg = _native.gather_max_bf16q(P, Qh, table.nbr, want_arg=need_grad)
+        else:
+            P, Q = _native.node_linear_split(x, weight, bias)
+            out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad)
         if need_grad:
             ctx.save_for_backward(x, weight, arg)
             ctx.table = table
@@ -83,7 +89,7 @@ class _EdgeConvLinearMax(torch.autograd.Function):
             gW = torch.cat([gWd, gW2 - gWd], dim=1)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gP.sum(0)
-        return gx, gW, gb, None
+        return gx, gW, gb, None, None
 
 
 class _EdgeFeatures(torch.autograd.Function):
@@ -125,6 +131,8 @@ class EdgeConv(torch.nn.Module):
         self.aggr = aggr
         self.flow = flow
         self.node_dim = 0
+        # None: follow torch.autocast (bf16 autocast -> bf16 MFMA dense layer); or torch.float32 / torch.bfloat16
+        self.compute_dtype = None
         self.reset_parameters()
 
     def reset_parameters(self) -> None:
@@ -141,8 +149,15 @@ class EdgeConv(torch.nn.Module):
     def _forward_table(self, x: torch.Tensor, table: NeighborTable) -> torch.Tensor:
         lin = _as_fusable_linear(self.nn) if self.aggr == "max" else None
         if lin is not None and x.shape[1] * 2 == lin.in_features and table.k <= 255:  # arg slot is uint8
-            return _EdgeConvLinearMax.apply(x, lin.weight, lin.bias, table)
+            return _EdgeConvLinearMax.apply(x, lin.weight, lin.bias, table, self._use_bf16(lin, table))
         return self._forward_edges(x, table.edge_list())
+
+    def _use_bf16(self, lin: torch.nn.Linear, table: NeighborTable) -> bool:
+        dt = self.compute_dtype
+        if dt is None and torch.is_autocast_enabled():
+            dt = torch.get_autocast_gpu_dtype()
+        return (dt == torch.bfloat16 and lin.in_features == 64 and lin.out_features == 32
+                and table.k in (8, 16, 32))
 
     def _forward_edges(self, x: torch.Tensor, edges: EdgeList) -> torch.Tensor:
         N = x.shape[0]

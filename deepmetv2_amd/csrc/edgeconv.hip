@@ -11,12 +11,24 @@
 // Un-fused path (arbitrary nn / arbitrary edge list): edge_features -> user nn -> segment_max / segment_sum.
 #include <stdlib.h>
 
+#include <hip/hip_bf16.h>
+
 #include "common.h"
 
 namespace dmet {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int xcd_swizzle(int bid, int nblk)
+{
+    // bijective remap: blocks sharing an XCD (bid % 8) get one contiguous chunk of the grid
+    const int q = nblk / kNumXcd, rm = nblk % kNumXcd;
+    const int xcd = bid % kNumXcd, idx = bid / kNumXcd;
+    const int base = (xcd < rm) ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q;
+    return base + idx;
+}
+
 
 // ---------------------------------------------------------------------------------------------------------
 // node_linear_split: one wavefront computes [32 nodes] x [HOUT] for both P and Q with 32x32x2 fp32 MFMAs.
@@ -87,18 +99,163 @@ __global__ __launch_bounds__(256) void node_linear_split_kernel(const float *__r
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// bf16 variant of the node-level dense layer (BASELINE configs[2]): x and the split weights are rounded to bf16
+// (RNE) and multiplied on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate); P stays fp32 (it is the
+// node's own row, read once), Q is STORED as bf16 because it is the table that is gathered k times per node.
+// Operand maps (32x32x16): lane l (r = l&31, h = l>>5) holds A[row r][k = 8h+j], B[k = 8h+j][col r], j = 0..7.
+// ---------------------------------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f)
+{
+    __hip_bfloat16 h = __float2bfloat16(f);
+    return *reinterpret_cast<unsigned short *>(&h);
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
+template <int HIN, int HOUT>
+__global__ __launch_bounds__(256) void node_linear_split_bf16_kernel(const float *__restrict__ x, int64_t N,
+                                                                      const float *__restrict__ W,
+                                                                      const float *__restrict__ bias,
+                                                                      float *__restrict__ P,
+                                                                      unsigned short *__restrict__ Qh)
+{
+    constexpr int KB = HIN / 16;    // k-blocks of 16 features
+    constexpr int JT = HOUT / 32;
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t ntiles = (N + 31) / 32;
+
+    bf16x8 wd[JT][KB], w2[JT][KB];
+    float bj[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        const float *wrow = W + (int64_t)(jt * 32 + r) * (2 * HIN);
+#pragma unroll
+        for (int s = 0; s < KB; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = wrow[16 * s + 8 * h + j];
+                const float b2 = wrow[HIN + 16 * s + 8 * h + j];
+                wd[jt][s][j] = (short)f32_to_bf16_rne(a - b2);
+                w2[jt][s][j] = (short)f32_to_bf16_rne(b2);
+            }
+        bj[jt] = bias ? bias[jt * 32 + r] : 0.0f;
+    }
+    for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+        const int64_t node = tile * 32 + r;
+        const int64_t nload = node < N ? node : N - 1;
+        bf16x8 a[KB];
+#pragma unroll
+        for (int s = 0; s < KB; ++s) {
+            const float4 *src = reinterpret_cast<const float4 *>(x + nload * HIN + 16 * s + 8 * h);
+            const float4 v0 = src[0], v1 = src[1];
+            a[s][0] = (short)f32_to_bf16_rne(v0.x); a[s][1] = (short)f32_to_bf16_rne(v0.y);
+            a[s][2] = (short)f32_to_bf16_rne(v0.z); a[s][3] = (short)f32_to_bf16_rne(v0.w);
+            a[s][4] = (short)f32_to_bf16_rne(v1.x); a[s][5] = (short)f32_to_bf16_rne(v1.y);
+            a[s][6] = (short)f32_to_bf16_rne(v1.z); a[s][7] = (short)f32_to_bf16_rne(v1.w);
+        }
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            f32x16 accP, accQ;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { accP[e] = bj[jt]; accQ[e] = 0.0f; }
+#pragma unroll
+            for (int s = 0; s < KB; ++s) {
+                accP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], wd[jt][s], accP, 0, 0, 0);
+                accQ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], w2[jt][s], accQ, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int64_t n = tile * 32 + row;
+                if (n < N) {
+                    P[n * HOUT + jt * 32 + r] = accP[e];
+                    Qh[n * HOUT + jt * 32 + r] = f32_to_bf16_rne(accQ[e]);
+                }
+            }
+        }
+    }
+}
+
+// gather+max over a bf16 Q table (H = 32): 4 lanes per node, 8 channels (16 B of bf16) per lane.
+template <bool WITH_ARG, int K4>
+__global__ __launch_bounds__(256) void gather_max_bf16q_kernel(const float *__restrict__ P,
+                                                                const unsigned short *__restrict__ Qh,
+                                                                const int32_t *__restrict__ nbr, int64_t N,
+                                                                float *__restrict__ out, uint8_t *__restrict__ arg)
+{
+    constexpr int H = 32, LPN = 4, NPB = 256 / LPN;
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int64_t node = (int64_t)bid * NPB + threadIdx.x / LPN;
+    const int c8 = threadIdx.x % LPN;
+    if (node >= N) return;
+    const int4 *row4 = reinterpret_cast<const int4 *>(nbr + node * (4 * K4));
+    const uint4 *Q16 = reinterpret_cast<const uint4 *>(Qh);    // 8 bf16 per uint4; 4 per row
+    int4 idv[K4];
+#pragma unroll
+    for (int q = 0; q < K4; ++q) idv[q] = row4[q];
+    const float4 p0 = reinterpret_cast<const float4 *>(P)[node * (H / 4) + 2 * c8];
+    const float4 p1 = reinterpret_cast<const float4 *>(P)[node * (H / 4) + 2 * c8 + 1];
+    const float ninf = -__builtin_inff();
+    float best[8];
+    int a[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { best[c] = ninf; a[c] = 255; }
+    bool any = false;
+#pragma unroll
+    for (int q0 = 0; q0 < K4; q0 += 2) {
+        uint4 v[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j[4] = {idv[q0 + q].x, idv[q0 + q].y, idv[q0 + q].z, idv[q0 + q].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                v[q][u] = (j[u] >= 0) ? Q16[(int64_t)j[u] * LPN + c8] : make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);  // -inf pairs
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j[4] = {idv[q0 + q].x, idv[q0 + q].y, idv[q0 + q].z, idv[q0 + q].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = 4 * (q0 + q) + u;
+                any = any || (j[u] >= 0);
+                const unsigned w[4] = {v[q][u].x, v[q][u].y, v[q][u].z, v[q][u].w};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float lo = __uint_as_float(w[m] << 16), hi = __uint_as_float(w[m] & 0xffff0000u);
+                    if (lo > best[2 * m]) { best[2 * m] = lo; a[2 * m] = s; }
+                    if (hi > best[2 * m + 1]) { best[2 * m + 1] = hi; a[2 * m + 1] = s; }
+                }
+            }
+        }
+    }
+    float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
+    if (any) {
+        o0 = make_float4(p0.x + best[0], p0.y + best[1], p0.z + best[2], p0.w + best[3]);
+        o1 = make_float4(p1.x + best[4], p1.y + best[5], p1.z + best[6], p1.w + best[7]);
+    }
+    reinterpret_cast<float4 *>(out)[node * (H / 4) + 2 * c8] = o0;
+    reinterpret_cast<float4 *>(out)[node * (H / 4) + 2 * c8 + 1] = o1;
+    if (WITH_ARG) {
+        uint2 pk;
+        if (any) {
+            pk.x = (unsigned)a[0] | ((unsigned)a[1] << 8) | ((unsigned)a[2] << 16) | ((unsigned)a[3] << 24);
+            pk.y = (unsigned)a[4] | ((unsigned)a[5] << 8) | ((unsigned)a[6] << 16) | ((unsigned)a[7] << 24);
+        } else {
+            pk.x = pk.y = 0xffffffffu;
+        }
+        reinterpret_cast<uint2 *>(arg)[node * LPN + c8] = pk;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // gather_max (L2-gather form): H/4 lanes per node, each lane owns 4 channels; neighbours' Q rows come from the
 // XCD's L2 (block ids are remapped so one XCD works on a contiguous window of events at a time).
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int xcd_swizzle(int bid, int nblk)
-{
-    // bijective remap: blocks sharing an XCD (bid % 8) get one contiguous chunk of the grid
-    const int q = nblk / kNumXcd, rm = nblk % kNumXcd;
-    const int xcd = bid % kNumXcd, idx = bid / kNumXcd;
-    const int base = (xcd < rm) ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q;
-    return base + idx;
-}
-
 template <int H, bool WITH_ARG>
 __global__ __launch_bounds__(256) void gather_max_kernel(const float *__restrict__ P, const float *__restrict__ Q,
                                                           const int32_t *__restrict__ nbr, int64_t N, int k,
@@ -217,31 +374,25 @@ __global__ __launch_bounds__(256) void gather_max_mlp_kernel(const float *__rest
 constexpr int kSliceC = 8;                         // channels per slice
 constexpr int kLdsGatherThreads = 1024;
 constexpr int kLdsGatherBytes = 160 * 1024;        // whole LDS of a gfx950 CU
-constexpr int kLdsGatherRows = kLdsGatherBytes / (kSliceC * 4);  // 5120 nodes per event fit
+constexpr int kLdsGatherRows = kLdsGatherBytes / (kSliceC * 4);  // 5120 rows: events up to 5119 nodes (+ the -inf row)
 
-template <int K4>
-__device__ __forceinline__ void load_ids(const int32_t *__restrict__ row, int k, bool vec, int4 (&ids)[K4])
-{
-#pragma unroll
-    for (int q = 0; q < K4; ++q) {
-        if (vec) ids[q] = *reinterpret_cast<const int4 *>(row + 4 * q);
-        else {
-            ids[q].x = (4 * q + 0 < k) ? row[4 * q + 0] : -1;
-            ids[q].y = (4 * q + 1 < k) ? row[4 * q + 1] : -1;
-            ids[q].z = (4 * q + 2 < k) ? row[4 * q + 2] : -1;
-            ids[q].w = (4 * q + 3 < k) ? row[4 * q + 3] : -1;
-        }
-    }
-}
+// One (value, slot) update of the running maximum: best = max(best, v) keeping the LOWEST slot on ties (strict >),
+// as three VALU ops on VCC.  Written as asm so the 64 compares of a node are not hoisted into 64 live SGPR masks
+// (hipcc then spills them through v_writelane / v_readlane, which dominated the kernel).
+#define DMET_MAX_ARG(best, a, v, slot)                                                                            \
+    asm("v_cmp_gt_f32 vcc, %2, %0\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_cndmask_b32_e64 %1, %1, %3, vcc"          \
+        : "+v"(best), "+v"(a) : "v"(v), "n"(slot) : "vcc")
+#define DMET_MAX_ONLY(best, v) asm("v_max_f32 %0, %0, %1" : "+v"(best) : "v"(v))
 
-// K4 = number of int4 id loads per node (k <= 4*K4): ids of the NEXT node and its P slice are prefetched while the
-// current node's rows are gathered from LDS, and the Q slice is staged with all of a thread's loads in flight.
+// K4 = number of int4 id loads per node (k == 4*K4).  LDS image: rows 0..n-1 = the event's Q slice, row n = -inf
+// (ids < 0 and anything outside the event map to it, so the gather needs no per-neighbour branch).  Per node all
+// 4*K4 LDS reads are issued before the compare chain; the next node's ids and P slice are prefetched meanwhile.
 template <bool WITH_ARG, int K4, int GML_MODE = 0>
 __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ nbr,
     const int64_t *__restrict__ ptr, int B, int k, int H, float *__restrict__ out, uint8_t *__restrict__ arg)
 {
-    __shared__ __attribute__((aligned(16))) float4 qs[kLdsGatherRows * 2];   // [n_b][2] float4 = 8 channels/node
+    __shared__ __attribute__((aligned(16))) float4 qs[kLdsGatherRows * 2];   // [n_b + 1][2] float4 = 8 channels/node
     constexpr int RPI = kLdsGatherThreads / 2;                                // rows per iteration (2 lanes per node)
     const int nsl = H / kSliceC;
     // block -> (event, slice): slices of one event are 8 blocks apart (same XCD under round-robin placement)
@@ -252,7 +403,6 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     const int lo = (int)ptr[b], hi = (int)ptr[b + 1];
     const int n = hi - lo;
     if (n <= 0) return;
-    const bool in_lds = n <= kLdsGatherRows;
     const int h4 = H / 4;                       // float4s per full row
     const float4 *Q4 = reinterpret_cast<const float4 *>(Q);
     const float4 *P4 = reinterpret_cast<const float4 *>(P);
@@ -260,16 +410,43 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     const int r0 = threadIdx.x >> 1;
     const int col4 = sl * 2 + half;             // float4 column of this lane inside a full row
     const float ninf = -__builtin_inff();
-    const bool vec_ids = (k == 4 * K4) ;        // rows of ids are int4-aligned (nbr is 16-B aligned, k % 4 == 0)
+
+    if (n + 1 > kLdsGatherRows) {
+        // event too large for the LDS image: same arithmetic, rows gathered from global memory (L2)
+        for (int r = r0; r < n; r += RPI) {
+            const int64_t node = lo + r;
+            float4 best = make_float4(ninf, ninf, ninf, ninf);
+            int a0 = 255, a1 = 255, a2 = 255, a3 = 255;
+            for (int s = 0; s < k; ++s) {
+                const int j = nbr[node * k + s];
+                if (j < 0) continue;
+                const float4 v = Q4[(int64_t)j * h4 + col4];
+                if (v.x > best.x) { best.x = v.x; a0 = s; }
+                if (v.y > best.y) { best.y = v.y; a1 = s; }
+                if (v.z > best.z) { best.z = v.z; a2 = s; }
+                if (v.w > best.w) { best.w = v.w; a3 = s; }
+            }
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a0 != 255) {
+                const float4 p = P4[node * h4 + col4];
+                o = make_float4(p.x + best.x, p.y + best.y, p.z + best.z, p.w + best.w);
+            }
+            reinterpret_cast<float4 *>(out)[node * h4 + col4] = o;
+            if (WITH_ARG)
+                reinterpret_cast<uchar4 *>(arg)[node * h4 + col4] =
+                    make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
+        }
+        return;
+    }
 
     // stage the Q slice with LDS-DMA (global_load_lds_dwordx4: per-lane source address, LDS destination =
     // wave-uniform base + lane*16, no registers, every chunk of the wave in flight at once); 32 rows per chunk
-    if (in_lds && GML_MODE != 1) {
+    if (GML_MODE != 1) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int nchunk = (n + 31) / 32;
         for (int c = wave; c < nchunk; c += kLdsGatherThreads / 64) {
             int row = 32 * c + (lane >> 1);
-            row = min(row, n - 1);   // tail lanes re-read the last row; their LDS rows are never gathered
+            row = min(row, n - 1);   // tail lanes re-read the last row into rows >= n (row n is rewritten below)
             const float4 *src = Q4 + (int64_t)(lo + row) * h4 + sl * 2 + (lane & 1);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(qs + 64 * c), 16, 0, 0);
@@ -278,45 +455,67 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     // first node's ids and P slice
     int4 ids[K4];
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r0 < n) { load_ids<K4>(nbr + (int64_t)(lo + r0) * k, k, vec_ids, ids); pv = P4[(int64_t)(lo + r0) * h4 + col4]; }
+    if (r0 < n) {
+        const int4 *row4 = reinterpret_cast<const int4 *>(nbr + (int64_t)(lo + r0) * k);
+#pragma unroll
+        for (int q = 0; q < K4; ++q) ids[q] = row4[q];
+        pv = P4[(int64_t)(lo + r0) * h4 + col4];
+    }
     __builtin_amdgcn_s_waitcnt(0);   // LDS-DMA is counted by vmcnt and is not covered by the barrier itself
+    __syncthreads();
+    if (threadIdx.x < 2) qs[n * 2 + threadIdx.x] = make_float4(ninf, ninf, ninf, ninf);   // the -inf row
     __syncthreads();
 
     for (int r = r0; r < n; r += RPI) {
         const int64_t node = lo + r;
-        int4 cur[K4];
+        unsigned off[4 * K4];
 #pragma unroll
-        for (int q = 0; q < K4; ++q) cur[q] = ids[q];
+        for (int q = 0; q < K4; ++q) {
+            off[4 * q + 0] = min((unsigned)(ids[q].x - lo), (unsigned)n) * 2 + half;
+            off[4 * q + 1] = min((unsigned)(ids[q].y - lo), (unsigned)n) * 2 + half;
+            off[4 * q + 2] = min((unsigned)(ids[q].z - lo), (unsigned)n) * 2 + half;
+            off[4 * q + 3] = min((unsigned)(ids[q].w - lo), (unsigned)n) * 2 + half;
+        }
         const float4 p = pv;
-        if (r + RPI < n) { load_ids<K4>(nbr + (int64_t)(lo + r + RPI) * k, k, vec_ids, ids); pv = P4[(int64_t)(lo + r + RPI) * h4 + col4]; }
-        float4 best = make_float4(ninf, ninf, ninf, ninf);
+        if (r + RPI < n) {
+            const int4 *row4 = reinterpret_cast<const int4 *>(nbr + (node + RPI) * k);
+#pragma unroll
+            for (int q = 0; q < K4; ++q) ids[q] = row4[q];
+            pv = P4[(node + RPI) * h4 + col4];
+        }
+        float bx = ninf, by = ninf, bz = ninf, bw = ninf;
         int a0 = 255, a1 = 255, a2 = 255, a3 = 255;
-        bool any = false;
 #pragma unroll
-        for (int q = 0; q < (GML_MODE == 2 ? 0 : K4); ++q) {
-            const int j[4] = {cur[q].x, cur[q].y, cur[q].z, cur[q].w};
-            float4 v[4];
+        for (int q0 = 0; q0 < (GML_MODE == 2 ? 0 : K4); q0 += 2) {
+            float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (j[u] < 0) v[u] = make_float4(ninf, ninf, ninf, ninf);
-                else if (in_lds) v[u] = qs[(j[u] - lo) * 2 + half];
-                else v[u] = Q4[(int64_t)j[u] * h4 + col4];
-            }
+            for (int u = 0; u < 8; ++u) v[u] = qs[off[4 * q0 + u]];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                any = any || (j[u] >= 0);
-                if (v[u].x > best.x) { best.x = v[u].x; a0 = 4 * q + u; }
-                if (v[u].y > best.y) { best.y = v[u].y; a1 = 4 * q + u; }
-                if (v[u].z > best.z) { best.z = v[u].z; a2 = 4 * q + u; }
-                if (v[u].w > best.w) { best.w = v[u].w; a3 = 4 * q + u; }
+            for (int u = 0; u < 8; ++u) {
+                if (WITH_ARG) {
+                    switch (4 * q0 + u) {   // the slot must be an immediate
+#define DMET_CASE(S_) case S_: DMET_MAX_ARG(bx, a0, v[u].x, S_); DMET_MAX_ARG(by, a1, v[u].y, S_); \
+                               DMET_MAX_ARG(bz, a2, v[u].z, S_); DMET_MAX_ARG(bw, a3, v[u].w, S_); break;
+                        DMET_CASE(0) DMET_CASE(1) DMET_CASE(2) DMET_CASE(3) DMET_CASE(4) DMET_CASE(5) DMET_CASE(6)
+                        DMET_CASE(7) DMET_CASE(8) DMET_CASE(9) DMET_CASE(10) DMET_CASE(11) DMET_CASE(12)
+                        DMET_CASE(13) DMET_CASE(14) DMET_CASE(15) DMET_CASE(16) DMET_CASE(17) DMET_CASE(18)
+                        DMET_CASE(19) DMET_CASE(20) DMET_CASE(21) DMET_CASE(22) DMET_CASE(23) DMET_CASE(24)
+                        DMET_CASE(25) DMET_CASE(26) DMET_CASE(27) DMET_CASE(28) DMET_CASE(29) DMET_CASE(30)
+                        DMET_CASE(31)
+#undef DMET_CASE
+                    }
+                } else {
+                    DMET_MAX_ONLY(bx, v[u].x); DMET_MAX_ONLY(by, v[u].y);
+                    DMET_MAX_ONLY(bz, v[u].z); DMET_MAX_ONLY(bw, v[u].w);
+                }
             }
         }
+        const bool any = WITH_ARG ? (a0 != 255) : (bx > ninf);
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (any) o = make_float4(p.x + best.x, p.y + best.y, p.z + best.z, p.w + best.w);
+        if (any) o = make_float4(p.x + bx, p.y + by, p.z + bz, p.w + bw);
         reinterpret_cast<float4 *>(out)[node * h4 + col4] = o;
         if (WITH_ARG) {
-            uchar4 a = make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
-            if (!any) a = make_uchar4(255, 255, 255, 255);
+            const uchar4 a = make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
             reinterpret_cast<uchar4 *>(arg)[node * h4 + col4] = a;
         }
     }
@@ -529,6 +728,51 @@ extern "C" int dmet_gather_max_f32(const float *P, const float *Q, const int32_t
     return 0;
 }
 
+extern "C" int dmet_node_linear_split_bf16(const float *x, int64_t N, int Hin, int Hout, const float *W, const float *b,
+                                           float *P, uint16_t *Qh, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0, "dmet_node_linear_split_bf16: N<0");
+    if (N == 0) return 0;
+    DMET_REQUIRE(x && W && P && Qh, "dmet_node_linear_split_bf16: null pointer");
+    DMET_REQUIRE(aligned16(x) && aligned16(P) && aligned16(Qh), "dmet_node_linear_split_bf16: pointers must be 16-B aligned");
+    DMET_REQUIRE(Hin == 32 && Hout == 32, "dmet_node_linear_split_bf16: only (Hin,Hout)=(32,32) is built, got (%d,%d)", Hin, Hout);
+    const int64_t ntiles = (N + 31) / 32;
+    int64_t blocks = (ntiles + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((node_linear_split_bf16_kernel<32, 32>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x,
+                       N, W, b, P, Qh);
+    DMET_LAUNCH_CHECK("node_linear_split_bf16_kernel");
+    return 0;
+}
+
+extern "C" int dmet_gather_max_bf16q(const float *P, const uint16_t *Qh, const int32_t *nbr, int64_t N, int k, int H,
+                                     float *out, uint8_t *arg, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_gather_max_bf16q: N out of range");
+    DMET_REQUIRE(H == 32, "dmet_gather_max_bf16q: only H=32 is built, got %d", H);
+    DMET_REQUIRE(k == 8 || k == 16 || k == 32, "dmet_gather_max_bf16q: k=%d must be 8, 16 or 32", k);
+    if (N == 0) return 0;
+    DMET_REQUIRE(P && Qh && nbr && out, "dmet_gather_max_bf16q: null pointer");
+    DMET_REQUIRE(aligned16(P) && aligned16(Qh) && aligned16(out) && aligned16(nbr), "dmet_gather_max_bf16q: pointers must be 16-B aligned");
+    hipStream_t st = as_stream(stream);
+    const int64_t blocks = (N + 63) / 64;
+#define DMET_GMB(K4_)                                                                                           \
+    do {                                                                                                        \
+        if (arg)                                                                                                \
+            hipLaunchKernelGGL((gather_max_bf16q_kernel<true, K4_>), dim3((unsigned)blocks), dim3(256), 0, st,  \
+                               P, Qh, nbr, N, out, arg);                                                        \
+        else                                                                                                    \
+            hipLaunchKernelGGL((gather_max_bf16q_kernel<false, K4_>), dim3((unsigned)blocks), dim3(256), 0, st, \
+                               P, Qh, nbr, N, out, arg);                                                        \
+    } while (0)
+    if (k == 8) DMET_GMB(2);
+    else if (k == 16) DMET_GMB(4);
+    else DMET_GMB(8);
+#undef DMET_GMB
+    DMET_LAUNCH_CHECK("gather_max_bf16q_kernel");
+    return 0;
+}
+
 extern "C" int dmet_gather_max_lds_f32(const float *P, const float *Q, const int32_t *nbr, const int64_t *ptr, int B,
                                        int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream)
 {
@@ -563,10 +807,10 @@ extern "C" int dmet_gather_max_lds_f32(const float *P, const float *Q, const int
         return 0;
     }
 #endif
-    if (k <= 8) DMET_GML(2);
-    else if (k <= 16) DMET_GML(4);
-    else if (k <= 32) DMET_GML(8);
-    else return dmet_gather_max_f32(P, Q, nbr, ptr, B, N, k, H, out, arg, stream);  // wide tables: L2 form
+    if (k == 8) DMET_GML(2);
+    else if (k == 16) DMET_GML(4);
+    else if (k == 32) DMET_GML(8);
+    else return dmet_gather_max_f32(P, Q, nbr, ptr, B, N, k, H, out, arg, stream);  // other widths: L2 form
 #undef DMET_GML
     DMET_LAUNCH_CHECK("gather_max_lds_kernel");
     return 0;

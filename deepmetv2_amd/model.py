@@ -31,7 +31,7 @@ def _run(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
 
 class GraphMETNetwork(nn.Module):
     def __init__(self, continuous_dim: int, cat_dim: int, output_dim: int = 1, hidden_dim: int = 32,
-                 conv_depth: int = 1, graph: str = "static", k: int = 16):
+                 conv_depth: int = 1, graph: str = "static", k: int = 16, edge_dtype=None):
         super().__init__()
         if graph not in ("static", "dynamic"):
             raise ValueError("graph must be 'static' or 'dynamic'")
@@ -48,6 +48,7 @@ class GraphMETNetwork(nn.Module):
         for _ in range(conv_depth):
             message = nn.Sequential(nn.Linear(2 * hidden_dim, hidden_dim))
             conv = DynamicEdgeConv(nn=message, k=k) if graph == "dynamic" else EdgeConv(nn=message).jittable()
+            conv.compute_dtype = edge_dtype   # torch.bfloat16 -> bf16-MFMA edge MLP (BASELINE configs[2])
             self.conv_continuous.append(nn.ModuleList([conv, nn.BatchNorm1d(hidden_dim)]))
         self.output = nn.Sequential(nn.Linear(hidden_dim, h), nn.ELU(), nn.Linear(h, output_dim))
         self.pdgs = list(PDG_CLASSES)
@@ -75,10 +76,10 @@ class GraphMETNetwork(nn.Module):
 class Net(nn.Module):
     """net.py:38-47: GraphMETNetwork(output_dim=1, hidden_dim=32, conv_depth=2) followed by a sigmoid."""
 
-    def __init__(self, continuous_dim: int, categorical_dim: int, graph: str = "static", k: int = 16):
+    def __init__(self, continuous_dim: int, categorical_dim: int, graph: str = "static", k: int = 16, edge_dtype=None):
         super().__init__()
         self.graphnet = GraphMETNetwork(continuous_dim, categorical_dim, output_dim=1, hidden_dim=32,
-                                        conv_depth=2, graph=graph, k=k)
+                                        conv_depth=2, graph=graph, k=k, edge_dtype=edge_dtype)
 
     def forward(self, x_cont, x_cat, edge_index, batch):
         return torch.sigmoid(self.graphnet(x_cont, x_cat, edge_index, batch))

@@ -85,6 +85,13 @@ int dmet_gather_max_f32(const float *P, const float *Q, const int32_t *nbr, cons
  * same kernel).  Needs ptr/B and H % 8 == 0.  The faster form for events of a few thousand nodes. */
 int dmet_gather_max_lds_f32(const float *P, const float *Q, const int32_t *nbr, const int64_t *ptr, int B,
                             int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream);
+/* bf16 variant (BASELINE configs[2]): x and the split weights rounded to bf16 (RNE), multiplied on the bf16 matrix
+ * cores with fp32 accumulation; P stays fp32, Q is stored as bf16 (raw bits) and gathered as 64-B rows.
+ * Built for Hin = Hout = 32, k in {8,16,32}.  Backward is shared with the fp32 path (arg-based, fp32). */
+int dmet_node_linear_split_bf16(const float *x, int64_t N, int Hin, int Hout, const float *W, const float *b,
+                                float *P, uint16_t *Qh, dmet_stream_t stream);
+int dmet_gather_max_bf16q(const float *P, const uint16_t *Qh, const int32_t *nbr, int64_t N, int k, int H,
+                          float *out, uint8_t *arg, dmet_stream_t stream);
 /* Backward of step 2 w.r.t. Q:  gQ[j,c] = sum over (i,s) with nbr[i,s]==j and arg[i,c]==s of g_out[i,c].
  * Deterministic (no float atomics): walks the reverse index rev_ptr[N+1] (int32), rev_slot[E] (int32,
  * entry = i*k+s, ascending inside a row) built by dmet_reverse_index(nbr, N*k, N, ...). */

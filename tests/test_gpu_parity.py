@@ -135,6 +135,63 @@ def test_dynamic_edgeconv_fused_fwd_bwd(dev, sizes, H, k):
     _close(lin[0].bias.grad.cpu(), gb_ref, rtol=1e-4, atol=1e-5 * float(gb_ref.abs().max()))
 
 
+@pytest.mark.parametrize("sizes,k", [([256], 8), ([50, 450, 800], 16), ([1, 3, 0, 17, 129], 16), ([300, 100], 32)])
+def test_dynamic_edgeconv_bf16_mfma(dev, sizes, k):
+    """BASELINE configs[2]: bf16 edge-MLP on the matrix cores.  (a) tight against a torch emulation of the same
+    recipe (x, W1-W2, W2 rounded to bf16, fp32 accumulate, Q stored as bf16); (b) within the stated bf16 bar of
+    the fp32 PyG-shaped oracle (rtol 2e-2); kNN stays fp32-exact; backward against the oracle's."""
+    import deepmetv2_amd as dm
+    from oracle import ref_ops
+    H = 32
+    x, batch, ptr = _ragged(sizes, H, seed=70 + k, dup=True)
+    lin = torch.nn.Sequential(torch.nn.Linear(2 * H, H))
+    conv = dm.DynamicEdgeConv(nn=lin, k=k)
+    conv.compute_dtype = torch.bfloat16
+    W, b = lin[0].weight.detach(), lin[0].bias.detach()
+    xr = x.clone().requires_grad_(True)
+    out_ref = ref_ops.dynamic_edge_conv(xr, batch, lin, k)
+    gup = torch.randn(out_ref.shape, generator=torch.Generator().manual_seed(1))
+    out_ref.backward(gup)
+    gW_ref, gx_ref = lin[0].weight.grad.clone(), xr.grad.clone()
+    lin.zero_grad()
+    # emulation of the bf16 recipe on the oracle's graph
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    xb = bf(x)
+    Pe = xb @ bf(W[:, :H] - W[:, H:]).t() + b
+    Qe = bf(xb @ bf(W[:, H:]).t())
+    nbr, _ = ref_ops.knn_table(x, ptr, k)
+    g = Qe[nbr.long().clamp(min=0)]
+    g = torch.where((nbr >= 0).unsqueeze(-1), g, torch.full_like(g, float("-inf")))
+    emu = Pe + g.max(dim=1).values
+    conv = conv.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    out = conv(xd, batch.to(dev))
+    out.backward(gup.to(dev))
+    o = out.detach().cpu()
+    # (a) same recipe: only the accumulation order inside the MFMA and rare bf16 rounding flips of Q differ
+    torch.testing.assert_close(o, emu, rtol=1e-2, atol=1e-2 * float(emu.abs().max()) * 2 ** -6)
+    assert float((o - emu).abs().median()) < 1e-5 * max(1.0, float(emu.abs().max()))
+    # (b) the stated bf16 bar against the fp32 oracle
+    torch.testing.assert_close(o, out_ref.detach(), rtol=2e-2, atol=2e-2 * float(out_ref.abs().max()))
+    # backward: fp32 arithmetic routed through the winners the bf16 table selected (straight-through over the
+    # roundings).  Emulate exactly that: winners from the emulated table (lowest slot on ties), fp32 weights.
+    valid = (nbr >= 0).unsqueeze(-1)
+    slot = (g == g.max(dim=1, keepdim=True).values).float().argmax(dim=1)                  # [N,H] lowest winning slot
+    src = torch.gather(nbr.long().clamp(min=0), 1, slot)                                   # [N,H] winning source node
+    gQ = torch.zeros_like(Qe)
+    gQ.scatter_add_(0, src, gup)
+    Wd, W2 = W[:, :H] - W[:, H:], W[:, H:]
+    gx_emu = gup @ Wd + gQ @ W2
+    gWd, gW2 = gup.t() @ x, gQ.t() @ x
+    gW_emu = torch.cat([gWd, gW2 - gWd], dim=1)
+    rel = float((xd.grad.cpu() - gx_emu).norm() / gx_emu.norm())
+    assert rel < 2e-2, rel          # a rare bf16 rounding flip of Q moves one winner; everything else is fp32-exact
+    relw = float((lin[0].weight.grad.cpu() - gW_emu).norm() / gW_emu.norm())
+    assert relw < 2e-2, relw
+    # and the routing error w.r.t. the fp32 oracle stays bounded (near-ties decided differently by bf16)
+    assert float((xd.grad.cpu() - gx_ref).norm() / gx_ref.norm()) < 0.5
+
+
 @pytest.mark.parametrize("aggr", ["max", "add", "mean"])
 def test_edgeconv_generic_nn_irregular_graph(dev, aggr):
     """DRN call shape (dynamic_reduction_network.py:59-73,86-87): multi-layer nn, loop=False kNN, symmetrised
