@@ -27,6 +27,7 @@ SIGNATURES = {
     "dmet_radius_f32": (_i, [_vp, _vp, _i, _i64, _i, _f, _i, _vp, _vp, _vp]),
     "dmet_edgeconv_linear_workspace_bytes": (_sz, [_i64, _i]),
     "dmet_edgeconv_linear_max_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dmet_edgeconv_fused_lds_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dmet_node_linear_split_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dmet_gather_max_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "dmet_gather_max_lds_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),

@@ -156,6 +156,29 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
     return out, arg
 
 
+def edgeconv_fused_lds(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], nbr: torch.Tensor,
+                       ptr: torch.Tensor, want_arg: bool):
+    """EdgeConv(Linear(64->32), max) in one launch (LDS-resident Q slice per event); see include/dmet.h."""
+    dev = _require_device(x, W, b, nbr, ptr)
+    L = _lib.load()
+    x = _f32c(x, "x"); W = _f32c(W, "W")
+    N, Hin = x.shape
+    Hout = W.shape[0]
+    k = nbr.shape[1]
+    out = torch.empty((N, Hout), dtype=torch.float32, device=dev)
+    arg = torch.empty((N, Hout), dtype=torch.uint8, device=dev) if want_arg else None
+    bp = _f32c(b, "b").data_ptr() if b is not None else None
+    _t = timer.record('edgeconv_fused', dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_edgeconv_fused_lds_f32(x.data_ptr(), nbr.data_ptr(), ptr.data_ptr(), ptr.numel() - 1, N, k,
+                                                 Hin, Hout, W.data_ptr(), bp, out.data_ptr(),
+                                                 arg.data_ptr() if want_arg else None, _stream(dev)),
+                   "dmet_edgeconv_fused_lds_f32")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
+    return out, arg
+
+
 def node_linear_split_bf16(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
     """bf16-MFMA variant: P fp32 [N,H], Q as bf16 [N,H] (gathered table)."""
     dev = _require_device(x, W, b)

@@ -45,7 +45,7 @@ def knn_table(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loo
     if not loop:
         self_id = torch.arange(x.shape[0], dtype=torch.int32, device=x.device).view(-1, 1)
         nbr = torch.where(nbr == self_id, torch.full_like(nbr, -1), nbr)
-    return NeighborTable(nbr, info.ptr, dense=dense, dist=dist)
+    return NeighborTable(nbr, info.ptr, dense=dense, dist=dist, max_nodes=info.max_nodes)
 
 
 def knn_graph(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loop: bool = False,
@@ -83,7 +83,7 @@ def radius_table(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None
     if not loop:
         self_id = torch.arange(x.shape[0], dtype=torch.int32, device=x.device).view(-1, 1)
         nbr = torch.where(nbr == self_id, torch.full_like(nbr, -1), nbr)
-    return NeighborTable(nbr, info.ptr, dense=False)
+    return NeighborTable(nbr, info.ptr, dense=False, max_nodes=info.max_nodes)
 
 
 def radius_graph(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None, loop: bool = False,

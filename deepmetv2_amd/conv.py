@@ -10,6 +10,7 @@ The operators own NO parameters or buffers: `nn` is the caller's module and keep
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Tuple, Union
 
 import torch
@@ -48,6 +49,16 @@ def _as_fusable_linear(nn_module) -> Optional[torch.nn.Linear]:
     return lin
 
 
+EDGECONV_FORM = os.environ.get("DMET_EDGECONV_FORM", "fused")   # "fused" (LDS-resident, when eligible) | "split"
+_LDS_MAX_EVENT_NODES = 5119                                      # 160 KB LDS / 32 B per node, minus the -inf row
+
+
+def _fused_lds_eligible(x, weight, table: NeighborTable) -> bool:
+    return (EDGECONV_FORM == "fused" and x.shape[1] == 32 and weight.shape[0] == 32 and table.k in (8, 16, 32)
+            and table.ptr is not None and table.max_nodes is not None and table.max_nodes <= _LDS_MAX_EVENT_NODES
+            and table.nbr.data_ptr() % 16 == 0)
+
+
 class _EdgeConvLinearMax(torch.autograd.Function):
     """out[i] = max_s (W.[x_i || x_j - x_i] + b), j = nbr[i,s], through P = x.(W1-W2)^T + b, Q = x.W2^T."""
 
@@ -59,6 +70,9 @@ class _EdgeConvLinearMax(torch.autograd.Function):
             # max / add / backward stay fp32 (straight-through over the bf16 roundings)
             P, Qh = _native.node_linear_split_bf16(x, weight, bias)
             out, arg = _native.gather_max_bf16q(P, Qh, table.nbr, want_arg=need_grad)
+        elif _fused_lds_eligible(x, weight, table):
+            # gather + edge MLP + max in one launch, the event's Q slice resident in LDS
+            out, arg = _native.edgeconv_fused_lds(x, weight, bias, table.nbr, table.ptr, want_arg=need_grad)
         else:
             P, Q = _native.node_linear_split(x, weight, bias)
             out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad)

@@ -521,6 +521,188 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fully fused EdgeConv(Linear(64->32), max) over a fixed-width table: neighbour gather + edge MLP + max in ONE
+// launch, no P/Q round trip through memory.  One workgroup per (event, 8-channel slice):
+//   phase 1  [Q slice | P slice] = x_event . [W2^T | (W1-W2)^T + b] for the slice's 8 output channels with fp32
+//            matrix cores (v_mfma_f32_16x16x4_f32: 16 nodes x 16 columns per instruction group, exact fp32);
+//            the Q slice goes to LDS (n x 32 B), the P slice is parked in the output buffer;
+//   phase 2  out[i] = P[i] + max_s Q_lds[nbr[i,s]]  (+ uint8 arg), gathers served by LDS.
+// HBM-side traffic is the algorithmic minimum: x once per slice (4x through L2), ids, out (+arg).
+// MFMA operand maps (16x16x4): lane l holds A[row l&15][k l>>4], B[k l>>4][col l&15]; D: col = l&15,
+// row = 4*(l>>4) + reg.  k-step s, lane quarter kk = l>>4  <->  input feature f = 8*kk + s (contiguous per lane).
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool WITH_ARG, int K4, int FMODE = 0>
+__global__ __launch_bounds__(kLdsGatherThreads) void edgeconv_fused_lds_kernel(
+    const float *__restrict__ x, const int32_t *__restrict__ nbr, const int64_t *__restrict__ ptr, int B, int k,
+    const float *__restrict__ W, const float *__restrict__ bias, float *__restrict__ out, uint8_t *__restrict__ arg)
+{
+    constexpr int H = 32, h4 = H / 4, nsl = H / kSliceC;
+    __shared__ __attribute__((aligned(16))) float4 qs[kLdsGatherRows * 2];   // [n_b + 1][8 floats]
+    constexpr int RPI = kLdsGatherThreads / 2;
+    const int grp = blockIdx.x / (kNumXcd * nsl), rem = blockIdx.x % (kNumXcd * nsl);
+    const int b = grp * kNumXcd + (rem % kNumXcd);
+    const int sl = rem / kNumXcd;
+    if (b >= B) return;
+    const int lo = (int)ptr[b], hi = (int)ptr[b + 1];
+    const int n = hi - lo;
+    if (n <= 0) return;
+    const int half = threadIdx.x & 1;
+    const int r0 = threadIdx.x >> 1;
+    const int col4 = sl * 2 + half;
+    const float ninf = -__builtin_inff();
+
+    if (n + 1 > kLdsGatherRows) {
+        // event too large for the LDS image: direct per-edge evaluation (correct, slow; the host routes such
+        // batches to the unfused kernels when it knows the event sizes)
+        for (int r = r0; r < n; r += RPI) {
+            const int64_t node = lo + r;
+            float best[4] = {ninf, ninf, ninf, ninf};
+            int a[4] = {255, 255, 255, 255};
+#pragma unroll 1
+            for (int s = 0; s < k; ++s) {
+                const int j = nbr[node * k + s];
+                if (j < 0) continue;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int o = sl * 8 + half * 4 + c;
+                    float acc = bias ? bias[o] : 0.0f;
+#pragma unroll 1
+                    for (int f = 0; f < H; ++f) {
+                        const float xi = x[node * H + f], xj = x[(int64_t)j * H + f];
+                        acc = __builtin_fmaf(W[o * 2 * H + f], xi, acc);
+                        acc = __builtin_fmaf(W[o * 2 * H + H + f], xj - xi, acc);
+                    }
+                    if (acc > best[c]) { best[c] = acc; a[c] = s; }
+                }
+            }
+            const bool any = a[0] != 255;
+            reinterpret_cast<float4 *>(out)[node * h4 + col4] =
+                any ? make_float4(best[0], best[1], best[2], best[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (WITH_ARG)
+                reinterpret_cast<uchar4 *>(arg)[node * h4 + col4] =
+                    make_uchar4((unsigned char)a[0], (unsigned char)a[1], (unsigned char)a[2], (unsigned char)a[3]);
+        }
+        return;
+    }
+
+    // ---- phase 1: per-node dense layer for this slice on the fp32 matrix cores ----
+    if (FMODE != 1) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int j = lane & 15, kk = lane >> 4;
+        // B operand: column j < 8 -> Q (W2 row), j >= 8 -> P ((W1-W2) row); feature 8*kk + s at step s
+        const int o = sl * 8 + (j & 7);
+        float bw[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float w1 = W[o * 2 * H + 8 * kk + s], w2 = W[o * 2 * H + H + 8 * kk + s];
+            bw[s] = (j < 8) ? w2 : (w1 - w2);
+        }
+        const float cinit = (j >= 8 && bias) ? bias[o] : 0.0f;
+        float *qf = reinterpret_cast<float *>(qs);
+        const int ntile = (n + 15) / 16;
+        constexpr int NW = kLdsGatherThreads / 64;   // waves
+        constexpr int TU = 4;                        // tiles in flight per wave (loads issued before any MFMA)
+        for (int t0 = wave; t0 < ntile; t0 += NW * TU) {
+            float4 v0[TU], v1[TU];
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const int t = t0 + u * NW;
+                const int row = min(16 * t + (lane & 15), n - 1);
+                const float4 *src = reinterpret_cast<const float4 *>(x + (int64_t)(lo + row) * H + 8 * kk);
+                v0[u] = src[0];
+                v1[u] = src[1];
+            }
+#pragma unroll
+            for (int u = 0; u < TU; ++u) {
+                const int t = t0 + u * NW;
+                if (t >= ntile) break;
+                const float a[8] = {v0[u].x, v0[u].y, v0[u].z, v0[u].w, v1[u].x, v1[u].y, v1[u].z, v1[u].w};
+                f32x4 acc = {cinit, cinit, cinit, cinit};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], bw[s], acc, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int rr = 16 * t + 4 * kk + e;
+                    if (rr < n) {
+                        if (j < 8) qf[rr * 8 + j] = acc[e];
+                        else out[(int64_t)(lo + rr) * H + sl * 8 + (j - 8)] = acc[e];
+                    }
+                }
+            }
+        }
+        if (threadIdx.x < 2) qs[n * 2 + threadIdx.x] = make_float4(ninf, ninf, ninf, ninf);   // the -inf row
+    }
+    // first node's ids (independent of phase 1)
+    int4 ids[K4];
+    if (r0 < n) {
+        const int4 *row4 = reinterpret_cast<const int4 *>(nbr + (int64_t)(lo + r0) * k);
+#pragma unroll
+        for (int q = 0; q < K4; ++q) ids[q] = row4[q];
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- phase 2: gather from LDS + max (+arg), P read back from the output buffer ----
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 < n) pv = reinterpret_cast<const float4 *>(out)[(int64_t)(lo + r0) * h4 + col4];
+    for (int r = r0; r < (FMODE == 2 ? 0 : n); r += RPI) {
+        const int64_t node = lo + r;
+        unsigned off[4 * K4];
+#pragma unroll
+        for (int q = 0; q < K4; ++q) {
+            off[4 * q + 0] = min((unsigned)(ids[q].x - lo), (unsigned)n) * 2 + half;
+            off[4 * q + 1] = min((unsigned)(ids[q].y - lo), (unsigned)n) * 2 + half;
+            off[4 * q + 2] = min((unsigned)(ids[q].z - lo), (unsigned)n) * 2 + half;
+            off[4 * q + 3] = min((unsigned)(ids[q].w - lo), (unsigned)n) * 2 + half;
+        }
+        const float4 p = pv;
+        if (r + RPI < n) {
+            const int4 *row4 = reinterpret_cast<const int4 *>(nbr + (node + RPI) * k);
+#pragma unroll
+            for (int q = 0; q < K4; ++q) ids[q] = row4[q];
+            pv = reinterpret_cast<const float4 *>(out)[(node + RPI) * h4 + col4];
+        }
+        float bx = ninf, by = ninf, bz = ninf, bw2 = ninf;
+        int a0 = 255, a1 = 255, a2 = 255, a3 = 255;
+#pragma unroll
+        for (int q0 = 0; q0 < K4; q0 += 2) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = qs[off[4 * q0 + u]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (WITH_ARG) {
+                    switch (4 * q0 + u) {
+#define DMET_CASE(S_) case S_: DMET_MAX_ARG(bx, a0, v[u].x, S_); DMET_MAX_ARG(by, a1, v[u].y, S_); \
+                               DMET_MAX_ARG(bz, a2, v[u].z, S_); DMET_MAX_ARG(bw2, a3, v[u].w, S_); break;
+                        DMET_CASE(0) DMET_CASE(1) DMET_CASE(2) DMET_CASE(3) DMET_CASE(4) DMET_CASE(5) DMET_CASE(6)
+                        DMET_CASE(7) DMET_CASE(8) DMET_CASE(9) DMET_CASE(10) DMET_CASE(11) DMET_CASE(12)
+                        DMET_CASE(13) DMET_CASE(14) DMET_CASE(15) DMET_CASE(16) DMET_CASE(17) DMET_CASE(18)
+                        DMET_CASE(19) DMET_CASE(20) DMET_CASE(21) DMET_CASE(22) DMET_CASE(23) DMET_CASE(24)
+                        DMET_CASE(25) DMET_CASE(26) DMET_CASE(27) DMET_CASE(28) DMET_CASE(29) DMET_CASE(30)
+                        DMET_CASE(31)
+#undef DMET_CASE
+                    }
+                } else {
+                    DMET_MAX_ONLY(bx, v[u].x); DMET_MAX_ONLY(by, v[u].y);
+                    DMET_MAX_ONLY(bz, v[u].z); DMET_MAX_ONLY(bw2, v[u].w);
+                }
+            }
+        }
+        const bool any = WITH_ARG ? (a0 != 255) : (bx > ninf);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (any) o = make_float4(p.x + bx, p.y + by, p.z + bz, p.w + bw2);
+        reinterpret_cast<float4 *>(out)[node * h4 + col4] = o;
+        if (WITH_ARG) {
+            const uchar4 a = make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
+            reinterpret_cast<uchar4 *>(arg)[node * h4 + col4] = a;
+        }
+    }
+}
+
 // Backward of gather_max w.r.t. Q: deterministic walk of the reverse index (ascending table position).
 template <int H>
 __global__ __launch_bounds__(256) void gather_max_bwd_kernel(const float *__restrict__ g_out,
@@ -725,6 +907,47 @@ extern "C" int dmet_gather_max_f32(const float *P, const float *Q, const int32_t
     }
 #undef DMET_GM
     DMET_LAUNCH_CHECK("gather_max_kernel");
+    return 0;
+}
+
+extern "C" int dmet_edgeconv_fused_lds_f32(const float *x, const int32_t *nbr, const int64_t *ptr, int B, int64_t N,
+                                           int k, int Hin, int Hout, const float *W, const float *b, float *out,
+                                           uint8_t *arg, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_edgeconv_fused_lds_f32: N out of range");
+    DMET_REQUIRE(Hin == 32 && Hout == 32, "dmet_edgeconv_fused_lds_f32: only (Hin,Hout)=(32,32) is built, got (%d,%d)", Hin, Hout);
+    DMET_REQUIRE(k == 8 || k == 16 || k == 32, "dmet_edgeconv_fused_lds_f32: k=%d must be 8, 16 or 32", k);
+    if (N == 0 || B == 0) return 0;
+    DMET_REQUIRE(x && nbr && ptr && W && out, "dmet_edgeconv_fused_lds_f32: null pointer");
+    DMET_REQUIRE(aligned16(x) && aligned16(out) && aligned16(nbr), "dmet_edgeconv_fused_lds_f32: pointers must be 16-B aligned");
+    const int nsl = 32 / kSliceC;
+    const int64_t groups = (B + kNumXcd - 1) / kNumXcd;
+    const int64_t blocks = groups * kNumXcd * nsl;
+    hipStream_t st = as_stream(stream);
+#define DMET_EFL(K4_)                                                                                          \
+    do {                                                                                                       \
+        if (arg)                                                                                               \
+            hipLaunchKernelGGL((edgeconv_fused_lds_kernel<true, K4_>), dim3((unsigned)blocks),                 \
+                               dim3(kLdsGatherThreads), 0, st, x, nbr, ptr, B, k, W, b, out, arg);             \
+        else                                                                                                   \
+            hipLaunchKernelGGL((edgeconv_fused_lds_kernel<false, K4_>), dim3((unsigned)blocks),                \
+                               dim3(kLdsGatherThreads), 0, st, x, nbr, ptr, B, k, W, b, out, arg);             \
+    } while (0)
+#ifdef DMET_KNN_EXPERIMENT
+    if (const char *e = arg ? getenv("DMET_EFL_MODE") : nullptr) {
+        const int m = atoi(e);
+        if (m == 1) hipLaunchKernelGGL((edgeconv_fused_lds_kernel<true, 4, 1>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, x, nbr, ptr, B, k, W, b, out, arg);
+        else if (m == 2) hipLaunchKernelGGL((edgeconv_fused_lds_kernel<true, 4, 2>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, x, nbr, ptr, B, k, W, b, out, arg);
+        else DMET_EFL(4);
+        DMET_LAUNCH_CHECK("edgeconv_fused_lds_kernel");
+        return 0;
+    }
+#endif
+    if (k == 8) DMET_EFL(2);
+    else if (k == 16) DMET_EFL(4);
+    else DMET_EFL(8);
+#undef DMET_EFL
+    DMET_LAUNCH_CHECK("edgeconv_fused_lds_kernel");
     return 0;
 }
 

@@ -20,12 +20,13 @@ from . import _native
 # batch vector -> (ptr, B)
 # ---------------------------------------------------------------------------------------------------------------
 class BatchInfo:
-    __slots__ = ("ptr", "num_events", "num_nodes")
+    __slots__ = ("ptr", "num_events", "num_nodes", "max_nodes")
 
-    def __init__(self, ptr: torch.Tensor, num_events: int, num_nodes: int):
+    def __init__(self, ptr: torch.Tensor, num_events: int, num_nodes: int, max_nodes: Optional[int] = None):
         self.ptr = ptr
         self.num_events = num_events
         self.num_nodes = num_nodes
+        self.max_nodes = max_nodes      # largest event (None = unknown): picks the LDS-resident EdgeConv kernel
 
 
 _batch_registry: Dict[int, Tuple[weakref.ref, int, BatchInfo]] = {}
@@ -53,9 +54,14 @@ def _registry_put(reg, t: torch.Tensor, val) -> None:
     reg[key] = (weakref.ref(t, _drop), t._version, val)
 
 
-def register_batch(batch: torch.Tensor, ptr: torch.Tensor, num_events: int) -> BatchInfo:
-    """Tell the operators the ptr / event count of a batch vector up front (avoids a device->host sync)."""
-    info = BatchInfo(ptr.to(torch.int64).contiguous(), int(num_events), int(batch.numel()))
+def register_batch(batch: torch.Tensor, ptr: torch.Tensor, num_events: int,
+                   max_nodes: Optional[int] = None) -> BatchInfo:
+    """Tell the operators the ptr / event count (/ largest event) of a batch vector up front (avoids a device->host
+    sync on first use; without `max_nodes` one sync happens here)."""
+    ptr = ptr.to(torch.int64).contiguous()
+    if max_nodes is None and ptr.numel() > 1:
+        max_nodes = int(ptr.diff().max())
+    info = BatchInfo(ptr, int(num_events), int(batch.numel()), max_nodes)
     _registry_put(_batch_registry, batch, info)
     return info
 
@@ -64,7 +70,7 @@ def batch_info(batch: Optional[torch.Tensor], num_nodes: int, device: torch.devi
                num_events: Optional[int] = None) -> BatchInfo:
     if batch is None:
         ptr = torch.tensor([0, num_nodes], dtype=torch.int64, device=device)
-        return BatchInfo(ptr, 1, num_nodes)
+        return BatchInfo(ptr, 1, num_nodes, num_nodes)
     if batch.dim() != 1 or batch.numel() != num_nodes:
         raise ValueError(f"batch must be 1-D with {num_nodes} entries, got {tuple(batch.shape)}")
     info = _registry_get(_batch_registry, batch)
@@ -81,7 +87,7 @@ def batch_info(batch: Optional[torch.Tensor], num_nodes: int, device: torch.devi
             raise ValueError("batch vector must be sorted (torch_cluster / PyG precondition)")
         num_events = int(last) + 1
     ptr = _native.batch_to_ptr(batch, num_events)
-    info = BatchInfo(ptr, num_events, num_nodes)
+    info = BatchInfo(ptr, num_events, num_nodes, int(ptr.diff().max()) if num_events > 0 else 0)
     _registry_put(_batch_registry, batch, info)
     return info
 
@@ -151,9 +157,11 @@ def edge_list_from_edge_index(edge_index: torch.Tensor, num_nodes: int, flow: st
 class NeighborTable:
     """nbr[N,k] int32 global node ids, -1 = empty slot.  Row i lists the message SOURCES of target i."""
 
-    def __init__(self, nbr: torch.Tensor, ptr: Optional[torch.Tensor], dense: bool, dist: Optional[torch.Tensor] = None):
+    def __init__(self, nbr: torch.Tensor, ptr: Optional[torch.Tensor], dense: bool, dist: Optional[torch.Tensor] = None,
+                 max_nodes: Optional[int] = None):
         self.nbr = nbr
         self.ptr = ptr
+        self.max_nodes = max_nodes
         self.num_nodes, self.k = nbr.shape
         self.dense = dense          # True: no -1 entries anywhere (every row has exactly k neighbours)
         self.dist = dist

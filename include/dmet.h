@@ -75,6 +75,13 @@ int dmet_edgeconv_linear_max_fwd_f32(const float *x, const int32_t *nbr, const i
                                      int64_t N, int k, int Hin, int Hout, const float *W,
                                      const float *b, float *out, uint8_t *arg, void *ws,
                                      size_t ws_bytes, dmet_stream_t stream);
+/* The same operator in ONE launch for events of up to 5119 nodes (Hin = Hout = 32, k in {8,16,32}): one workgroup
+ * per (event, 8-channel slice) computes [Q slice | P slice] on the fp32 matrix cores (v_mfma_f32_16x16x4_f32),
+ * keeps the Q slice of the whole event in LDS and gathers the k neighbour rows from there -- neighbour gather +
+ * edge MLP + max with no P/Q round trip through memory.  Larger events are evaluated edge by edge (correct, slow). */
+int dmet_edgeconv_fused_lds_f32(const float *x, const int32_t *nbr, const int64_t *ptr, int B, int64_t N, int k,
+                                int Hin, int Hout, const float *W, const float *b, float *out, uint8_t *arg,
+                                dmet_stream_t stream);
 /* The two steps individually (step 2 is "the gather + scatter_max kernel" of BASELINE.json). */
 int dmet_node_linear_split_f32(const float *x, int64_t N, int Hin, int Hout, const float *W,
                                const float *b, float *P, float *Q, dmet_stream_t stream);

@@ -51,6 +51,11 @@ def gather_max(P, Q, nbr, ptr, want_arg):
     return out, (arg8 if want_arg else None)
 
 
+def edgeconv_fused_lds(x, W, b, nbr, ptr, want_arg):
+    P, Q = node_linear_split(x, W, b)
+    return gather_max(P, Q, nbr, ptr, want_arg)
+
+
 def reverse_index(keys, num_keys):
     keys = keys.reshape(-1)
     M = keys.numel()
@@ -152,7 +157,7 @@ def onehot_xty(index, Bm, num_rows):
 
 _NAMES = ["knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
           "edge_features_bwd", "segment_max", "segment_sum", "segment_max_bwd", "segment_sum_bwd", "met_reduce",
-          "met_reduce_bwd", "segment_sum_1d", "batch_to_ptr", "xty", "onehot_xty"]
+          "met_reduce_bwd", "segment_sum_1d", "batch_to_ptr", "xty", "onehot_xty", "edgeconv_fused_lds"]
 
 
 def install(monkeypatch=None):

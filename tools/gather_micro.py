@@ -27,4 +27,11 @@ for form in ("l2", "lds"):
         print(f"gather_max[{form}] arg={arg}: {us:7.2f} us  -> {byts/us/1e3:7.1f} GB/s algorithmic = {byts/us/1e3/8000*100:5.1f}% of 8 TB/s")
     res[form] = _native.gather_max(P, Q, nbr, ptr, True)
 print("forms agree:", torch.equal(res["l2"][0], res["lds"][0]), torch.equal(res["l2"][1], res["lds"][1]))
+for arg in (False, True):
+    us = timeit(lambda: _native.edgeconv_fused_lds(x, W, b, nbr, ptr, arg))
+    byts = B * n * (128 + 64 + 128 + (32 if arg else 0))
+    print(f"edgeconv_fused_lds arg={arg}: {us:7.2f} us -> {byts/us/1e3:7.1f} GB/s algorithmic = {byts/us/1e3/8000*100:5.1f}% of 8 TB/s")
+ref = _native.gather_max(P, Q, nbr, ptr, True)
+fo = _native.edgeconv_fused_lds(x, W, b, nbr, ptr, True)
+print("fused vs split max|d|:", float((fo[0]-ref[0]).abs().max()), "arg mismatches:", int((fo[1]!=ref[1]).sum()))
 print(f"node_linear_split: {timeit(lambda: _native.node_linear_split(x, W, b)):.2f} us")
