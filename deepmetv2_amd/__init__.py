@@ -13,6 +13,7 @@ calling an operator without the library or with non-GPU tensors raises.
 """
 from .cluster import knn, knn_graph, knn_table, radius_graph, radius_table
 from .conv import DynamicEdgeConv, EdgeConv
+from .data import Batch, EventLoader, collate, events_from_padded
 from .graph import NeighborTable, register_batch
 from .scatter import met_reduce, scatter_add, scatter_max
 

@@ -279,3 +279,24 @@ def loss_fn(weights: torch.Tensor, prediction: torch.Tensor, truth: torch.Tensor
     METx = scatter_add(weights * px, batch, dim_size=B)
     METy = scatter_add(weights * py, batch, dim_size=B)
     return 0.5 * ((METx + true_px) ** 2 + (METy + true_py) ** 2).mean()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# N2  raw-file decoding, event by event           model/data_loader.py:63-90 (METDataset.process)
+# ----------------------------------------------------------------------------------------------------------------
+def decode_padded_events(x_pad: np.ndarray, y: np.ndarray):
+    """Line-by-line restatement of METDataset.process for one npz payload: per event transpose, take columns 3:10,
+    insert pX, pY, pT, eta in front, drop rows whose pdgId / charge are the -999 padding, nan_to_num, clip +-5000."""
+    out = []
+    for ievt in range(np.shape(x_pad)[1]):
+        inputs = np.array(x_pad[:, ievt, :]).astype(np.float32).T          # :70-71
+        x = inputs[:, 3:10]                                                 # :73
+        x = np.insert(x, 0, inputs[:, 0] * np.cos(inputs[:, 2]), axis=1)    # :74
+        x = np.insert(x, 1, inputs[:, 0] * np.sin(inputs[:, 2]), axis=1)    # :75
+        x = np.insert(x, 2, inputs[:, 0], axis=1)                           # :76
+        x = np.insert(x, 3, inputs[:, 1], axis=1)                           # :77
+        x = x[x[:, 8] != -999]                                              # :78
+        x = x[x[:, 9] != -999]                                              # :79
+        x = np.clip(np.nan_to_num(x), -5000.0, 5000.0)                      # :81-82
+        out.append((torch.from_numpy(x.astype(np.float32)), torch.from_numpy(np.asarray(y[ievt], np.float32)[None])))
+    return out
