@@ -38,6 +38,9 @@ def parse_args():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 = BASELINE configs[2]: edge-MLP dense layer on the bf16 matrix cores, bf16 Q table "
                          "(kNN, max, MET and the backward stay fp32)")
+    ap.add_argument("--graph", choices=["dynamic", "static"], default="dynamic",
+                    help="dynamic = kNN in the embedding before each EdgeConv (north star); static = the active reference "
+                         "flow (train.py:42-50): one radius graph dR<0.4 in (eta,phi) per batch, rebuilt every step")
     ap.add_argument("--ragged", type=int, nargs=2, metavar=("LO", "HI"), default=None,
                     help="BASELINE configs[4]: event sizes drawn uniformly from [LO, HI] (seeded) instead of --nodes")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -132,7 +135,7 @@ def main():
     N = x.shape[0]
 
     torch.manual_seed(0)
-    model = Net(8, 3, graph="dynamic", k=k, edge_dtype=torch.bfloat16 if args.dtype == "bf16" else None).to(dev)
+    model = Net(8, 3, graph=args.graph, k=k, edge_dtype=torch.bfloat16 if args.dtype == "bf16" else None).to(dev)
     flat = FlatModule(model)
     sync = GradSync(flat)
     sync.broadcast_state(0)
@@ -141,8 +144,15 @@ def main():
     if args.mode == "train":
         model.train()
 
+        def static_graph():
+            if args.graph != "static":
+                return None
+            phi = torch.atan2(x[:, 1], x[:, 0])                                   # train.py:45-48
+            etaphi = torch.cat([x[:, 3][:, None], phi[:, None]], dim=1)
+            return dm.radius_graph(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255)
+
         def step():
-            return train_step(model, flat, sync, opt, x, y, batch, ptr)
+            return train_step(model, flat, sync, opt, x, y, batch, ptr, edge_index=static_graph())
     else:
         model.eval()
 
@@ -218,7 +228,7 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: {B} events/GPU x {n} PF candidates x 11 features, k={k}, "
                                    f"2 DynamicEdgeConv layers (kNN rebuilt per layer in the 32-d embedding), {'fp32' if args.dtype == 'f32' else 'bf16 edge-MLP on MFMA (configs[2])'}, "
                                    f"{args.mode} step", "events_per_gpu": B, "nodes_per_event": n if args.ragged is None else f"U[{args.ragged[0]},{args.ragged[1]}]", "k": k,
-                       "global_batch": B * world, "mode": args.mode, "parallelism": f"dp{world}"},
+                       "global_batch": B * world, "mode": args.mode, "graph": args.graph, "parallelism": f"dp{world}"},
             "roofline": roof, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

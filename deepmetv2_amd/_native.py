@@ -137,13 +137,22 @@ def node_linear_split(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor
 
 
 def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optional[torch.Tensor],
-               want_arg: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+               want_arg: bool, cnt: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     dev = _require_device(P, Q, nbr)
     L = _lib.load()
     N, H = P.shape
     k = nbr.shape[1]
     out = torch.empty((N, H), dtype=torch.float32, device=dev)
     arg = torch.empty((N, H), dtype=torch.uint8, device=dev) if want_arg else None
+    if cnt is not None:
+        _t = timer.record('gather_max', dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.dmet_gather_max_counted_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), cnt.data_ptr(), N, k, H,
+                                                     out.data_ptr(), arg.data_ptr() if want_arg else None,
+                                                     _stream(dev)), "dmet_gather_max_counted_f32")
+        if _t is not None:
+            _t.record(torch.cuda.current_stream(dev))
+        return out, arg
     _t = timer.record('gather_max', dev)
     use_lds = GATHER_MAX_FORM == "lds" and ptr is not None and H % 8 == 0
     fn = L.dmet_gather_max_lds_f32 if use_lds else L.dmet_gather_max_f32

@@ -83,7 +83,7 @@ def radius_table(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None
     if not loop:
         self_id = torch.arange(x.shape[0], dtype=torch.int32, device=x.device).view(-1, 1)
         nbr = torch.where(nbr == self_id, torch.full_like(nbr, -1), nbr)
-    return NeighborTable(nbr, info.ptr, dense=False, max_nodes=info.max_nodes)
+    return NeighborTable(nbr, info.ptr, dense=False, max_nodes=info.max_nodes, cnt=_cnt)
 
 
 def radius_graph(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None, loop: bool = False,

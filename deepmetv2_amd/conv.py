@@ -70,6 +70,9 @@ class _EdgeConvLinearMax(torch.autograd.Function):
             # max / add / backward stay fp32 (straight-through over the bf16 roundings)
             P, Qh = _native.node_linear_split_bf16(x, weight, bias)
             out, arg = _native.gather_max_bf16q(P, Qh, table.nbr, want_arg=need_grad)
+        elif table.cnt is not None:
+            P, Q = _native.node_linear_split(x, weight, bias)
+            out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad, cnt=table.cnt)
         elif _fused_lds_eligible(x, weight, table):
             # gather + edge MLP + max in one launch, the event's Q slice resident in LDS
             out, arg = _native.edgeconv_fused_lds(x, weight, bias, table.nbr, table.ptr, want_arg=need_grad)

@@ -258,7 +258,8 @@ __global__ __launch_bounds__(256) void gather_max_bf16q_kernel(const float *__re
 // ---------------------------------------------------------------------------------------------------------
 template <int H, bool WITH_ARG>
 __global__ __launch_bounds__(256) void gather_max_kernel(const float *__restrict__ P, const float *__restrict__ Q,
-                                                          const int32_t *__restrict__ nbr, int64_t N, int k,
+                                                          const int32_t *__restrict__ nbr,
+                                                          const int32_t *__restrict__ cnt, int64_t N, int kmax,
                                                           float *__restrict__ out, uint8_t *__restrict__ arg)
 {
     constexpr int LPN = H / 4;               // lanes per node
@@ -267,7 +268,10 @@ __global__ __launch_bounds__(256) void gather_max_kernel(const float *__restrict
     const int64_t node = (int64_t)bid * NPB + threadIdx.x / LPN;
     const int c4 = threadIdx.x % LPN;
     if (node >= N) return;
-    const int32_t *row = nbr + node * k;
+    const int32_t *row = nbr + node * kmax;
+    // cnt (optional): only the first cnt[node] slots of a row can hold neighbours (radius tables are 255 wide
+    // but ~36 deep: walking the padding would cost 7x the useful work)
+    const int k = cnt ? min(kmax, cnt[node]) : kmax;
     const float4 *Q4 = reinterpret_cast<const float4 *>(Q);
     const float ninf = -__builtin_inff();
     float4 best = make_float4(ninf, ninf, ninf, ninf);
@@ -859,10 +863,19 @@ extern "C" int dmet_node_linear_split_f32(const float *x, int64_t N, int Hin, in
     return -22;
 }
 
+extern "C" int dmet_gather_max_counted_f32(const float *P, const float *Q, const int32_t *nbr, const int32_t *cnt,
+                                           int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream);
+
 extern "C" int dmet_gather_max_f32(const float *P, const float *Q, const int32_t *nbr, const int64_t *ptr, int B,
                                    int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream)
 {
     (void)ptr; (void)B;
+    return dmet_gather_max_counted_f32(P, Q, nbr, nullptr, N, k, H, out, arg, stream);
+}
+
+extern "C" int dmet_gather_max_counted_f32(const float *P, const float *Q, const int32_t *nbr, const int32_t *cnt,
+                                           int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream)
+{
     DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_gather_max_f32: N out of range");
     DMET_REQUIRE(k >= 1 && k <= 255, "dmet_gather_max_f32: k=%d not in [1,255] (arg is uint8, 255 = none)", k);
     if (N == 0) return 0;
@@ -875,12 +888,12 @@ extern "C" int dmet_gather_max_f32(const float *P, const float *Q, const int32_t
         const int64_t blocks = (N + NPB - 1) / NPB;                                                             \
         if (arg)                                                                                                \
             hipLaunchKernelGGL((gather_max_kernel<HH, true>), dim3((unsigned)blocks), dim3(256), 0, st, P, Q,   \
-                               nbr, N, k, out, arg);                                                            \
+                               nbr, cnt, N, k, out, arg);                                                       \
         else                                                                                                    \
             hipLaunchKernelGGL((gather_max_kernel<HH, false>), dim3((unsigned)blocks), dim3(256), 0, st, P, Q,  \
-                               nbr, N, k, out, arg);                                                            \
+                               nbr, cnt, N, k, out, arg);                                                       \
     } while (0)
-    if (H == 32 && (k == 8 || k == 16 || k == 32) && aligned16(nbr)) {
+    if (H == 32 && !cnt && (k == 8 || k == 16 || k == 32) && aligned16(nbr)) {
         // the kNN tables of the hot path: deep-MLP variant
         const int64_t blocks = (N + 31) / 32;
 #define DMET_GMM(K4_)                                                                                          \

@@ -158,10 +158,11 @@ class NeighborTable:
     """nbr[N,k] int32 global node ids, -1 = empty slot.  Row i lists the message SOURCES of target i."""
 
     def __init__(self, nbr: torch.Tensor, ptr: Optional[torch.Tensor], dense: bool, dist: Optional[torch.Tensor] = None,
-                 max_nodes: Optional[int] = None):
+                 max_nodes: Optional[int] = None, cnt: Optional[torch.Tensor] = None):
         self.nbr = nbr
         self.ptr = ptr
         self.max_nodes = max_nodes
+        self.cnt = cnt              # optional int32 [N]: slots beyond cnt[i] in row i are all -1 (wide, shallow tables)
         self.num_nodes, self.k = nbr.shape
         self.dense = dense          # True: no -1 entries anywhere (every row has exactly k neighbours)
         self.dist = dist
@@ -170,8 +171,17 @@ class NeighborTable:
         self._edge_index = {}
 
     def reverse(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """rev_ptr[N+1], rev_slot[...]: the table positions i*k+s that hold node j, ascending, for every j."""
         if self._rev is None:
-            self._rev = _native.reverse_index(self.nbr.view(-1), self.num_nodes)
+            if self.cnt is None:
+                self._rev = _native.reverse_index(self.nbr.view(-1), self.num_nodes)
+            else:
+                # wide, shallow table: sort the valid entries only (a 255-wide radius table is ~85 % padding)
+                flat = self.nbr.view(-1)
+                pos = torch.nonzero(flat >= 0).view(-1).to(torch.int32)
+                keys = flat[pos.long()].contiguous()
+                rev_ptr, rev_e = _native.reverse_index(keys, self.num_nodes)
+                self._rev = (rev_ptr, pos[rev_e[: keys.numel()].long()].contiguous())
         return self._rev
 
     def edge_list(self) -> EdgeList:

@@ -87,6 +87,10 @@ int dmet_node_linear_split_f32(const float *x, int64_t N, int Hin, int Hout, con
                                const float *b, float *P, float *Q, dmet_stream_t stream);
 int dmet_gather_max_f32(const float *P, const float *Q, const int32_t *nbr, const int64_t *ptr, int B,
                         int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream);
+/* Same contract with a per-node slot count: only the first cnt[i] slots of row i are examined (radius tables are
+ * max_num_neighbors wide but a few dozen deep).  cnt may be NULL (= k for every node). */
+int dmet_gather_max_counted_f32(const float *P, const float *Q, const int32_t *nbr, const int32_t *cnt, int64_t N,
+                                int k, int H, float *out, uint8_t *arg, dmet_stream_t stream);
 /* Same contract, LDS-resident form: one workgroup per (event, 8-channel slice) stages that slice of Q for the
  * whole event in the CU's 160 KB LDS (events up to 5120 nodes; larger events gather from global memory inside the
  * same kernel).  Needs ptr/B and H % 8 == 0.  The faster form for events of a few thousand nodes. */
