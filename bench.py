@@ -169,6 +169,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    ev_overhead_ms = _native.timer.calibrate(dev)
     _native.timer.enabled = True
     _native.timer.reset()
     barrier()
@@ -196,7 +197,7 @@ def main():
         # the kernel that actually ran: the fully fused one (gather + edge MLP + max, LDS-resident) when eligible,
         # else the gather+max step of the split form; same algorithmic-byte definition (own row, ids, out[, arg])
         gname = "edgeconv_fused" if "edgeconv_fused" in ksum else ("gather_max" if "gather_max" in ksum else None)
-        if gname is not None:
+        if gname is not None and args.graph == "dynamic":   # the byte count below assumes the fixed-k kNN table
             ms = ksum[gname][1]
             ach = alg_bytes / (ms * 1e-3) / 1e9
             traffic = None
@@ -207,10 +208,12 @@ def main():
                 except Exception:
                     traffic = None
             kname = {"edgeconv_fused": "edgeconv_fused_lds_kernel (gather + edge-MLP + max in one launch)",
-                     "gather_max": "gather_max_kernel (gather + max step of the split form)"}[gname]
+                     "gather_max": "gather_max_lds_kernel (gather + max; per-event Q slice resident in LDS)"
+                     if args.dtype == "f32" else "gather_max_bf16q_kernel (gather + max over the bf16 Q table)"}[gname]
             roof = {"kernel": kname, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(ms * 1e3, 2),
+                    "event_bracket_overhead_us": round(ev_overhead_ms * 1e3, 2),
                     "launches": ksum[gname][0]}
         kernels = {}
         for name, (cnt, ms) in sorted(ksum.items()):

@@ -63,20 +63,37 @@ class KernelTimer:
         self._pending.setdefault(name, []).append((a, b))
         return b
 
+    def calibrate(self, dev: torch.device, n: int = 50) -> float:
+        """Cost of an EMPTY bracket (two event records back to back on the stream), in ms: the two records are
+        stream commands of their own, so a bracket reads ~2-4 us longer than the kernel inside it."""
+        pairs = []
+        st = torch.cuda.current_stream(dev)
+        for _ in range(n):
+            a = torch.cuda.Event(enable_timing=True)
+            b = torch.cuda.Event(enable_timing=True)
+            a.record(st)
+            b.record(st)
+            pairs.append((a, b))
+        torch.cuda.synchronize(dev)
+        ts = sorted(a.elapsed_time(b) for a, b in pairs)
+        self.overhead_ms = ts[len(ts) // 2]
+        return self.overhead_ms
+
     def summary(self) -> dict:
-        """{name: (launches, mean_ms)} -- call after a device synchronise."""
+        """{name: (launches, mean_ms)} with the empty-bracket cost removed -- call after a device synchronise."""
         out = {}
+        oh = getattr(self, "overhead_ms", 0.0)
         for name, pairs in self._pending.items():
-            ts = [a.elapsed_time(b) for a, b in pairs]
+            ts = [max(a.elapsed_time(b) - oh, 0.0) for a, b in pairs]
             out[name] = (len(ts), sum(ts) / max(len(ts), 1))
         return out
 
 
 timer = KernelTimer()
 
-# which form of the gather+max kernel the fused EdgeConv uses: "l2" (gather from the XCD's L2, any event size) or
-# "lds" (per-event slice of Q resident in LDS)
-GATHER_MAX_FORM = os.environ.get("DMET_GATHER_MAX_FORM", "l2")
+# gather+max kernel form: "auto" = LDS-resident when the caller says the events fit, else L2 gathers;
+# "lds" / "l2-only" force one form (experiments, tools/gather_micro.py)
+GATHER_MAX_FORM = os.environ.get("DMET_GATHER_MAX_FORM", "auto")
 
 
 # ---- K1 ------------------------------------------------------------------------------------------------------
@@ -137,7 +154,10 @@ def node_linear_split(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor
 
 
 def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optional[torch.Tensor],
-               want_arg: bool, cnt: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+               want_arg: bool, cnt: Optional[torch.Tensor] = None, lds: bool = False
+               ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """out = P + max over the rows of Q listed in nbr (+ uint8 arg).  lds=True: the caller knows every event fits
+    the LDS image (<= 5119 nodes, k in {8,16,32}, H % 8 == 0) -> LDS-resident kernel; else gathers come from L2."""
     dev = _require_device(P, Q, nbr)
     L = _lib.load()
     N, H = P.shape
@@ -154,7 +174,7 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
             _t.record(torch.cuda.current_stream(dev))
         return out, arg
     _t = timer.record('gather_max', dev)
-    use_lds = GATHER_MAX_FORM == "lds" and ptr is not None and H % 8 == 0
+    use_lds = (lds or GATHER_MAX_FORM == "lds") and GATHER_MAX_FORM != "l2-only" and ptr is not None and H % 8 == 0
     fn = L.dmet_gather_max_lds_f32 if use_lds else L.dmet_gather_max_f32
     with torch.cuda.device(dev):
         _lib.check(fn(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), ptr.data_ptr() if ptr is not None else None,

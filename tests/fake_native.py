@@ -36,7 +36,7 @@ def node_linear_split(x, W, b):
     return P.detach(), (x @ W[:, H:].t()).detach()
 
 
-def gather_max(P, Q, nbr, ptr, want_arg, cnt=None):
+def gather_max(P, Q, nbr, ptr, want_arg, cnt=None, lds=False):
     N, H = P.shape
     k = nbr.shape[1]
     idx = nbr.long().clamp(min=0)

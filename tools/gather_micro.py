@@ -19,14 +19,14 @@ def timeit(f, reps=30):
     e.record(); torch.cuda.synchronize()
     return a.elapsed_time(e) / reps * 1e3
 res = {}
-for form in ("l2", "lds"):
+for form in ("l2-only", "lds"):
     _native.GATHER_MAX_FORM = form
     for arg in (False, True):
         us = timeit(lambda: _native.gather_max(P, Q, nbr, ptr, arg))
         byts = B * n * (128 + 64 + 128 + (32 if arg else 0))
         print(f"gather_max[{form}] arg={arg}: {us:7.2f} us  -> {byts/us/1e3:7.1f} GB/s algorithmic = {byts/us/1e3/8000*100:5.1f}% of 8 TB/s")
     res[form] = _native.gather_max(P, Q, nbr, ptr, True)
-print("forms agree:", torch.equal(res["l2"][0], res["lds"][0]), torch.equal(res["l2"][1], res["lds"][1]))
+print("forms agree:", torch.equal(res["l2-only"][0], res["lds"][0]), torch.equal(res["l2-only"][1], res["lds"][1]))
 for arg in (False, True):
     us = timeit(lambda: _native.edgeconv_fused_lds(x, W, b, nbr, ptr, arg))
     byts = B * n * (128 + 64 + 128 + (32 if arg else 0))
