@@ -50,6 +50,9 @@ SIGNATURES = {
     "dmet_xty_workspace_bytes": (_sz, [_i64, _i, _i]),
     "dmet_xty_f32": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _sz, _vp]),
     "dmet_onehot_xty_f32": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _sz, _vp]),
+    "dmet_encode_fwd_f32": (_i, [_vp, _i64, _vp, _i64] + [_vp] * 9 + [_vp, _vp]),
+    "dmet_encode_bwd_workspace_bytes": (_sz, [_i64]),
+    "dmet_encode_bwd_f32": (_i, [_vp, _i64, _vp, _i64] + [_vp] * 9 + [_vp, _vp] + [_vp] * 9 + [_vp, _sz, _vp]),
 }
 
 

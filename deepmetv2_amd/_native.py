@@ -444,3 +444,58 @@ def onehot_xty(index: torch.Tensor, Bm: torch.Tensor, num_rows: int) -> torch.Te
         _lib.check(L.dmet_onehot_xty_f32(index.data_ptr(), Bm.data_ptr(), N, num_rows, Hb, C.data_ptr(), ws.data_ptr(),
                                          ws.numel(), _stream(dev)), "dmet_onehot_xty_f32")
     return C
+
+
+def _encode_params(params, dev):
+    shapes = [(16, 8), (16,), (16, 24), (16,), (32, 32), (32,), (3, 8), (7, 8), (8, 8)]
+    if len(params) != 9:
+        raise ValueError("encode: expected 9 parameter tensors (Wc, bc, Wk, bk, Wa, ba, Echg, Epdg, Epv)")
+    out = []
+    for t, shp in zip(params, shapes):
+        if tuple(t.shape) != shp:
+            raise ValueError(f"encode: parameter of shape {tuple(t.shape)}, expected {shp}")
+        if t.device != dev:
+            raise ValueError("encode: parameters must be on the device of x")
+        out.append(_f32c(t, "param"))
+    return out
+
+
+def _encode_x(x: torch.Tensor, x_cat: torch.Tensor):
+    if x.dim() != 2 or x.shape[1] != 8 or x.dtype != torch.float32:
+        raise ValueError(f"encode: x_cont must be float32 [N,8], got {tuple(x.shape)} {x.dtype}")
+    if x_cat.dim() != 2 or x_cat.shape != (x.shape[0], 3) or x_cat.dtype != torch.int64:
+        raise ValueError(f"encode: x_cat must be int64 [N,3], got {tuple(x_cat.shape)} {x_cat.dtype}")
+    return (x if x.stride(1) == 1 else x.contiguous()), x_cat.contiguous()
+
+
+def encode_fwd(x_cont: torch.Tensor, x_cat: torch.Tensor, params) -> torch.Tensor:
+    """h[N,32] = the per-node encoder (graph_met_network.py:48-58 before bn_all) in one kernel."""
+    dev = _require_device(x_cont, x_cat)
+    L = _lib.load()
+    x, xc = _encode_x(x_cont, x_cat)
+    ps = _encode_params(params, dev)
+    N = x.shape[0]
+    h = torch.empty((N, 32), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_encode_fwd_f32(x.data_ptr(), x.stride(0), xc.data_ptr(), N, *[t.data_ptr() for t in ps],
+                                         h.data_ptr(), _stream(dev)), "dmet_encode_fwd_f32")
+    return h
+
+
+def encode_bwd(x_cont: torch.Tensor, x_cat: torch.Tensor, params, h: torch.Tensor, g_h: torch.Tensor):
+    """The nine parameter gradients of `encode_fwd` given its output h and dL/dh."""
+    dev = _require_device(x_cont, x_cat, h, g_h)
+    L = _lib.load()
+    x, xc = _encode_x(x_cont, x_cat)
+    ps = _encode_params(params, dev)
+    h = _f32c(h, "h"); g_h = _f32c(g_h, "g_h")
+    N = x.shape[0]
+    grads = [torch.empty_like(t) for t in ps]
+    if N == 0:
+        return [g.zero_() for g in grads]
+    with torch.cuda.device(dev):
+        ws = _ws(L.dmet_encode_bwd_workspace_bytes(N), dev)
+        _lib.check(L.dmet_encode_bwd_f32(x.data_ptr(), x.stride(0), xc.data_ptr(), N, *[t.data_ptr() for t in ps],
+                                         h.data_ptr(), g_h.data_ptr(), *[g.data_ptr() for g in grads], ws.data_ptr(),
+                                         ws.numel(), _stream(dev)), "dmet_encode_bwd_f32")
+    return grads

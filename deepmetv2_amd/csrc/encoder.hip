@@ -1,0 +1,386 @@
+// encoder.hip -- N3: the per-node encoder of the graph-MET model as two kernels (gfx950).
+//
+// /root/reference/model/graph_met_network.py:48-58 runs, per node, a chain of ~25 tiny torch kernels:
+//   e_cont = ELU(Linear 8->16 (x_cont))
+//   cls    = sequential remap of |pdgId| over (1,2,11,13,22,130,211) -> 0..6           (:52-54)
+//   cat24  = [embed_charge[charge+1] | embed_pdgid[cls] | embed_pv[fromPV]]              (:49,:50,:55,:57)
+//   e_cat  = ELU(Linear 24->16 (cat24))
+//   h      = ELU(Linear 32->32 ([e_cat | e_cont]))                                       (:58, before bn_all)
+// and autograd runs twice as many in backward.  Here: encode_fwd (one thread per node, weights broadcast from LDS)
+// and encode_bwd (recomputes the activations, back-propagates per node, and reduces ALL parameter gradients over
+// the nodes in-kernel: per 64-node chunk the per-node vectors are transposed through LDS and multiplied on the
+// fp32 matrix cores, C = A^T B with K = nodes; fixed node ranges per wavefront, block partials summed in order by a
+// second kernel => bitwise reproducible, no float atomics).
+#include "common.h"
+
+namespace dmet {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// The weights are read straight from global memory with wave-uniform addresses: the compiler turns those into scalar
+// loads (s_load_dwordx8/16 through the scalar cache), so a weight costs no VGPR, no LDS traffic and is an SGPR operand
+// of the FMA.  (A first version staged them in LDS: the scheduler hoisted hundreds of ds_reads and spilled.)
+#define ENC_PARAMS                                                                                                  \
+    const float *__restrict__ Wc, const float *__restrict__ bc, const float *__restrict__ Wk,                      \
+        const float *__restrict__ bk, const float *__restrict__ Wa, const float *__restrict__ ba,                  \
+        const float *__restrict__ Echg, const float *__restrict__ Epdg, const float *__restrict__ Epv
+#define ENC_ARGS Wc, bc, Wk, bk, Wa, ba, Echg, Epdg, Epv
+
+__device__ __forceinline__ float elu(float z) { return z > 0.0f ? z : (__expf(z) - 1.0f); }
+
+// categorical columns (x_cat[N,3] int64 = pdgId, charge, fromPV) -> table rows; the pdg remap is the reference's
+// SEQUENTIAL torch.where chain, kept sequential so unexpected ids behave identically; indices are clamped into
+// their tables (torch would raise on an out-of-range index).
+__device__ __forceinline__ void cat_indices(const int64_t *__restrict__ xcat, int64_t i, int &ichg, int &ipdg, int &ipv)
+{
+    long long c = xcat[i * 3 + 0];
+    c = c < 0 ? -c : c;
+    const long long table[7] = {1, 2, 11, 13, 22, 130, 211};
+#pragma unroll
+    for (int t = 0; t < 7; ++t) c = (c == table[t]) ? (long long)t : c;
+    ipdg = (int)min(max(c, 0ll), 6ll);
+    ichg = (int)min(max((long long)xcat[i * 3 + 1] + 1, 0ll), 2ll);
+    ipv = (int)min(max((long long)xcat[i * 3 + 2], 0ll), 7ll);
+}
+
+// forward chain for one node; pre-activations are returned because backward needs ELU'(z)
+__device__ __forceinline__ void encode_node(ENC_PARAMS, const float (&xc)[8], int ichg, int ipdg, int ipv,
+                                            float (&cat24)[24], float (&z1)[16], float (&z2)[16], float (&joint)[32],
+                                            float (&z3)[32])
+{
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        cat24[e] = Echg[ichg * 8 + e];
+        cat24[8 + e] = Epdg[ipdg * 8 + e];
+        cat24[16 + e] = Epv[ipv * 8 + e];
+    }
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+        float a = bc[o];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) a = __builtin_fmaf(Wc[o * 8 + f], xc[f], a);
+        z1[o] = a;
+        float b = bk[o];
+#pragma unroll
+        for (int f = 0; f < 24; ++f) b = __builtin_fmaf(Wk[o * 24 + f], cat24[f], b);
+        z2[o] = b;
+    }
+#pragma unroll
+    for (int o = 0; o < 16; ++o) { joint[o] = elu(z2[o]); joint[16 + o] = elu(z1[o]); }   // [e_cat | e_cont]
+#pragma unroll
+    for (int o = 0; o < 32; ++o) {
+        float a = ba[o];
+#pragma unroll
+        for (int f = 0; f < 32; ++f) a = __builtin_fmaf(Wa[o * 32 + f], joint[f], a);
+        z3[o] = a;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void encode_fwd_kernel(const float *__restrict__ x, int64_t x_stride,
+                                                          const int64_t *__restrict__ xcat, int64_t N,
+                                                          ENC_PARAMS, float *__restrict__ h)
+{
+    // one node per thread and NO loop: with a grid-stride loop the compiler hoists the (loop-invariant) scalar
+    // weight loads out of it, runs out of SGPRs and shuttles 1.5k weights through v_writelane/v_readlane
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float *row = x + i * x_stride;
+    float xc[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) xc[f] = row[f];
+    int ichg, ipdg, ipv;
+    cat_indices(xcat, i, ichg, ipdg, ipv);
+    float cat24[24], z1[16], z2[16], joint[32], z3[32];
+    encode_node(ENC_ARGS, xc, ichg, ipdg, ipv, cat24, z1, z2, joint, z3);
+    float4 *o = reinterpret_cast<float4 *>(h + i * 32);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        o[c] = make_float4(elu(z3[4 * c]), elu(z3[4 * c + 1]), elu(z3[4 * c + 2]), elu(z3[4 * c + 3]));
+}
+
+// ---- backward -------------------------------------------------------------------------------------------------
+// Gradient tiles (each 32x32, C = A^T B over nodes, on the fp32 matrix cores):
+//   T0 = g_z3^T . joint                       -> dWa
+//   T1 = [g_z2 | g_z1]^T . [cat24 | x_cont]   -> dWk = T1[0:16, 0:24], dWc = T1[16:32, 24:32]
+//   T2 = S^T . [g_cat24 | 0]                  -> dEchg = T2[0:3, 0:8], dEpdg = T2[3:10, 8:16], dEpv = T2[10:18, 16:24]
+// with S = [onehot(chg) (3) | onehot(pdg) (7) | onehot(pv) (8) | 0...] per node, generated on the fly from the
+// packed table rows; bias gradients are column sums of the staged A tiles (lane (c, half) sums 32 nodes of column c).
+// ELU'(z) is taken from the activation itself (1 if a > 0 else a + 1), so z3 = Wa.joint is never recomputed.
+constexpr int kEncTiles = 3;
+constexpr int kEncBwdWaves = 2;
+constexpr int kEncPartial = kEncTiles * 1024 + 64;   // floats per wavefront partial: 3 tiles + [dba | dbk | dbc]
+
+__device__ __forceinline__ void enc_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// C += A^T B for a 64-node chunk held in LDS as A[64][33], B[64][33] (padded rows: conflict-free column reads)
+__device__ __forceinline__ void tile_mma(f32x16 &acc, const float *__restrict__ A, const float *__restrict__ Bm, int lane)
+{
+    const int c = lane & 31, hh = lane >> 5;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) {
+        const int node = 2 * s + hh;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[node * 33 + c], Bm[node * 33 + c], acc, 0, 0, 0);
+    }
+}
+
+// C += S^T B with S[node][c] = (field of packed[node] selected by c) == target(c)
+__device__ __forceinline__ void tile_mma_onehot(f32x16 &acc, const int *__restrict__ packed, const float *__restrict__ Bm,
+                                                int lane)
+{
+    const int c = lane & 31, hh = lane >> 5;
+    int sh, mask, tgt;
+    if (c < 3) { sh = 0; mask = 3; tgt = c; }
+    else if (c < 10) { sh = 2; mask = 7; tgt = c - 3; }
+    else if (c < 18) { sh = 5; mask = 7; tgt = c - 10; }
+    else { sh = 0; mask = 0; tgt = 1; }
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) {
+        const int node = 2 * s + hh;
+        const float a = (((packed[node] >> sh) & mask) == tgt) ? 1.0f : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bm[node * 33 + c], acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ float column_half_sum(const float *__restrict__ A, int lane)
+{
+    const int c = lane & 31, hh = lane >> 5;
+    float s = 0.0f;
+#pragma unroll 8
+    for (int n = 0; n < 32; ++n) s += A[(hh * 32 + n) * 33 + c];
+    return s;
+}
+
+__global__ __launch_bounds__(64 * kEncBwdWaves, 2) void encode_bwd_kernel(const float *__restrict__ x, int64_t x_stride,
+                                                                          const int64_t *__restrict__ xcat, int64_t N,
+                                                                          ENC_PARAMS, const float *__restrict__ gh,
+                                                                          const float *__restrict__ hout,
+                                                                          int64_t nodes_per_wave,
+                                                                          float *__restrict__ partial)
+{
+    __shared__ float bufA[kEncBwdWaves][64 * 33];
+    __shared__ float bufB[kEncBwdWaves][64 * 33];
+    __shared__ int bufI[kEncBwdWaves][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *A = bufA[wv], *Bm = bufB[wv];
+    int *packed = bufI[wv];
+    const int64_t wave = (int64_t)blockIdx.x * kEncBwdWaves + wv;
+    const int64_t lo = wave * nodes_per_wave, hi = min(N, lo + nodes_per_wave);
+    f32x16 acc[kEncTiles];
+#pragma unroll
+    for (int t = 0; t < kEncTiles; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+    float bias3 = 0.0f, bias21 = 0.0f;
+
+    for (int64_t base = lo; base < hi; base += 64) {
+        // an opaque (always zero) scalar offset makes the weight addresses loop-variant: the loads stay scalar
+        // (uniform address off a __restrict__ base) but cannot be hoisted out of this loop, where 2.5k weights
+        // would overflow the SGPR file and be shuttled through v_writelane/v_readlane
+        int zero = 0;
+        asm volatile("" : "+s"(zero));
+        const float *__restrict__ wc = Wc + zero, *__restrict__ wk = Wk + zero, *__restrict__ wa = Wa + zero,
+                                  *__restrict__ pbc = bc + zero, *__restrict__ pbk = bk + zero;
+        const int64_t i = base + lane;
+        const bool live = i < hi;
+        const int64_t ii = live ? i : (hi - 1);
+        const float *row = x + ii * x_stride;
+        float xc[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) xc[f] = row[f];
+        int ichg, ipdg, ipv;
+        cat_indices(xcat, ii, ichg, ipdg, ipv);
+        packed[lane] = ichg | (ipdg << 2) | (ipv << 5);
+        float cat24[24], joint[32];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            cat24[e] = Echg[ichg * 8 + e];
+            cat24[8 + e] = Epdg[ipdg * 8 + e];
+            cat24[16 + e] = Epv[ipv * 8 + e];
+        }
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            float a = pbc[o];
+#pragma unroll
+            for (int f = 0; f < 8; ++f) a = __builtin_fmaf(wc[o * 8 + f], xc[f], a);
+            joint[16 + o] = elu(a);
+            float b = pbk[o];
+#pragma unroll
+            for (int f = 0; f < 24; ++f) b = __builtin_fmaf(wk[o * 24 + f], cat24[f], b);
+            joint[o] = elu(b);
+        }
+        // g_z3 = g_h * ELU'(z3), ELU' from h itself; stage A = g_z3, B = joint
+        float gz[32];
+        {
+            const float4 *gp = reinterpret_cast<const float4 *>(gh + ii * 32);
+            const float4 *hp = reinterpret_cast<const float4 *>(hout + ii * 32);
+#pragma unroll
+            for (int c4 = 0; c4 < 8; ++c4) {
+                const float4 gv = gp[c4], hv = hp[c4];
+                const float gg[4] = {gv.x, gv.y, gv.z, gv.w}, hh4[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float d = hh4[u] > 0.0f ? 1.0f : (hh4[u] + 1.0f);
+                    gz[4 * c4 + u] = live ? gg[u] * d : 0.0f;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) { A[lane * 33 + c] = gz[c]; Bm[lane * 33 + c] = joint[c]; }
+        enc_wave_sync();
+        tile_mma(acc[0], A, Bm, lane);           // g_z3^T joint
+        bias3 += column_half_sum(A, lane);
+        // back through encode_all: g_joint = Wa^T g_z3 (rows of Wa read sequentially), then the two ELUs
+        float gj[32];
+#pragma unroll
+        for (int f = 0; f < 32; ++f) gj[f] = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 32; ++o)
+#pragma unroll
+            for (int f = 0; f < 32; ++f) gj[f] = __builtin_fmaf(wa[o * 32 + f], gz[o], gj[f]);
+#pragma unroll
+        for (int f = 0; f < 32; ++f) gj[f] *= joint[f] > 0.0f ? 1.0f : (joint[f] + 1.0f);   // [g_z2 | g_z1]
+        enc_wave_sync();
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            A[lane * 33 + c] = gj[c];
+            Bm[lane * 33 + c] = (c < 24) ? cat24[c] : xc[c - 24];
+        }
+        enc_wave_sync();
+        tile_mma(acc[1], A, Bm, lane);           // [g_z2|g_z1]^T [cat24|x_cont]
+        bias21 += column_half_sum(A, lane);
+        // g_cat24 = Wk^T g_z2
+        float gc[24];
+#pragma unroll
+        for (int f = 0; f < 24; ++f) gc[f] = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 16; ++o)
+#pragma unroll
+            for (int f = 0; f < 24; ++f) gc[f] = __builtin_fmaf(wk[o * 24 + f], gj[o], gc[f]);
+        enc_wave_sync();
+#pragma unroll
+        for (int c = 0; c < 32; ++c) Bm[lane * 33 + c] = (c < 24) ? gc[c < 24 ? c : 0] : 0.0f;
+        enc_wave_sync();
+        tile_mma_onehot(acc[2], packed, Bm, lane);   // S^T [g_cat24|0]
+        enc_wave_sync();
+    }
+    // per-wave partial: 3 tiles [32][32] then [dba(32) | dbk(16) dbc(16)]
+    float *out = partial + wave * (int64_t)kEncPartial;
+    const int c = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < kEncTiles; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = (e & 3) + 8 * (e >> 2) + 4 * hh;
+            out[t * 1024 + r * 32 + c] = acc[t][e];
+        }
+    const float b3 = bias3 + __shfl_xor(bias3, 32), b21 = bias21 + __shfl_xor(bias21, 32);
+    if (hh == 0) { out[kEncTiles * 1024 + c] = b3; out[kEncTiles * 1024 + 32 + c] = b21; }
+}
+
+struct EncGrads {
+    float *Wc, *bc, *Wk, *bk, *Wa, *ba, *Echg, *Epdg, *Epv;
+};
+
+// Sum the wavefront partials in a fixed order and route each element to its parameter gradient.  A block owns 32
+// consecutive elements; its 32 thread groups each sum every 32nd partial, then group 0 adds the 32 group sums in order.
+__global__ __launch_bounds__(1024) void encode_bwd_finalize_kernel(const float *__restrict__ partial, int64_t nwaves,
+                                                                    EncGrads g)
+{
+    __shared__ float red[32][33];
+    const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + e;
+    float s = 0.0f;
+    for (int64_t w = grp; w < nwaves; w += 32) s += partial[w * kEncPartial + idx];
+    red[grp][e] = s;
+    __syncthreads();
+    if (grp != 0) return;
+    s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) s += red[q][e];
+    const int t = idx / 1024, r = (idx % 1024) / 32, c = idx % 32;
+    if (t == 0) g.Wa[r * 32 + c] = s;
+    else if (t == 1) {
+        if (r < 16 && c < 24) g.Wk[r * 24 + c] = s;
+        else if (r >= 16 && c >= 24) g.Wc[(r - 16) * 8 + (c - 24)] = s;
+    } else if (t == 2) {
+        if (r < 3 && c < 8) g.Echg[r * 8 + c] = s;
+        else if (r >= 3 && r < 10 && c >= 8 && c < 16) g.Epdg[(r - 3) * 8 + (c - 8)] = s;
+        else if (r >= 10 && r < 18 && c >= 16 && c < 24) g.Epv[(r - 10) * 8 + (c - 16)] = s;
+    } else if (r == 0) g.ba[c] = s;
+    else if (c < 16) g.bk[c] = s;
+    else g.bc[c - 16] = s;
+}
+
+inline int64_t enc_nodes_per_wave(int64_t N, int64_t *nwaves)
+{
+    const int64_t target_waves = 2048;   // 256 CUs x 8 resident wavefronts
+    int64_t npw = (N + target_waves - 1) / target_waves;
+    npw = (npw + 63) / 64 * 64;
+    if (npw < 64) npw = 64;
+    int64_t nw = (N + npw - 1) / npw;
+    nw = (nw + kEncBwdWaves - 1) / kEncBwdWaves * kEncBwdWaves;
+    *nwaves = nw;
+    return npw;
+}
+
+}  // namespace
+}  // namespace dmet
+
+using namespace dmet;
+
+extern "C" int dmet_encode_fwd_f32(const float *x, int64_t x_stride, const int64_t *xcat, int64_t N, const float *Wc, const float *bc,
+                                   const float *Wk, const float *bk, const float *Wa, const float *ba,
+                                   const float *Echg, const float *Epdg, const float *Epv, float *h,
+                                   dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && x_stride >= 8, "dmet_encode_fwd_f32: bad sizes");
+    if (N == 0) return 0;
+    DMET_REQUIRE(x && xcat && Wc && bc && Wk && bk && Wa && ba && Echg && Epdg && Epv && h, "dmet_encode_fwd_f32: null pointer");
+    DMET_REQUIRE(aligned16(h), "dmet_encode_fwd_f32: h must be 16-B aligned");
+    const int64_t blocks = (N + 255) / 256;
+    DMET_REQUIRE(blocks < (1ll << 31), "dmet_encode_fwd_f32: too many nodes");
+    hipLaunchKernelGGL(encode_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, x_stride, xcat, N, ENC_ARGS, h);
+    DMET_LAUNCH_CHECK("encode_fwd_kernel");
+    return 0;
+}
+
+extern "C" size_t dmet_encode_bwd_workspace_bytes(int64_t N)
+{
+    if (N <= 0) return 0;
+    int64_t nw;
+    (void)enc_nodes_per_wave(N, &nw);
+    return sizeof(float) * (size_t)nw * kEncPartial + 512;
+}
+
+extern "C" int dmet_encode_bwd_f32(const float *x, int64_t x_stride, const int64_t *xcat, int64_t N, const float *Wc, const float *bc,
+                                   const float *Wk, const float *bk, const float *Wa, const float *ba,
+                                   const float *Echg, const float *Epdg, const float *Epv, const float *h,
+                                   const float *g_h, float *gWc, float *gbc, float *gWk, float *gbk, float *gWa,
+                                   float *gba, float *gEchg, float *gEpdg, float *gEpv, void *ws, size_t ws_bytes,
+                                   dmet_stream_t stream)
+{
+    DMET_REQUIRE(N > 0 && x_stride >= 8, "dmet_encode_bwd_f32: bad sizes");
+    DMET_REQUIRE(x && xcat && Wc && bc && Wk && bk && Wa && ba && Echg && Epdg && Epv && h && g_h && gWc && gbc && gWk && gbk &&
+                     gWa && gba && gEchg && gEpdg && gEpv && ws,
+                 "dmet_encode_bwd_f32: null pointer");
+    DMET_REQUIRE(ws_bytes >= dmet_encode_bwd_workspace_bytes(N), "dmet_encode_bwd_f32: workspace too small");
+    DMET_REQUIRE(aligned16(h) && aligned16(g_h), "dmet_encode_bwd_f32: h / g_h must be 16-B aligned");
+    int64_t nw;
+    const int64_t npw = enc_nodes_per_wave(N, &nw);
+    float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(encode_bwd_kernel, dim3((unsigned)(nw / kEncBwdWaves)), dim3(64 * kEncBwdWaves), 0, st, x, x_stride,
+                       xcat, N, ENC_ARGS, g_h, h, npw, partial);
+    DMET_LAUNCH_CHECK("encode_bwd_kernel");
+    EncGrads gr{gWc, gbc, gWk, gbk, gWa, gba, gEchg, gEpdg, gEpv};
+    static_assert(kEncPartial % 32 == 0, "finalize blocks own 32 elements");
+    hipLaunchKernelGGL(encode_bwd_finalize_kernel, dim3(kEncPartial / 32), dim3(1024), 0, st, partial, nw, gr);
+    DMET_LAUNCH_CHECK("encode_bwd_finalize_kernel");
+    return 0;
+}

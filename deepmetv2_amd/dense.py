@@ -56,3 +56,26 @@ def embedding(index: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     if weight.shape[0] > 64 or weight.shape[1] > 64 or index.dim() != 1:
         return torch.nn.functional.embedding(index, weight)
     return _Embedding.apply(index, weight)
+
+
+class _Encode(torch.autograd.Function):
+    """The whole per-node encoder (graph_met_network.py:48-58 before bn_all) as one HIP kernel each way
+    (csrc/encoder.hip).  Inputs carry no gradient; the nine parameter gradients come out of one backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x_cont, x_cat, *params):
+        h = _native.encode_fwd(x_cont, x_cat, [p.detach() for p in params])
+        ctx.save_for_backward(x_cont, x_cat, h, *params)
+        return h
+
+    @staticmethod
+    def backward(ctx, g_h):
+        x_cont, x_cat, h, *params = ctx.saved_tensors
+        grads = _native.encode_bwd(x_cont, x_cat, [p.detach() for p in params], h, g_h.contiguous())
+        return (None, None, *grads)
+
+
+def encode(x_cont: torch.Tensor, x_cat: torch.Tensor, *params: torch.Tensor) -> torch.Tensor:
+    """h[N,32] = ELU(Wa [ELU(Wk [Echg[chg+1] | Epdg[remap |pdg|] | Epv[pv]] + bk) | ELU(Wc x_cont + bc)] + ba);
+    params = (Wc, bc, Wk, bk, Wa, ba, Echg, Epdg, Epv) in torch layouts."""
+    return _Encode.apply(x_cont, x_cat, *params)

@@ -10,6 +10,7 @@ package's operators.  `graph='dynamic'` rebuilds a kNN graph in the current embe
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -37,6 +38,7 @@ class GraphMETNetwork(nn.Module):
             raise ValueError("graph must be 'static' or 'dynamic'")
         q, h = hidden_dim // 4, hidden_dim // 2
         self.graph, self.k = graph, k
+        self.fused_encoder = os.environ.get("DMET_FUSED_ENCODER", "1") != "0"
         self.embed_charge = nn.Embedding(3, q)
         self.embed_pdgid = nn.Embedding(len(PDG_CLASSES), q)
         self.embed_pv = nn.Embedding(8, q)
@@ -53,8 +55,20 @@ class GraphMETNetwork(nn.Module):
         self.output = nn.Sequential(nn.Linear(hidden_dim, h), nn.ELU(), nn.Linear(h, output_dim))
         self.pdgs = list(PDG_CLASSES)
 
+    def _fused_encoder_ok(self, x_cont: torch.Tensor, x_cat: torch.Tensor) -> bool:
+        return (self.fused_encoder and x_cont.dtype == torch.float32 and x_cont.shape[1] == 8
+                and x_cat.shape[1] == 3 and self.encode_all[0].weight.shape == (32, 32)
+                and list(self.pdgs) == list(PDG_CLASSES) and not x_cont.requires_grad)
+
     def embed(self, x_cont: torch.Tensor, x_cat: torch.Tensor) -> torch.Tensor:
-        """Per-node encoder (graph_met_network.py:48-58): columns of x_cat are (pdgId, charge, fromPV)."""
+        """Per-node encoder (graph_met_network.py:48-58): columns of x_cat are (pdgId, charge, fromPV).
+        The standard shape (8 continuous columns, hidden_dim 32) runs as one HIP kernel each way (csrc/encoder.hip);
+        anything else takes the layer-by-layer route below."""
+        if self._fused_encoder_ok(x_cont, x_cat):
+            lc, lk, la = self.embed_continuous[0], self.embed_categorical[0], self.encode_all[0]
+            h = dense.encode(x_cont, x_cat, lc.weight, lc.bias, lk.weight, lk.bias, la.weight, la.bias,
+                             self.embed_charge.weight, self.embed_pdgid.weight, self.embed_pv.weight)
+            return self.bn_all(h)
         e_cont = _run(self.embed_continuous, x_cont)
         e_chrg = dense.embedding(x_cat[:, 1] + 1, self.embed_charge.weight)
         e_pv = dense.embedding(x_cat[:, 2], self.embed_pv.weight)

@@ -169,6 +169,23 @@ int dmet_xty_f32(const float *A, const float *B, int64_t N, int Ha, int Hb, floa
 int dmet_onehot_xty_f32(const int64_t *index, const float *B, int64_t N, int R, int Hb, float *C, void *ws,
                         size_t ws_bytes, dmet_stream_t stream);
 
+/* ---- N3 (second piece): the per-node encoder as one kernel each way ---------------------------------------
+ * model/graph_met_network.py:48-58 up to (not including) bn_all:
+ *   h = ELU(Wa [ELU(Wk [Echg[chg+1] | Epdg[remap(|pdg|)] | Epv[pv]] + bk) | ELU(Wc x[:, :8] + bc)] + ba)
+ * x[N,8] fp32 continuous columns with row stride x_stride floats (a view into the 11-column feature matrix is
+ * fine); x_cat[N,3] int64 = (pdgId, charge, fromPV), the arguments of GraphMETNetwork.forward.  Torch layouts
+ * for the weights (Linear.weight [out,in], Embedding.weight [rows,8]).  Backward takes the forward output h and g_h = dL/dh and
+ * writes (not accumulates) all nine parameter gradients, reduced over the nodes deterministically. */
+int dmet_encode_fwd_f32(const float *x, int64_t x_stride, const int64_t *x_cat, int64_t N, const float *Wc, const float *bc,
+                        const float *Wk, const float *bk, const float *Wa, const float *ba, const float *Echg,
+                        const float *Epdg, const float *Epv, float *h, dmet_stream_t stream);
+size_t dmet_encode_bwd_workspace_bytes(int64_t N);
+int dmet_encode_bwd_f32(const float *x, int64_t x_stride, const int64_t *x_cat, int64_t N, const float *Wc, const float *bc,
+                        const float *Wk, const float *bk, const float *Wa, const float *ba, const float *Echg,
+                        const float *Epdg, const float *Epv, const float *h, const float *g_h, float *gWc,
+                        float *gbc, float *gWk, float *gbk, float *gWa, float *gba, float *gEchg, float *gEpdg,
+                        float *gEpv, void *ws, size_t ws_bytes, dmet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -155,7 +155,31 @@ def onehot_xty(index, Bm, num_rows):
     return torch.zeros((num_rows, Bm.shape[1]), dtype=Bm.dtype).index_add_(0, index, Bm.detach())
 
 
-_NAMES = ["knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
+def _encode_chain(x_cont, x_cat, params):
+    Wc, bc, Wk, bk, Wa, ba, Echg, Epdg, Epv = params
+    F = torch.nn.functional
+    pdg = x_cat[:, 0].abs()
+    for cls, val in enumerate((1, 2, 11, 13, 22, 130, 211)):
+        pdg = torch.where(pdg == val, torch.full_like(pdg, cls), pdg)
+    cat = torch.cat([Echg[x_cat[:, 1] + 1], Epdg[pdg], Epv[x_cat[:, 2]]], dim=1)
+    e_cat = F.elu(F.linear(cat, Wk, bk))
+    e_cont = F.elu(F.linear(x_cont, Wc, bc))
+    return F.elu(F.linear(torch.cat([e_cat, e_cont], dim=1), Wa, ba))
+
+
+def encode_fwd(x_cont, x_cat, params):
+    with torch.no_grad():
+        return _encode_chain(x_cont, x_cat, params)
+
+
+def encode_bwd(x_cont, x_cat, params, h, g_h):
+    ps = [p.detach().clone().requires_grad_(True) for p in params]
+    with torch.enable_grad():
+        out = _encode_chain(x_cont, x_cat, ps)
+    return list(torch.autograd.grad(out, ps, g_h))
+
+
+_NAMES = ["encode_fwd", "encode_bwd", "knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
           "edge_features_bwd", "segment_max", "segment_sum", "segment_max_bwd", "segment_sum_bwd", "met_reduce",
           "met_reduce_bwd", "segment_sum_1d", "batch_to_ptr", "xty", "onehot_xty", "edgeconv_fused_lds"]
 

@@ -327,6 +327,49 @@ def test_dense_weight_grad_kernels(dev, N, Ha, Hb):
     assert float((got2.cpu().double() - ref2).abs().max()) <= 1e-5 * max(1.0, float(ref2.abs().max()))
 
 
+@pytest.mark.parametrize("N", [1, 63, 65, 5000, 70001])
+def test_fused_encoder_fwd_bwd(dev, N):
+    """N3: csrc/encoder.hip (one kernel each way) vs the oracle's layer-by-layer encoder in float64 on the CPU
+    (the restatement of graph_met_network.py:48-58 in oracle/ref_model.py), including unexpected pdg ids."""
+    from deepmetv2_amd import dense
+    from oracle import ref_model
+    torch.manual_seed(11)
+    ref = ref_model.RefGraphMETNetwork(8, 3, output_dim=1, hidden_dim=32, conv_depth=1)
+    g = torch.Generator().manual_seed(N)
+    x_cont = torch.randn(N, 8, generator=g) * 2.0
+    pdg_pool = torch.tensor([1, 2, 11, -11, 13, -13, 22, 130, 211, -211, 0, 5, 4, 3])   # 0/5/4/3: not in the table
+    x_cat = torch.stack([pdg_pool[torch.randint(0, len(pdg_pool), (N,), generator=g)],
+                         torch.randint(-1, 2, (N,), generator=g), torch.randint(0, 8, (N,), generator=g)], dim=1)
+    g_h = torch.randn(N, 32, generator=g)
+    names = ["embed_continuous.0.weight", "embed_continuous.0.bias", "embed_categorical.0.weight",
+             "embed_categorical.0.bias", "encode_all.0.weight", "encode_all.0.bias", "embed_charge.weight",
+             "embed_pdgid.weight", "embed_pv.weight"]
+    sd = dict(ref.named_parameters())
+    # reference chain in float64
+    ref64 = ref.double()
+    F = torch.nn.functional
+    pdg = x_cat[:, 0].abs()
+    for cls, val in enumerate(ref_model._PDG_TABLE):
+        pdg = torch.where(pdg == val, torch.full_like(pdg, cls), pdg)
+    cat = torch.cat([ref64.embed_charge(x_cat[:, 1] + 1), ref64.embed_pdgid(pdg), ref64.embed_pv(x_cat[:, 2])], dim=1)
+    h_ref = ref64.encode_all(torch.cat([ref64.embed_categorical(cat), ref64.embed_continuous(x_cont.double())], dim=1))
+    h_ref.backward(g_h.double())
+    params = [sd[n].detach().float().to(dev).requires_grad_(True) for n in names]
+    big = torch.cat([x_cont, x_cat.float()], dim=1).to(dev)          # strided view, as split_features hands over
+    h = dense.encode(big[:, :8], x_cat.to(dev), *params)
+    h.backward(g_h.to(dev))
+    torch.testing.assert_close(h.detach().cpu().double(), h_ref.detach(), rtol=1e-5, atol=1e-5)
+    for n, p in zip(names, params):
+        r = sd[n].grad
+        torch.testing.assert_close(p.grad.cpu().double(), r, rtol=1e-4, atol=1e-5 * max(1.0, float(r.abs().max())),
+                                   msg=lambda m, n=n: f"{n}: {m}")
+    # bitwise reproducible (fixed reduction order)
+    params2 = [p.detach().clone().requires_grad_(True) for p in params]
+    dense.encode(big[:, :8], x_cat.to(dev), *params2).backward(g_h.to(dev))
+    for p, q in zip(params, params2):
+        assert torch.equal(p.grad, q.grad)
+
+
 def test_dense_linear_embedding_autograd(dev):
     from deepmetv2_amd import dense
     g = torch.Generator().manual_seed(0)
