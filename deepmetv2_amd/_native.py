@@ -97,8 +97,9 @@ GATHER_MAX_FORM = os.environ.get("DMET_GATHER_MAX_FORM", "auto")
 
 
 # ---- K1 ------------------------------------------------------------------------------------------------------
-def knn(x: torch.Tensor, ptr: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """nbr[N,k] int32 (global ids, -1 padded), dist[N,k] fp32."""
+def knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """nbr[N,k] int32 (global ids, -1 padded), dist[N,k] fp32.  With a `stats` dict the call synchronises and stores
+    stats['flagged_tiles'] (128-query tiles the matrix-core path handed to the exact kernel; diagnostics only)."""
     dev = _require_device(x, ptr)
     L = _lib.load()
     x = _f32c(x.detach(), "x")
@@ -116,6 +117,10 @@ def knn(x: torch.Tensor, ptr: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch
                                   ws.data_ptr(), ws.numel(), _stream(dev)), "dmet_knn_f32")
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))
+    if stats is not None and N > 0 and B > 0:
+        with torch.cuda.device(dev):
+            stats["flagged_tiles"] = int(L.dmet_knn_flagged_tiles(ws.data_ptr(), N, B, D, k, _stream(dev)))
+            stats["tiles"] = (N + 127) // 128
     return nbr, dist
 
 

@@ -167,6 +167,8 @@ struct KnnArgs {
     const int32_t *tile_ptr;  // [B+1] exclusive prefix of per-position tile counts
     float *psd;            // [(tile-n_full)*tile_queries + slot][split][KP] partial lists of split tiles
     int32_t *psj;
+    const int32_t *flags;  // optional [tiles] = number of uncertified queries per tile (matrix-core path): only
+    int flag_min;          // tiles with flags[tile] >= flag_min are computed here
 };
 
 // One workgroup: events ordered LONGEST FIRST (a tile of an n-node event costs n candidates, so big events go out
@@ -176,8 +178,9 @@ struct KnnArgs {
 constexpr int kMaxSortedEvents = 4096;  // beyond this the O(B^2) ranking is skipped (identity order)
 
 __global__ __launch_bounds__(256) void knn_plan_kernel(const int64_t *__restrict__ ptr, int B, int tile_queries,
-                                                        int simds, int32_t *__restrict__ order,
-                                                        int32_t *__restrict__ tile_ptr, KnnPlan *__restrict__ plan)
+                                                        int simds, int max_split, int32_t *__restrict__ order,
+                                                        int32_t *__restrict__ pos_of, int32_t *__restrict__ tile_ptr,
+                                                        KnnPlan *__restrict__ plan)
 {
     __shared__ int part[256];
     const int tid = threadIdx.x;
@@ -190,9 +193,10 @@ __global__ __launch_bounds__(256) void knn_plan_kernel(const int64_t *__restrict
                 rank += (nc > nb || (nc == nb && c < b)) ? 1 : 0;
             }
             order[rank] = b;
+            pos_of[b] = rank;
         }
     } else {
-        for (int b = tid; b < B; b += 256) order[b] = b;
+        for (int b = tid; b < B; b += 256) { order[b] = b; pos_of[b] = b; }
     }
     __syncthreads();
     const int chunk = (B + 255) / 256;
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256) void knn_plan_kernel(const int64_t *__restrict
             const int rem = tiles - full;
             if (rem > 0) {
                 int f = simds / rem;
-                if (f > kMaxSplit) f = kMaxSplit;
+                if (f > max_split) f = max_split;
                 if (f >= 2) { n_full = full; split = f; }
             }
         }
@@ -307,6 +311,7 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 3) void knn_kernel(const Kn
         nsub = split;
     }
     if (tile >= total) return;
+    if (a.flags && a.flags[tile] < a.flag_min) return;
     const int pos = find_tile_event(a.tile_ptr, a.B, tile);
     const int ev = a.order[pos];
     const int ev_lo = (int)ptr[ev], ev_hi = (int)ptr[ev + 1];
@@ -468,6 +473,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const KnnArgs a, int til
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int tile = n_full + (int)(slot / tile_queries);
     if (tile >= total) return;
+    if (a.flags && a.flags[tile] < a.flag_min) return;
     const int pos = find_tile_event(a.tile_ptr, a.B, tile);
     const int ev = a.order[pos];
     const int64_t qi = a.ptr[ev] + (int64_t)(tile - a.tile_ptr[pos]) * tile_queries + (slot % tile_queries);
@@ -496,6 +502,460 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const KnnArgs a, int til
     }
 }
 
+// ---- matrix-core filter + exact re-rank (D = 32) ---------------------------------------------------------------
+// The difference form of R1 cannot run on the matrix cores, but it does not have to run for every pair.  With
+//   key(i,j) = |x_j|^2 - 2 x_i.x_j   ( = d(i,j) - |x_i|^2 in exact arithmetic )
+// a matrix-core sweep ranks the candidates of every query approximately.  Each fp32 feature is split into two bf16
+// terms x = h + m + r (h = bf16(x), m = bf16(x - h), |r| <= 2^-18 |x|) and x_i.x_j is taken as h.h' + h.m' + m.h' with
+// v_mfma_f32_32x32x16_bf16 (exact bf16 products, fp32 accumulation): 6 MFMAs of 8 passes per 32x32 block instead of
+// 16 fp32 MFMAs of 16 passes (measured on MI355X, tools/mfma_valu_micro.hip: MFMA passes and VALU instructions of a
+// SIMD do NOT overlap, not even across wavefronts, so matrix-pipe time adds to the selection's VALU time).
+// Error budget per pair, relative to (|x_i| + |x_j|)^2: dropped terms 1.5 * 2^-18, fp32 accumulation and the norms
+// ~3 * 2^-18, the R1 chain itself 0.5 * 2^-18; e_i = kSlackRel * (|x_i| + max_j |x_j|)^2 with kSlackRel = 2^-13 keeps a
+// 4x margin, so  |d_chain(i,j) - (key(i,j) + |x_i|^2)| <= e_i  for every j of the event.
+//   1. knn_filter_kernel: every query keeps, per partial list (two half-row lanes x candidate sub-sweeps), the KP
+//      smallest keys.
+//   2. knn_rerank_kernel: the exact R1 chain for the <= 2*split*KP kept candidates, top-k by (d, j) (R2).  It is THE
+//      exact answer iff nothing that could belong to the top k was dropped: a dropped candidate of a full list has
+//      key >= that list's largest kept key w, hence d >= w + |x_i|^2 - e_i; if that exceeds the k-th smallest exact
+//      distance among the kept candidates for every full list, the kept top-k is the global top-k.
+//   3. Queries that fail the test (exact ties beyond the list length, duplicates, lattices) are recomputed exactly:
+//      one wavefront per query when a 128-query tile has few of them, the exact tile kernel above otherwise.
+// Result: bit-identical output at a fraction of the VALU work.
+constexpr int kFQ = 64;             // queries per filter work item: two 32-column MFMA blocks
+constexpr int kFQueue = 16;         // pending-queue slots per lane and block (8 keys are examined between checks)
+constexpr int kFilterMaxSplit = 2;  // tail balancing of the filter: at most 2 candidate sub-sweeps
+constexpr float kSlackRel = 1.220703125e-4f;   // 2^-13
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+struct KnnFilterArgs {
+    const float *x;
+    const int64_t *ptr;
+    int B;
+    int64_t N;
+    int k;
+    float *nrm;                 // [N] squared norms
+    unsigned short *xs;         // [N][64] bf16 split of x: 32 high terms, then 32 middle terms
+    unsigned *evmax;            // [B] largest squared norm of the event (float bits; non-negative floats order as uints)
+    float *fd;                  // [N][2][KP] keys of the whole-sweep lists
+    int32_t *fj;
+    const KnnPlan *plan;        // filter plan (kFQ-query tiles)
+    const int32_t *order;
+    const int32_t *pos_of;
+    const int32_t *tile_ptr;
+    float *psd;                 // split tiles: [(tile-n_full)*kFQ + slot][split][2][KP]
+    int32_t *psj;
+    int32_t *nbr;
+    float *dist;
+    int32_t *flags;             // [exact tiles] number of uncertified queries of the tile
+    uint8_t *qflag;             // [N] 1 = uncertified query
+    const int32_t *xtile_ptr;   // tile prefix of the exact kernel's plan (same event order)
+    int xtile_queries;
+};
+
+__device__ __forceinline__ unsigned bf16_rne_bits(float f)   // finite inputs
+{
+    const unsigned u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__ x, const int64_t *__restrict__ ptr,
+                                                        int B, int64_t N, float *__restrict__ nrm,
+                                                        unsigned short *__restrict__ xs, unsigned *__restrict__ evmax)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < N;
+    if (!live) i = N - 1;                         // keep whole wavefronts for the shuffles below
+    const float4 *row = reinterpret_cast<const float4 *>(x + i * 32);
+    uint2 *hi = reinterpret_cast<uint2 *>(xs + i * 64), *mid = hi + 8;
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float4 v = row[c];
+        s = __builtin_fmaf(v.x, v.x, s); s = __builtin_fmaf(v.y, v.y, s);
+        s = __builtin_fmaf(v.z, v.z, s); s = __builtin_fmaf(v.w, v.w, s);
+        const float f[4] = {v.x, v.y, v.z, v.w};
+        unsigned h[4], m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            h[u] = bf16_rne_bits(f[u]);
+            m[u] = bf16_rne_bits(f[u] - __uint_as_float(h[u] << 16));   // the subtraction is exact
+        }
+        if (live) {
+            hi[c] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            mid[c] = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+        }
+    }
+    if (live) nrm[i] = s;
+    // one atomic per (wavefront, event): max is order-independent, hence deterministic
+    const int b = find_event(ptr, B, i);
+    const int b0 = __shfl(b, 0, 64);
+    if (__all(b == b0)) {
+        float m = s;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(evmax + b0, __float_as_uint(m));
+    } else {
+        atomicMax(evmax + b, __float_as_uint(s));
+    }
+}
+
+// One 32(candidates) x 32(queries) block: acc = cinit + sum over both 16-feature k-blocks of  h.h' + h.m' + m.h'.
+// Operand map of v_mfma_f32_32x32x16_bf16: lane (r = lane & 31, hh = lane >> 5) holds A[row r][k = 8 hh + 0..7].
+// av / bv = {high k-block 0, high k-block 1, middle k-block 0, middle k-block 1}.
+__device__ __forceinline__ f32x16 filter_block(const bf16x8 (&av)[4], const bf16x8 (&bv)[4], const f32x16 &cinit)
+{
+    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], cinit, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[3], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[3], bv[1], acc, 0, 0, 0);
+    return acc;
+}
+
+// candidate tile [c0, c0+32): A operand = the lane's 8-feature slices of candidate c0 + (lane & 31); the accumulator
+// is seeded with |x_j|^2 of the 16 candidate rows this lane receives results for
+__device__ __forceinline__ void filter_load(bf16x8 (&av)[4], f32x16 &cinit, const unsigned short *__restrict__ xs,
+                                            const float *__restrict__ nrm, int c0, int chi, int col, int hh)
+{
+    const int row = min(c0 + col, chi - 1);
+    const bf16x8 *g = reinterpret_cast<const bf16x8 *>(xs + (int64_t)row * 64 + 8 * hh);
+    av[0] = g[0]; av[1] = g[2]; av[2] = g[4]; av[3] = g[6];
+    const float inf = __builtin_inff();
+    if (c0 + 32 <= chi) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cinit[e] = nrm[c0 + (e & 3) + 8 * (e >> 2) + 4 * hh];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = c0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            cinit[e] = (r < chi) ? nrm[r] : inf;   // rows past the range: key = +inf, never admitted
+        }
+    }
+}
+
+// Selection of the 16 keys of a finished block.  The push is branch-free: the queue slot is always written and only
+// kept (cnt advanced) when the key is admitted; queues are drained when any lane has fewer than 8 free slots.
+template <int KP>
+__device__ __forceinline__ void filter_select(const f32x16 &acc, float &tau, int &cnt, uint2 (*queue)[kWave], int lane,
+                                              int jbase, unsigned &fresh, unsigned bit, bool valid,
+                                              float *__restrict__ ld, int32_t *__restrict__ lj)
+{
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = half * 8 + u;
+            const float key = acc[e];
+            queue[cnt][lane] = make_uint2(__float_as_uint(key), (unsigned)(jbase + (e & 3) + 8 * (e >> 2)));
+            cnt += (key < tau) ? 1 : 0;
+        }
+        if (__any(cnt > kFQueue - 8)) {
+            tau = drain_queue<KP>(queue, lane, cnt, (fresh & bit) != 0u, valid, ld, lj);
+            if (!valid) tau = -__builtin_inff();
+            cnt = 0;
+            fresh &= ~bit;
+        }
+    }
+}
+
+template <int KP>
+__global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(const KnnFilterArgs a)
+{
+    __shared__ uint2 queue_all[kWavesPerGroup][2][kFQueue][kWave];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = lane & 31, hh = lane >> 5;
+    const int item = blockIdx.x * kWavesPerGroup + wv;
+    const unsigned short *__restrict__ xs = a.xs;
+    const int64_t *__restrict__ ptr = a.ptr;
+
+    const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
+    int tile = item, sub = 0, nsub = 1;
+    if (item >= n_full) {
+        const int r = item - n_full;
+        tile = n_full + r / split;
+        sub = r % split;
+        nsub = split;
+    }
+    if (tile >= total) return;
+    const int pos = find_tile_event(a.tile_ptr, a.B, tile);
+    const int ev = a.order[pos];
+    const int ev_lo = (int)ptr[ev], ev_hi = (int)ptr[ev + 1];
+    const int q_first = ev_lo + (tile - a.tile_ptr[pos]) * kFQ;
+    int clo = ev_lo, chi = ev_hi;
+    if (nsub > 1) {
+        const int chunk = (((chi - clo) + nsub - 1) / nsub + 31) & ~31;
+        clo = min(chi, clo + sub * chunk);
+        chi = min(chi, clo + chunk);
+    }
+
+    bf16x8 bq[2][4];   // B operands: -2 * the query's bf16 terms (exact: sign flip and exponent + 1)
+    float tau[2];
+    int cnt[2];
+    bool valid[2];
+    float *ld[2];
+    int32_t *lj[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int q = q_first + b * 32 + col;
+        valid[b] = q < ev_hi;
+        const int64_t qq = valid[b] ? q : ev_lo;
+        const bf16x8 *g = reinterpret_cast<const bf16x8 *>(xs + qq * 64 + 8 * hh);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const bf16x8 v = g[2 * m];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float f = -2.0f * __uint_as_float(((unsigned)(unsigned short)v[u]) << 16);
+                bq[b][m][u] = (short)(__float_as_uint(f) >> 16);
+            }
+        }
+        tau[b] = valid[b] ? kKnnSentinel : -__builtin_inff();
+        cnt[b] = 0;
+        if (nsub == 1) {
+            ld[b] = a.fd + (qq * 2 + hh) * KP;
+            lj[b] = a.fj + (qq * 2 + hh) * KP;
+        } else {
+            const int64_t slot = (int64_t)(tile - n_full) * kFQ + b * 32 + col;
+            ld[b] = a.psd + ((slot * nsub + sub) * 2 + hh) * KP;
+            lj[b] = a.psj + ((slot * nsub + sub) * 2 + hh) * KP;
+        }
+    }
+    unsigned fresh = 3u;
+    uint2 (*queue0)[kWave] = queue_all[wv][0];
+    uint2 (*queue1)[kWave] = queue_all[wv][1];
+
+    if (clo < chi) {
+        bf16x8 av[4], an[4];
+        f32x16 ci, cn;
+        filter_load(av, ci, xs, a.nrm, clo, chi, col, hh);
+        f32x16 acc0 = filter_block(av, bq[0], ci);
+        for (int c0 = clo; c0 < chi; c0 += 32) {
+            const bool more = c0 + 32 < chi;
+            if (more) filter_load(an, cn, xs, a.nrm, c0 + 32, chi, col, hh);
+            // a block's MFMAs are issued one selection ahead of their use (result latency)
+            const f32x16 acc1 = filter_block(av, bq[1], ci);
+            filter_select<KP>(acc0, tau[0], cnt[0], queue0, lane, c0 + 4 * hh, fresh, 1u, valid[0], ld[0], lj[0]);
+            if (more) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) av[m] = an[m];
+                ci = cn;
+                acc0 = filter_block(av, bq[0], ci);
+            }
+            filter_select<KP>(acc1, tau[1], cnt[1], queue1, lane, c0 + 4 * hh, fresh, 2u, valid[1], ld[1], lj[1]);
+        }
+    }
+    (void)drain_queue<KP>(queue0, lane, cnt[0], (fresh & 1u) != 0u, valid[0], ld[0], lj[0]);
+    (void)drain_queue<KP>(queue1, lane, cnt[1], (fresh & 2u) != 0u, valid[1], ld[1], lj[1]);
+}
+
+// Exact R1 chain for the kept candidates of one query (32 lanes per query), top-k by (d, j), verification.
+template <int KP>
+__global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
+{
+    constexpr int EMAX = 2 * kFilterMaxSplit * KP;       // entries per query at most
+    constexpr int EL = (EMAX + 31) / 32;                 // entries per lane at most
+    __shared__ float sc[8][EMAX];
+    __shared__ int32_t sj[8][EMAX];
+    __shared__ float skth[8];
+    const int hw = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int64_t q = (int64_t)blockIdx.x * 8 + hw;
+    const bool active = q < a.N;
+    const int64_t qq = active ? q : 0;
+    const int ev = find_event(a.ptr, a.B, qq);
+    const int pos = a.pos_of[ev];
+    const int64_t ev_lo = a.ptr[ev];
+    const int n_full = a.plan->n_full, split = a.plan->split;
+    const int ft = a.tile_ptr[pos] + (int)((qq - ev_lo) / kFQ);
+    int nsub = 1;
+    const float *bd;
+    const int32_t *bj;
+    if (ft >= n_full) {
+        nsub = split;
+        const int64_t slot = (int64_t)(ft - n_full) * kFQ + (qq - ev_lo) % kFQ;
+        bd = a.psd + slot * nsub * 2 * KP;
+        bj = a.psj + slot * nsub * 2 * KP;
+    } else {
+        bd = a.fd + qq * 2 * KP;
+        bj = a.fj + qq * 2 * KP;
+    }
+    const int E = 2 * nsub * KP;
+
+    float qrow[32];
+    {
+        const float4 *g = reinterpret_cast<const float4 *>(a.x + qq * 32);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 v = g[c];
+            qrow[4 * c] = v.x; qrow[4 * c + 1] = v.y; qrow[4 * c + 2] = v.z; qrow[4 * c + 3] = v.w;
+        }
+    }
+    float myc[EL], mykey[EL];
+    int32_t myj[EL];
+#pragma unroll
+    for (int t = 0; t < EL; ++t) {
+        const int idx = l + 32 * t;
+        myc[t] = kKnnSentinel; mykey[t] = 0.0f; myj[t] = -1;
+        if (active && idx < E) {
+            const int32_t j = bj[idx];
+            mykey[t] = bd[idx];
+            myj[t] = j;
+            if (j >= 0) {
+                const float4 *g = reinterpret_cast<const float4 *>(a.x + (int64_t)j * 32);
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float4 v = g[c];
+                    float df;
+                    df = v.x - qrow[4 * c + 0]; acc = __builtin_fmaf(df, df, acc);
+                    df = v.y - qrow[4 * c + 1]; acc = __builtin_fmaf(df, df, acc);
+                    df = v.z - qrow[4 * c + 2]; acc = __builtin_fmaf(df, df, acc);
+                    df = v.w - qrow[4 * c + 3]; acc = __builtin_fmaf(df, df, acc);
+                }
+                myc[t] = acc;
+            }
+            sc[hw][idx] = myc[t];
+            sj[hw][idx] = (j >= 0) ? j : (0x7fffffff - idx);   // missing entries sort last, all distinct
+        }
+    }
+    if (l == 0) skth[hw] = -1.0f;
+    wave_sync();
+    const int k = a.k;
+#pragma unroll
+    for (int t = 0; t < EL; ++t) {
+        const int idx = l + 32 * t;
+        if (active && idx < E) {
+            const float c = myc[t];
+            const int32_t jj = (myj[t] >= 0) ? myj[t] : (0x7fffffff - idx);
+            int rank = 0;
+            for (int e = 0; e < E; ++e) {
+                const float ce = sc[hw][e];
+                const int32_t je = sj[hw][e];
+                rank += (ce < c || (ce == c && je < jj)) ? 1 : 0;
+            }
+            if (rank < k) {
+                a.nbr[q * k + rank] = myj[t];
+                a.dist[q * k + rank] = (myj[t] >= 0) ? c : kKnnSentinel;
+                if (rank == k - 1 && myj[t] >= 0) skth[hw] = c;
+            }
+        }
+    }
+    wave_sync();
+    // verification: every FULL list's largest kept key must put its dropped candidates beyond the k-th distance
+    bool fail = false;
+    if (active) {
+        const float kth = skth[hw];
+        const float nx = a.nrm[qq];
+        const float ymax = __uint_as_float(a.evmax[ev]);
+        const float sn = __builtin_sqrtf(nx) + __builtin_sqrtf(ymax);
+        const float slack = kSlackRel * sn * sn + 1e-30f;
+#pragma unroll
+        for (int t = 0; t < EL; ++t) {
+            const int idx = l + 32 * t;
+            if (idx < E && (idx % KP) == KP - 1 && myj[t] >= 0) {
+                // kth < 0: fewer than k kept candidates although a list is full cannot happen (KP >= k)
+                if (!(mykey[t] + nx - slack > kth)) fail = true;
+            }
+        }
+    }
+    if (fail) {
+        const int xt = a.xtile_ptr[pos] + (int)((qq - ev_lo) / a.xtile_queries);
+        a.qflag[qq] = 1;
+        atomicAdd(a.flags + xt, 1);   // a count: order-independent
+    }
+}
+
+// Uncertified queries of sparsely flagged tiles (1..kRequeryMax per 128-query tile; denser tiles go to the exact
+// tile kernel): one wavefront per query, lanes stride over the event's candidates with the exact R1 chain, then k
+// rounds of "smallest (d, j) above the previous pick" (R2).  Distances are cached in LDS when the event fits.
+constexpr int kRequeryMax = 8;
+constexpr int kRequeryCache = 8192;   // floats per wavefront
+
+__device__ __forceinline__ float chain_dist32(const float *__restrict__ xj, const float (&q)[32])
+{
+    const float4 *g = reinterpret_cast<const float4 *>(xj);
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float4 v = g[c];
+        float df;
+        df = v.x - q[4 * c + 0]; acc = __builtin_fmaf(df, df, acc);
+        df = v.y - q[4 * c + 1]; acc = __builtin_fmaf(df, df, acc);
+        df = v.z - q[4 * c + 2]; acc = __builtin_fmaf(df, df, acc);
+        df = v.w - q[4 * c + 3]; acc = __builtin_fmaf(df, df, acc);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a, const KnnPlan *__restrict__ xplan)
+{
+    __shared__ float cache_all[4][kRequeryCache];
+    const int tile = blockIdx.x;
+    if (tile >= xplan->total_tiles) return;
+    const int nflag = a.flags[tile];
+    if (nflag == 0 || nflag > kRequeryMax) return;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *cache = cache_all[wv];
+    const int pos = find_tile_event(a.xtile_ptr, a.B, tile);
+    const int ev = a.order[pos];
+    const int ev_lo = (int)a.ptr[ev], ev_hi = (int)a.ptr[ev + 1];
+    const int n = ev_hi - ev_lo;
+    const int q_first = ev_lo + (tile - a.xtile_ptr[pos]) * a.xtile_queries;
+    const int q_end = min(ev_hi, q_first + a.xtile_queries);
+    const bool cached = n <= kRequeryCache;
+    const int k = a.k;
+    for (int q = q_first + wv; q < q_end; q += 4) {
+        if (a.qflag[q] == 0) continue;   // wave-uniform
+        float qrow[32];
+        {
+            const float4 *g = reinterpret_cast<const float4 *>(a.x + (int64_t)q * 32);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 v = g[c];
+                qrow[4 * c] = v.x; qrow[4 * c + 1] = v.y; qrow[4 * c + 2] = v.z; qrow[4 * c + 3] = v.w;
+            }
+        }
+        if (cached) {
+            wave_sync();
+            for (int j = lane; j < n; j += kWave) cache[j] = chain_dist32(a.x + (int64_t)(ev_lo + j) * 32, qrow);
+            wave_sync();
+        }
+        float last_d = -1.0f;   // distances are >= 0
+        int last_j = -1;
+        for (int r = 0; r < k; ++r) {
+            float bd = __builtin_inff();
+            int bj = 0x7fffffff;
+            for (int j = lane; j < n; j += kWave) {
+                const float d = cached ? cache[j] : chain_dist32(a.x + (int64_t)(ev_lo + j) * 32, qrow);
+                const int jj = ev_lo + j;
+                const bool after = d > last_d || (d == last_d && jj > last_j);
+                const bool better = d < bd || (d == bd && jj < bj);
+                if (after && better) { bd = d; bj = jj; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float od = __shfl_xor(bd, off, 64);
+                const int oj = __shfl_xor(bj, off, 64);
+                if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+            }
+            const bool found = bj != 0x7fffffff;
+            if (lane == 0) {
+                a.nbr[(int64_t)q * k + r] = found ? bj : -1;
+                a.dist[(int64_t)q * k + r] = found ? bd : kKnnSentinel;
+            }
+            if (!found) {
+                for (int rr = r + 1; rr < k; ++rr)
+                    if (lane == 0) { a.nbr[(int64_t)q * k + rr] = -1; a.dist[(int64_t)q * k + rr] = kKnnSentinel; }
+                break;
+            }
+            last_d = bd; last_j = bj;
+        }
+    }
+}
+
 int num_simds()
 {
     static int cached = 0;
@@ -516,13 +976,27 @@ constexpr int kMaxSimds = 4096;  // workspace bound for the split (tail) tiles: 
 struct KnnWorkspace {
     KnnPlan *plan;
     int32_t *order;
+    int32_t *pos_of;
     int32_t *tile_ptr;
     float *wsd;
     int32_t *wsj;
     float *psd;
     int32_t *psj;
+    // matrix-core filter path
+    KnnPlan *fplan;
+    int32_t *forder;
+    int32_t *fpos_of;
+    int32_t *ftile_ptr;
+    float *nrm;
+    unsigned short *xs;
+    unsigned *evmax;      // evmax[B] and flags[...] are one zero-filled region
+    int32_t *flags;
+    uint8_t *qflag;
+    size_t zero_bytes;
     size_t bytes;
 };
+
+inline int64_t exact_tiles_max(int64_t N, int B) { return (N + 63) / 64 + B + 1; }   // bound for 64- and 128-query tiles
 
 inline KnnWorkspace carve_workspace(void *ws, int64_t N, int B, int KP)
 {
@@ -533,13 +1007,37 @@ inline KnnWorkspace carve_workspace(void *ws, int64_t N, int B, int KP)
     if ((size_t)N + 128 < split_q) split_q = (size_t)N + 128;
     w.plan = reinterpret_cast<KnnPlan *>(take(sizeof(KnnPlan)));
     w.order = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
+    w.pos_of = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
     w.tile_ptr = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
-    w.wsd = reinterpret_cast<float *>(take(sizeof(float) * (size_t)N * KP));
-    w.wsj = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)N * KP));
+    // wsd/wsj double as the filter's [N][2][KP] key lists (the exact kernel runs after the re-rank consumed them)
+    w.wsd = reinterpret_cast<float *>(take(sizeof(float) * (size_t)N * KP * 2));
+    w.wsj = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)N * KP * 2));
     w.psd = reinterpret_cast<float *>(take(sizeof(float) * split_q * kMaxSplit * KP));
     w.psj = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * split_q * kMaxSplit * KP));
+    w.fplan = reinterpret_cast<KnnPlan *>(take(sizeof(KnnPlan)));
+    w.forder = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
+    w.fpos_of = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
+    w.ftile_ptr = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
+    w.nrm = reinterpret_cast<float *>(take(sizeof(float) * (size_t)N));
+    w.xs = reinterpret_cast<unsigned short *>(take(sizeof(unsigned short) * (size_t)N * 64));
+    w.zero_bytes = sizeof(unsigned) * ((size_t)B + 1) + sizeof(int32_t) * (size_t)exact_tiles_max(N, B) + (size_t)N;
+    w.evmax = reinterpret_cast<unsigned *>(take(w.zero_bytes));
+    w.flags = reinterpret_cast<int32_t *>(w.evmax + B + 1);
+    w.qflag = reinterpret_cast<uint8_t *>(w.flags + exact_tiles_max(N, B));
     w.bytes = (size_t)(p - reinterpret_cast<uintptr_t>(ws));
     return w;
+}
+
+// DMET_KNN_PATH=exact disables the matrix-core filter (tests and A/B timing); =filter_only skips the exact fallback
+// of uncertified tiles (diagnostics: output may then be wrong); anything else: filter when eligible + fallback
+inline int filter_mode()
+{
+    static int cached = -1;
+    if (cached < 0) {
+        const char *e = getenv("DMET_KNN_PATH");
+        cached = (e && strcmp(e, "exact") == 0) ? 0 : (e && strcmp(e, "filter_only") == 0) ? 2 : 1;
+    }
+    return cached;
 }
 
 template <int DP, int KP>
@@ -550,9 +1048,40 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     constexpr int QT = kWave * TQ;
     int simds = num_simds();
     if (simds > kMaxSimds) simds = kMaxSimds;
-    hipLaunchKernelGGL(knn_plan_kernel, dim3(1), dim3(256), 0, st, ptr, B, QT, simds, w.order, w.tile_ptr, w.plan);
+    hipLaunchKernelGGL(knn_plan_kernel, dim3(1), dim3(256), 0, st, ptr, B, QT, simds, kMaxSplit, w.order, w.pos_of,
+                       w.tile_ptr, w.plan);
     DMET_LAUNCH_CHECK("knn_plan_kernel");
-    KnnArgs a{x, ptr, B, N, D, k, nbr, dist, w.wsd, w.wsj, w.plan, w.order, w.tile_ptr, w.psd, w.psj};
+    KnnArgs a{x, ptr, B, N, D, k, nbr, dist, w.wsd, w.wsj, w.plan, w.order, w.tile_ptr, w.psd, w.psj, nullptr, 0};
+
+    // matrix-core filter + exact re-rank for the hot shape (D = 32, k <= 32); the exact kernel then only recomputes
+    // the tiles the re-rank could not certify
+    if constexpr (DP == 32 && KP <= 32) {
+        if (D == 32 && aligned16(x) && filter_mode() != 0) {
+            if (hipMemsetAsync(w.evmax, 0, w.zero_bytes, st) != hipSuccess) return hip_fail(hipGetLastError(), "memset");
+            hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, x, ptr, B, N, w.nrm,
+                               w.xs, w.evmax);
+            DMET_LAUNCH_CHECK("knn_prep_kernel");
+            const int slots = simds * 2;   // two filter wavefronts per SIMD
+            hipLaunchKernelGGL(knn_plan_kernel, dim3(1), dim3(256), 0, st, ptr, B, kFQ, slots, kFilterMaxSplit, w.forder,
+                               w.fpos_of, w.ftile_ptr, w.fplan);
+            DMET_LAUNCH_CHECK("knn_plan_kernel");
+            KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.xs, w.evmax, w.wsd, w.wsj, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
+                            w.psd, w.psj, nbr, dist, w.flags, w.qflag, w.tile_ptr, QT};
+            const int64_t ftiles_max = (N + kFQ - 1) / kFQ + B;
+            const int64_t fblocks = (ftiles_max + slots + kWavesPerGroup - 1) / kWavesPerGroup;
+            hipLaunchKernelGGL((knn_filter_kernel<KP>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
+            DMET_LAUNCH_CHECK("knn_filter_kernel");
+            hipLaunchKernelGGL((knn_rerank_kernel<KP>), dim3((unsigned)((N + 7) / 8)), dim3(256), 0, st, f);
+            DMET_LAUNCH_CHECK("knn_rerank_kernel");
+            if (filter_mode() == 2) return 0;
+            const int64_t xtiles_max = (N + QT - 1) / QT + B;
+            hipLaunchKernelGGL(knn_requery_kernel, dim3((unsigned)xtiles_max), dim3(256), 0, st, f, w.plan);
+            DMET_LAUNCH_CHECK("knn_requery_kernel");
+            a.flags = w.flags;
+            a.flag_min = kRequeryMax + 1;
+        }
+    }
+
     // worst-case grid (the plan is on the device): every event adds at most one partial tile, and splitting the
     // fewer-than-`simds` tail tiles adds fewer than `simds` workgroups; surplus workgroups exit at once
     const int64_t tiles_max = (N + QT - 1) / QT + B;
@@ -666,6 +1195,25 @@ extern "C" int dmet_knn_f32(const float *x, const int64_t *ptr, int B, int64_t N
     if (D <= 16) return dispatch_k<16>(x, ptr, B, N, D, k, nbr, dist, ws, st);
     if (D <= 32) return dispatch_k<32>(x, ptr, B, N, D, k, nbr, dist, ws, st);
     return dispatch_k<64>(x, ptr, B, N, D, k, nbr, dist, ws, st);
+}
+
+extern "C" int64_t dmet_knn_flagged_tiles(const void *ws, int64_t N, int B, int D, int k, dmet_stream_t stream)
+{
+    (void)D;
+    if (N <= 0 || B <= 0 || k < 1 || k > DMET_MAX_K || !ws) return -1;
+    const KnnWorkspace w = carve_workspace(const_cast<void *>(ws), N, B, padded_k(k));
+    const int64_t n = exact_tiles_max(N, B);
+    int32_t *host = static_cast<int32_t *>(malloc(sizeof(int32_t) * (size_t)n));
+    if (!host) return -1;
+    hipStream_t st = as_stream(stream);
+    int64_t count = -1;
+    if (hipMemcpyAsync(host, w.flags, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st) == hipSuccess &&
+        hipStreamSynchronize(st) == hipSuccess) {
+        count = 0;
+        for (int64_t i = 0; i < n; ++i) count += host[i] != 0;
+    }
+    free(host);
+    return count;
 }
 
 extern "C" int dmet_radius_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr,
