@@ -523,7 +523,6 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const KnnArgs a, int til
 //      one wavefront per query when a 128-query tile has few of them, the exact tile kernel above otherwise.
 // Result: bit-identical output at a fraction of the VALU work.
 constexpr int kFQ = 64;             // queries per filter work item: two 32-column MFMA blocks
-constexpr int kFQueue = 16;         // pending-queue slots per lane and block (8 keys are examined between checks)
 constexpr int kFilterMaxSplit = 2;  // tail balancing of the filter: at most 2 candidate sub-sweeps
 constexpr float kSlackRel = 1.220703125e-4f;   // 2^-13
 
@@ -539,13 +538,13 @@ struct KnnFilterArgs {
     float *nrm;                 // [N] squared norms
     unsigned short *xs;         // [N][64] bf16 split of x: 32 high terms, then 32 middle terms
     unsigned *evmax;            // [B] largest squared norm of the event (float bits; non-negative floats order as uints)
-    float *fd;                  // [N][2][KP] keys of the whole-sweep lists
+    float *fd;                  // [N][MS] kept keys of the whole-sweep lists (MS = M + threshold slot, padded)
     int32_t *fj;
     const KnnPlan *plan;        // filter plan (kFQ-query tiles)
     const int32_t *order;
     const int32_t *pos_of;
     const int32_t *tile_ptr;
-    float *psd;                 // split tiles: [(tile-n_full)*kFQ + slot][split][2][KP]
+    float *psd;                 // split tiles: [(tile-n_full)*kFQ + slot][split][MS]
     int32_t *psj;
     int32_t *nbr;
     float *dist;
@@ -637,27 +636,98 @@ __device__ __forceinline__ void filter_load(bf16x8 (&av)[4], f32x16 &cinit, cons
     }
 }
 
-// Selection of the 16 keys of a finished block.  The push is branch-free: the queue slot is always written and only
-// kept (cnt advanced) when the key is admitted; queues are drained when any lane has fewer than 8 free slots.
-template <int KP>
-__device__ __forceinline__ void filter_select(const f32x16 &acc, float &tau, int &cnt, uint2 (*queue)[kWave], int lane,
-                                              int jbase, unsigned &fresh, unsigned bit, bool valid,
-                                              float *__restrict__ ld, int32_t *__restrict__ lj)
+// ---- selection state of one query (= one lane) ----------------------------------------------------------------
+// After v_permlane32_swap of the two accumulators lane (c, hh) holds all 32 keys of query (block hh, column c), so
+// a lane owns ONE query.  Per lane:
+//   * tk[M]: the M smallest keys so far, sorted, in registers; inserting is a v_med3_f32 chain (one op per slot,
+//     no payload to move);  tau = tk[M-1] is the admission threshold;
+//   * an LDS queue of (key, j) pairs that doubles as the store of the kept candidates: admitted keys are appended;
+//     when a lane runs out of room the wave drains: new entries update tk, then every lane compacts its queue in
+//     place to the entries with key <= tau (at most M survive, ties aside).  No global-memory traffic until the end.
+// A lane whose queue cannot be compacted below the refill mark (more than M candidates tied at tau) gives up
+// (tau = -inf) and marks its list as overflowed: the re-rank flags such queries for the exact path.
+template <int M>
+struct FilterLane {
+    float tk[M];
+    float tau;
+    int cnt;       // entries in the queue
+    int kept;      // entries that survived the last compaction (already in tk)
+    bool overflow;
+};
+
+constexpr int filter_list_len(int KP) { return KP + (KP / 4 > 4 ? KP / 4 : 4); }   // M: k=16 -> 20, k=8 -> 12
+constexpr int filter_queue_len(int M) { return M + 28; }
+
+// LDS queue of one wavefront: keys and 16-bit event-relative candidate ids in separate arrays (6 bytes per entry:
+// QF = M + 28 slots per lane fit two wavefronts per SIMD).  Events of more than 65535 nodes do not fit the id and
+// are handed to the exact kernel (every lane reports overflow).
+template <int QF>
+struct FilterQueue {
+    unsigned key[QF][kWave];
+    unsigned short id[QF][kWave];
+};
+
+template <int M>
+__device__ __forceinline__ void filter_drain(FilterLane<M> &L, FilterQueue<filter_queue_len(M)> &Q, int lane)
 {
+    constexpr int QF = filter_queue_len(M);
+    // 1. new entries -> sorted keys
+    int maxnew = L.cnt - L.kept;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxnew = max(maxnew, __shfl_xor(maxnew, off, 64));
+    for (int s = 0; s < maxnew; ++s) {
+        const int idx = L.kept + s;
+        if (idx < L.cnt) {
+            const float key = __uint_as_float(Q.key[idx][lane]);
+            if (key < L.tk[M - 1]) {
+#pragma unroll
+                for (int p = M - 1; p >= 1; --p) L.tk[p] = __builtin_amdgcn_fmed3f(L.tk[p - 1], key, L.tk[p]);
+                L.tk[0] = fminf(L.tk[0], key);
+            }
+        }
+    }
+    const float tau = L.tk[M - 1];
+    // 2. in-place compaction of every lane's queue to key <= tau
+    int maxcnt = L.cnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, off, 64));
+    int out = 0;
+    for (int s = 0; s < maxcnt; ++s) {
+        if (s < L.cnt) {
+            const unsigned kb = Q.key[s][lane];
+            const unsigned short id = Q.id[s][lane];
+            if (__uint_as_float(kb) <= tau) { Q.key[out][lane] = kb; Q.id[out][lane] = id; ++out; }
+        }
+    }
+    L.cnt = out;
+    L.kept = out;
+    if (out > QF - 8) {          // cannot make room: too many candidates tied at tau
+        L.overflow = true;
+        L.cnt = 0; L.kept = 0;
+        L.tau = -__builtin_inff();
+    } else if (!L.overflow) {
+        L.tau = tau;
+    }
+}
+
+// 16 keys of one accumulator.  The push is branch-free (a compare, a carry add, the slot address and the id: four VALU
+// ops per key; per-key branches cost more in scalar work and pipeline bubbles than they skip): the slot is always
+// written and only kept when the key is admitted.
+template <int M>
+__device__ __forceinline__ void filter_select(FilterLane<M> &L, const f32x16 &acc, int jrel,
+                                              FilterQueue<filter_queue_len(M)> &Q, int lane)
+{
+    constexpr int QF = filter_queue_len(M);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
+        if (__any(L.cnt > QF - 8)) filter_drain<M>(L, Q, lane);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int e = half * 8 + u;
             const float key = acc[e];
-            queue[cnt][lane] = make_uint2(__float_as_uint(key), (unsigned)(jbase + (e & 3) + 8 * (e >> 2)));
-            cnt += (key < tau) ? 1 : 0;
-        }
-        if (__any(cnt > kFQueue - 8)) {
-            tau = drain_queue<KP>(queue, lane, cnt, (fresh & bit) != 0u, valid, ld, lj);
-            if (!valid) tau = -__builtin_inff();
-            cnt = 0;
-            fresh &= ~bit;
+            Q.key[L.cnt][lane] = __float_as_uint(key);
+            Q.id[L.cnt][lane] = (unsigned short)(jrel + (e & 3) + 8 * (e >> 2));
+            L.cnt += (key < L.tau) ? 1 : 0;
         }
     }
 }
@@ -665,12 +735,16 @@ __device__ __forceinline__ void filter_select(const f32x16 &acc, float &tau, int
 template <int KP>
 __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(const KnnFilterArgs a)
 {
-    __shared__ uint2 queue_all[kWavesPerGroup][2][kFQueue][kWave];
+    constexpr int M = filter_list_len(KP);
+    constexpr int QF = filter_queue_len(M);
+    constexpr int MS = (M + 1 + 3) & ~3;   // list stride in the workspace: M entries, then tau (d array) / overflow (j array)
+    __shared__ FilterQueue<QF> queue_all[kWavesPerGroup];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = lane & 31, hh = lane >> 5;
     const int item = blockIdx.x * kWavesPerGroup + wv;
     const unsigned short *__restrict__ xs = a.xs;
     const int64_t *__restrict__ ptr = a.ptr;
+    FilterQueue<QF> &Q = queue_all[wv];
 
     const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
     int tile = item, sub = 0, nsub = 1;
@@ -691,18 +765,14 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
         clo = min(chi, clo + sub * chunk);
         chi = min(chi, clo + chunk);
     }
+    const bool fits = (ev_hi - ev_lo) <= 65535;   // 16-bit candidate ids
 
-    bf16x8 bq[2][4];   // B operands: -2 * the query's bf16 terms (exact: sign flip and exponent + 1)
-    float tau[2];
-    int cnt[2];
-    bool valid[2];
-    float *ld[2];
-    int32_t *lj[2];
+    // B operands of both 32-query blocks: -2 * the query's bf16 terms (exact: sign flip and exponent + 1)
+    bf16x8 bq[2][4];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int q = q_first + b * 32 + col;
-        valid[b] = q < ev_hi;
-        const int64_t qq = valid[b] ? q : ev_lo;
+        const int64_t qq = (q < ev_hi) ? q : ev_lo;
         const bf16x8 *g = reinterpret_cast<const bf16x8 *>(xs + qq * 64 + 8 * hh);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -713,50 +783,98 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
                 bq[b][m][u] = (short)(__float_as_uint(f) >> 16);
             }
         }
-        tau[b] = valid[b] ? kKnnSentinel : -__builtin_inff();
-        cnt[b] = 0;
-        if (nsub == 1) {
-            ld[b] = a.fd + (qq * 2 + hh) * KP;
-            lj[b] = a.fj + (qq * 2 + hh) * KP;
-        } else {
-            const int64_t slot = (int64_t)(tile - n_full) * kFQ + b * 32 + col;
-            ld[b] = a.psd + ((slot * nsub + sub) * 2 + hh) * KP;
-            lj[b] = a.psj + ((slot * nsub + sub) * 2 + hh) * KP;
-        }
     }
-    unsigned fresh = 3u;
-    uint2 (*queue0)[kWave] = queue_all[wv][0];
-    uint2 (*queue1)[kWave] = queue_all[wv][1];
+    // the query this lane selects for (after the half-wave swap): block hh, column col
+    const int myq = q_first + hh * 32 + col;
+    const bool valid = myq < ev_hi;
+    FilterLane<M> L;
+#pragma unroll
+    for (int p = 0; p < M; ++p) L.tk[p] = kKnnSentinel;
+    L.tau = (valid && fits) ? kKnnSentinel : -__builtin_inff();
+    L.cnt = 0; L.kept = 0;
+    L.overflow = !(valid && fits);   // idle lanes never admit; oversized events are left to the exact kernel
 
-    if (clo < chi) {
+    if (clo < chi && fits) {
         bf16x8 av[4], an[4];
         f32x16 ci, cn;
         filter_load(av, ci, xs, a.nrm, clo, chi, col, hh);
-        f32x16 acc0 = filter_block(av, bq[0], ci);
         for (int c0 = clo; c0 < chi; c0 += 32) {
             const bool more = c0 + 32 < chi;
             if (more) filter_load(an, cn, xs, a.nrm, c0 + 32, chi, col, hh);
-            // a block's MFMAs are issued one selection ahead of their use (result latency)
-            const f32x16 acc1 = filter_block(av, bq[1], ci);
-            filter_select<KP>(acc0, tau[0], cnt[0], queue0, lane, c0 + 4 * hh, fresh, 1u, valid[0], ld[0], lj[0]);
+            f32x16 acc0 = filter_block(av, bq[0], ci);
+            f32x16 acc1 = filter_block(av, bq[1], ci);
+            // lanes 32..63 of block 0 <-> lanes 0..31 of block 1: afterwards acc0 = rows {0-3, 8-11, ..} and
+            // acc1 = rows {4-7, 12-15, ..} of THIS lane's query
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[e]), __float_as_uint(acc1[e]),
+                                                                false, false);
+                acc0[e] = __uint_as_float(r[0]);
+                acc1[e] = __uint_as_float(r[1]);
+            }
+            filter_select<M>(L, acc0, c0 - ev_lo, Q, lane);
+            filter_select<M>(L, acc1, c0 - ev_lo + 4, Q, lane);
             if (more) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) av[m] = an[m];
                 ci = cn;
-                acc0 = filter_block(av, bq[0], ci);
             }
-            filter_select<KP>(acc1, tau[1], cnt[1], queue1, lane, c0 + 4 * hh, fresh, 2u, valid[1], ld[1], lj[1]);
         }
     }
-    (void)drain_queue<KP>(queue0, lane, cnt[0], (fresh & 1u) != 0u, valid[0], ld[0], lj[0]);
-    (void)drain_queue<KP>(queue1, lane, cnt[1], (fresh & 2u) != 0u, valid[1], ld[1], lj[1]);
+    filter_drain<M>(L, Q, lane);
+    if (valid) {
+        float *ld;
+        int32_t *lj;
+        if (nsub == 1) {
+            ld = a.fd + (int64_t)myq * MS;
+            lj = a.fj + (int64_t)myq * MS;
+        } else {
+            const int64_t slot = (int64_t)(tile - n_full) * kFQ + hh * 32 + col;
+            ld = a.psd + (slot * nsub + sub) * MS;
+            lj = a.psj + (slot * nsub + sub) * MS;
+        }
+        // keys below the threshold first, then ties at the threshold until the list is full (a dropped tie has
+        // key == threshold, which is what the certification assumes of dropped candidates)
+        const float tfin = L.tk[M - 1];
+        int out = 0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int s = 0; s < L.cnt; ++s) {
+                const float key = __uint_as_float(Q.key[s][lane]);
+                if ((pass == 0 ? key < tfin : key == tfin) && out < M) {
+                    ld[out] = key;
+                    lj[out] = ev_lo + (int32_t)Q.id[s][lane];
+                    ++out;
+                }
+            }
+        for (; out < M; ++out) { ld[out] = kKnnSentinel; lj[out] = -1; }
+        ld[M] = L.tk[M - 1];              // the list's admission threshold (sentinel while fewer than M keys were seen)
+        lj[M] = (L.overflow || !fits) ? 1 : 0;
+    }
+}
+
+__device__ __forceinline__ float chain_dist32(const float *__restrict__ xj, const float (&q)[32])
+{
+    const float4 *g = reinterpret_cast<const float4 *>(xj);
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float4 v = g[c];
+        float df;
+        df = v.x - q[4 * c + 0]; acc = __builtin_fmaf(df, df, acc);
+        df = v.y - q[4 * c + 1]; acc = __builtin_fmaf(df, df, acc);
+        df = v.z - q[4 * c + 2]; acc = __builtin_fmaf(df, df, acc);
+        df = v.w - q[4 * c + 3]; acc = __builtin_fmaf(df, df, acc);
+    }
+    return acc;
 }
 
 // Exact R1 chain for the kept candidates of one query (32 lanes per query), top-k by (d, j), verification.
 template <int KP>
 __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
 {
-    constexpr int EMAX = 2 * kFilterMaxSplit * KP;       // entries per query at most
+    constexpr int M = filter_list_len(KP);
+    constexpr int MS = (M + 1 + 3) & ~3;
+    constexpr int EMAX = kFilterMaxSplit * M;            // entries per query at most
     constexpr int EL = (EMAX + 31) / 32;                 // entries per lane at most
     __shared__ float sc[8][EMAX];
     __shared__ int32_t sj[8][EMAX];
@@ -776,13 +894,13 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
     if (ft >= n_full) {
         nsub = split;
         const int64_t slot = (int64_t)(ft - n_full) * kFQ + (qq - ev_lo) % kFQ;
-        bd = a.psd + slot * nsub * 2 * KP;
-        bj = a.psj + slot * nsub * 2 * KP;
+        bd = a.psd + slot * nsub * MS;
+        bj = a.psj + slot * nsub * MS;
     } else {
-        bd = a.fd + qq * 2 * KP;
-        bj = a.fj + qq * 2 * KP;
+        bd = a.fd + qq * MS;
+        bj = a.fj + qq * MS;
     }
-    const int E = 2 * nsub * KP;
+    const int E = nsub * M;
 
     float qrow[32];
     {
@@ -793,30 +911,16 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
             qrow[4 * c] = v.x; qrow[4 * c + 1] = v.y; qrow[4 * c + 2] = v.z; qrow[4 * c + 3] = v.w;
         }
     }
-    float myc[EL], mykey[EL];
+    float myc[EL];
     int32_t myj[EL];
 #pragma unroll
     for (int t = 0; t < EL; ++t) {
         const int idx = l + 32 * t;
-        myc[t] = kKnnSentinel; mykey[t] = 0.0f; myj[t] = -1;
+        myc[t] = kKnnSentinel; myj[t] = -1;
         if (active && idx < E) {
-            const int32_t j = bj[idx];
-            mykey[t] = bd[idx];
+            const int32_t j = bj[(idx / M) * MS + (idx % M)];
             myj[t] = j;
-            if (j >= 0) {
-                const float4 *g = reinterpret_cast<const float4 *>(a.x + (int64_t)j * 32);
-                float acc = 0.0f;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float4 v = g[c];
-                    float df;
-                    df = v.x - qrow[4 * c + 0]; acc = __builtin_fmaf(df, df, acc);
-                    df = v.y - qrow[4 * c + 1]; acc = __builtin_fmaf(df, df, acc);
-                    df = v.z - qrow[4 * c + 2]; acc = __builtin_fmaf(df, df, acc);
-                    df = v.w - qrow[4 * c + 3]; acc = __builtin_fmaf(df, df, acc);
-                }
-                myc[t] = acc;
-            }
+            if (j >= 0) myc[t] = chain_dist32(a.x + (int64_t)j * 32, qrow);
             sc[hw][idx] = myc[t];
             sj[hw][idx] = (j >= 0) ? j : (0x7fffffff - idx);   // missing entries sort last, all distinct
         }
@@ -844,22 +948,19 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
         }
     }
     wave_sync();
-    // verification: every FULL list's largest kept key must put its dropped candidates beyond the k-th distance
+    // verification (one lane per partial list): a list that saw at least M keys dropped only keys >= its threshold
     bool fail = false;
-    if (active) {
+    if (active && l < nsub) {
+        const float tau = bd[l * MS + M];
+        const bool overflow = bj[l * MS + M] != 0;
         const float kth = skth[hw];
         const float nx = a.nrm[qq];
         const float ymax = __uint_as_float(a.evmax[ev]);
         const float sn = __builtin_sqrtf(nx) + __builtin_sqrtf(ymax);
         const float slack = kSlackRel * sn * sn + 1e-30f;
-#pragma unroll
-        for (int t = 0; t < EL; ++t) {
-            const int idx = l + 32 * t;
-            if (idx < E && (idx % KP) == KP - 1 && myj[t] >= 0) {
-                // kth < 0: fewer than k kept candidates although a list is full cannot happen (KP >= k)
-                if (!(mykey[t] + nx - slack > kth)) fail = true;
-            }
-        }
+        const bool full = tau < kKnnSentinel;
+        // kth < 0 (fewer than k kept candidates) cannot coincide with a full list (M >= k)
+        fail = overflow || (full && !(tau + nx - slack > kth));
     }
     if (fail) {
         const int xt = a.xtile_ptr[pos] + (int)((qq - ev_lo) / a.xtile_queries);
@@ -869,36 +970,22 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
 }
 
 // Uncertified queries of sparsely flagged tiles (1..kRequeryMax per 128-query tile; denser tiles go to the exact
-// tile kernel): one wavefront per query, lanes stride over the event's candidates with the exact R1 chain, then k
-// rounds of "smallest (d, j) above the previous pick" (R2).  Distances are cached in LDS when the event fits.
+// tile kernel): the tile's workgroup takes them one at a time, its 256 lanes stride over the event's candidates with
+// the exact R1 chain (distances cached in LDS when the event fits), then k rounds of "smallest (d, j) above the
+// previous pick" (R2) with a wavefront + cross-wavefront reduction.
 constexpr int kRequeryMax = 8;
-constexpr int kRequeryCache = 8192;   // floats per wavefront
-
-__device__ __forceinline__ float chain_dist32(const float *__restrict__ xj, const float (&q)[32])
-{
-    const float4 *g = reinterpret_cast<const float4 *>(xj);
-    float acc = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const float4 v = g[c];
-        float df;
-        df = v.x - q[4 * c + 0]; acc = __builtin_fmaf(df, df, acc);
-        df = v.y - q[4 * c + 1]; acc = __builtin_fmaf(df, df, acc);
-        df = v.z - q[4 * c + 2]; acc = __builtin_fmaf(df, df, acc);
-        df = v.w - q[4 * c + 3]; acc = __builtin_fmaf(df, df, acc);
-    }
-    return acc;
-}
+constexpr int kRequeryCache = 16384;   // floats
 
 __global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a, const KnnPlan *__restrict__ xplan)
 {
-    __shared__ float cache_all[4][kRequeryCache];
+    __shared__ float cache[kRequeryCache];
+    __shared__ float red_d[4];
+    __shared__ int red_j[4];
     const int tile = blockIdx.x;
     if (tile >= xplan->total_tiles) return;
     const int nflag = a.flags[tile];
     if (nflag == 0 || nflag > kRequeryMax) return;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *cache = cache_all[wv];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int pos = find_tile_event(a.xtile_ptr, a.B, tile);
     const int ev = a.order[pos];
     const int ev_lo = (int)a.ptr[ev], ev_hi = (int)a.ptr[ev + 1];
@@ -907,8 +994,8 @@ __global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a,
     const int q_end = min(ev_hi, q_first + a.xtile_queries);
     const bool cached = n <= kRequeryCache;
     const int k = a.k;
-    for (int q = q_first + wv; q < q_end; q += 4) {
-        if (a.qflag[q] == 0) continue;   // wave-uniform
+    for (int q = q_first; q < q_end; ++q) {
+        if (a.qflag[q] == 0) continue;   // block-uniform
         float qrow[32];
         {
             const float4 *g = reinterpret_cast<const float4 *>(a.x + (int64_t)q * 32);
@@ -918,17 +1005,17 @@ __global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a,
                 qrow[4 * c] = v.x; qrow[4 * c + 1] = v.y; qrow[4 * c + 2] = v.z; qrow[4 * c + 3] = v.w;
             }
         }
+        __syncthreads();   // previous query's cache / reduction slots are free
         if (cached) {
-            wave_sync();
-            for (int j = lane; j < n; j += kWave) cache[j] = chain_dist32(a.x + (int64_t)(ev_lo + j) * 32, qrow);
-            wave_sync();
+            for (int j = tid; j < n; j += 256) cache[j] = chain_dist32(a.x + (int64_t)(ev_lo + j) * 32, qrow);
+            __syncthreads();
         }
         float last_d = -1.0f;   // distances are >= 0
         int last_j = -1;
         for (int r = 0; r < k; ++r) {
             float bd = __builtin_inff();
             int bj = 0x7fffffff;
-            for (int j = lane; j < n; j += kWave) {
+            for (int j = tid; j < n; j += 256) {
                 const float d = cached ? cache[j] : chain_dist32(a.x + (int64_t)(ev_lo + j) * 32, qrow);
                 const int jj = ev_lo + j;
                 const bool after = d > last_d || (d == last_d && jj > last_j);
@@ -941,14 +1028,24 @@ __global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a,
                 const int oj = __shfl_xor(bj, off, 64);
                 if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
             }
-            const bool found = bj != 0x7fffffff;
-            if (lane == 0) {
+            if (lane == 0) { red_d[wv] = bd; red_j[wv] = bj; }
+            __syncthreads();
+            bd = red_d[0]; bj = red_j[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float od = red_d[w];
+                const int oj = red_j[w];
+                if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+            }
+            __syncthreads();
+            const bool found = bj != 0x7fffffff;   // block-uniform
+            if (tid == 0) {
                 a.nbr[(int64_t)q * k + r] = found ? bj : -1;
                 a.dist[(int64_t)q * k + r] = found ? bd : kKnnSentinel;
             }
             if (!found) {
-                for (int rr = r + 1; rr < k; ++rr)
-                    if (lane == 0) { a.nbr[(int64_t)q * k + rr] = -1; a.dist[(int64_t)q * k + rr] = kKnnSentinel; }
+                if (tid == 0)
+                    for (int rr = r + 1; rr < k; ++rr) { a.nbr[(int64_t)q * k + rr] = -1; a.dist[(int64_t)q * k + rr] = kKnnSentinel; }
                 break;
             }
             last_d = bd; last_j = bj;
@@ -1003,8 +1100,17 @@ inline KnnWorkspace carve_workspace(void *ws, int64_t N, int B, int KP)
     KnnWorkspace w;
     uintptr_t p = (reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u;
     auto take = [&](size_t nbytes) { uintptr_t r = p; p = (p + nbytes + 255u) & ~(uintptr_t)255u; return r; };
+    // query slots of split (tail) tiles: fewer than kMaxSimds tiles, and never more than all tiles hold
     size_t split_q = (size_t)kMaxSimds * 128;
-    if ((size_t)N + 128 < split_q) split_q = (size_t)N + 128;
+    if ((size_t)N + 128 * ((size_t)B + 1) < split_q) split_q = (size_t)N + 128 * ((size_t)B + 1);
+    // the filter's split tiles use the same arrays: [slots][kFilterMaxSplit][KP + KP/4 + pad]
+    size_t ps_elems = split_q * kMaxSplit * KP;
+    {
+        size_t fslots = (size_t)kMaxSimds * 2 * kFQ;
+        if ((size_t)N + kFQ * ((size_t)B + 1) < fslots) fslots = (size_t)N + kFQ * ((size_t)B + 1);
+        const size_t need = fslots * kFilterMaxSplit * (size_t)(2 * KP);
+        if (need > ps_elems) ps_elems = need;
+    }
     w.plan = reinterpret_cast<KnnPlan *>(take(sizeof(KnnPlan)));
     w.order = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
     w.pos_of = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
@@ -1012,8 +1118,8 @@ inline KnnWorkspace carve_workspace(void *ws, int64_t N, int B, int KP)
     // wsd/wsj double as the filter's [N][2][KP] key lists (the exact kernel runs after the re-rank consumed them)
     w.wsd = reinterpret_cast<float *>(take(sizeof(float) * (size_t)N * KP * 2));
     w.wsj = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)N * KP * 2));
-    w.psd = reinterpret_cast<float *>(take(sizeof(float) * split_q * kMaxSplit * KP));
-    w.psj = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * split_q * kMaxSplit * KP));
+    w.psd = reinterpret_cast<float *>(take(sizeof(float) * ps_elems));
+    w.psj = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ps_elems));
     w.fplan = reinterpret_cast<KnnPlan *>(take(sizeof(KnnPlan)));
     w.forder = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
     w.fpos_of = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
@@ -1055,7 +1161,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
 
     // matrix-core filter + exact re-rank for the hot shape (D = 32, k <= 32); the exact kernel then only recomputes
     // the tiles the re-rank could not certify
-    if constexpr (DP == 32 && KP <= 32) {
+    if constexpr (DP == 32 && KP <= 16) {
         if (D == 32 && aligned16(x) && filter_mode() != 0) {
             if (hipMemsetAsync(w.evmax, 0, w.zero_bytes, st) != hipSuccess) return hip_fail(hipGetLastError(), "memset");
             hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, x, ptr, B, N, w.nrm,
