@@ -510,9 +510,12 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const KnnArgs a, int til
 // v_mfma_f32_32x32x16_bf16 (exact bf16 products, fp32 accumulation): 6 MFMAs of 8 passes per 32x32 block instead of
 // 16 fp32 MFMAs of 16 passes (measured on MI355X, tools/mfma_valu_micro.hip: MFMA passes and VALU instructions of a
 // SIMD do NOT overlap, not even across wavefronts, so matrix-pipe time adds to the selection's VALU time).
-// Error budget per pair, relative to (|x_i| + |x_j|)^2: dropped terms 1.5 * 2^-18, fp32 accumulation and the norms
-// ~3 * 2^-18, the R1 chain itself 0.5 * 2^-18; e_i = kSlackRel * (|x_i| + max_j |x_j|)^2 with kSlackRel = 2^-13 keeps a
-// 4x margin, so  |d_chain(i,j) - (key(i,j) + |x_i|^2)| <= e_i  for every j of the event.
+// Error budget for a pair (a = |x_i|, b = |x_j|): dropped split terms 6.2 * 2^-18 a b, MFMA fp32 accumulation
+// (<= 100 roundings) 3.3 * 2^-18 a b + 6e-6 b^2, squared norms 1.9e-6 (a^2 + b^2), the R1 chain itself 2.1e-6 (a + b)^2:
+//   |d_chain(i,j) - (key(i,j) + |x_i|^2)|  <=  E(a, b) = 4e-5 a b + 1e-5 b^2 + 4e-6 a^2.
+// Certification only has to rule out dropped candidates that could beat the k-th kept distance d_k: such a candidate
+// has b <= R_i = a + sqrt(d_k) (otherwise d >= (b - a)^2 > d_k already), so the slack is e_i = 2 E(a, R_i) (2x margin)
+// and depends on the query alone -- an outlier with a huge norm elsewhere in the event does not loosen it.
 //   1. knn_filter_kernel: every query keeps, per partial list (two half-row lanes x candidate sub-sweeps), the KP
 //      smallest keys.
 //   2. knn_rerank_kernel: the exact R1 chain for the <= 2*split*KP kept candidates, top-k by (d, j) (R2).  It is THE
@@ -524,7 +527,6 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const KnnArgs a, int til
 // Result: bit-identical output at a fraction of the VALU work.
 constexpr int kFQ = 64;             // queries per filter work item: two 32-column MFMA blocks
 constexpr int kFilterMaxSplit = 2;  // tail balancing of the filter: at most 2 candidate sub-sweeps
-constexpr float kSlackRel = 1.220703125e-4f;   // 2^-13
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -537,7 +539,6 @@ struct KnnFilterArgs {
     int k;
     float *nrm;                 // [N] squared norms
     unsigned short *xs;         // [N][64] bf16 split of x: 32 high terms, then 32 middle terms
-    unsigned *evmax;            // [B] largest squared norm of the event (float bits; non-negative floats order as uints)
     float *fd;                  // [N][MS] kept keys of the whole-sweep lists (MS = M + threshold slot, padded)
     int32_t *fj;
     const KnnPlan *plan;        // filter plan (kFQ-query tiles)
@@ -562,11 +563,11 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float f)   // finite inputs
 
 __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__ x, const int64_t *__restrict__ ptr,
                                                         int B, int64_t N, float *__restrict__ nrm,
-                                                        unsigned short *__restrict__ xs, unsigned *__restrict__ evmax)
+                                                        unsigned short *__restrict__ xs)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < N;
-    if (!live) i = N - 1;                         // keep whole wavefronts for the shuffles below
+    if (!live) i = N - 1;
     const float4 *row = reinterpret_cast<const float4 *>(x + i * 32);
     uint2 *hi = reinterpret_cast<uint2 *>(xs + i * 64), *mid = hi + 8;
     float s = 0.0f;
@@ -588,17 +589,6 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__
         }
     }
     if (live) nrm[i] = s;
-    // one atomic per (wavefront, event): max is order-independent, hence deterministic
-    const int b = find_event(ptr, B, i);
-    const int b0 = __shfl(b, 0, 64);
-    if (__all(b == b0)) {
-        float m = s;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-        if ((threadIdx.x & 63) == 0) atomicMax(evmax + b0, __float_as_uint(m));
-    } else {
-        atomicMax(evmax + b, __float_as_uint(s));
-    }
 }
 
 // One 32(candidates) x 32(queries) block: acc = cinit + sum over both 16-feature k-blocks of  h.h' + h.m' + m.h'.
@@ -955,9 +945,9 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
         const bool overflow = bj[l * MS + M] != 0;
         const float kth = skth[hw];
         const float nx = a.nrm[qq];
-        const float ymax = __uint_as_float(a.evmax[ev]);
-        const float sn = __builtin_sqrtf(nx) + __builtin_sqrtf(ymax);
-        const float slack = kSlackRel * sn * sn + 1e-30f;
+        const float an = __builtin_sqrtf(nx) * 1.000001f;
+        const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
+        const float slack = 2.0f * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1e-30f;
         const bool full = tau < kKnnSentinel;
         // kth < 0 (fewer than k kept candidates) cannot coincide with a full list (M >= k)
         fail = overflow || (full && !(tau + nx - slack > kth));
@@ -1086,8 +1076,7 @@ struct KnnWorkspace {
     int32_t *ftile_ptr;
     float *nrm;
     unsigned short *xs;
-    unsigned *evmax;      // evmax[B] and flags[...] are one zero-filled region
-    int32_t *flags;
+    int32_t *flags;       // flags[...] and qflag[N] are one zero-filled region
     uint8_t *qflag;
     size_t zero_bytes;
     size_t bytes;
@@ -1126,9 +1115,8 @@ inline KnnWorkspace carve_workspace(void *ws, int64_t N, int B, int KP)
     w.ftile_ptr = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
     w.nrm = reinterpret_cast<float *>(take(sizeof(float) * (size_t)N));
     w.xs = reinterpret_cast<unsigned short *>(take(sizeof(unsigned short) * (size_t)N * 64));
-    w.zero_bytes = sizeof(unsigned) * ((size_t)B + 1) + sizeof(int32_t) * (size_t)exact_tiles_max(N, B) + (size_t)N;
-    w.evmax = reinterpret_cast<unsigned *>(take(w.zero_bytes));
-    w.flags = reinterpret_cast<int32_t *>(w.evmax + B + 1);
+    w.zero_bytes = sizeof(int32_t) * (size_t)exact_tiles_max(N, B) + (size_t)N;
+    w.flags = reinterpret_cast<int32_t *>(take(w.zero_bytes));
     w.qflag = reinterpret_cast<uint8_t *>(w.flags + exact_tiles_max(N, B));
     w.bytes = (size_t)(p - reinterpret_cast<uintptr_t>(ws));
     return w;
@@ -1163,15 +1151,15 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     // the tiles the re-rank could not certify
     if constexpr (DP == 32 && KP <= 16) {
         if (D == 32 && aligned16(x) && filter_mode() != 0) {
-            if (hipMemsetAsync(w.evmax, 0, w.zero_bytes, st) != hipSuccess) return hip_fail(hipGetLastError(), "memset");
+            if (hipMemsetAsync(w.flags, 0, w.zero_bytes, st) != hipSuccess) return hip_fail(hipGetLastError(), "memset");
             hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, x, ptr, B, N, w.nrm,
-                               w.xs, w.evmax);
+                               w.xs);
             DMET_LAUNCH_CHECK("knn_prep_kernel");
             const int slots = simds * 2;   // two filter wavefronts per SIMD
             hipLaunchKernelGGL(knn_plan_kernel, dim3(1), dim3(256), 0, st, ptr, B, kFQ, slots, kFilterMaxSplit, w.forder,
                                w.fpos_of, w.ftile_ptr, w.fplan);
             DMET_LAUNCH_CHECK("knn_plan_kernel");
-            KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.xs, w.evmax, w.wsd, w.wsj, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
+            KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.xs, w.wsd, w.wsj, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
                             w.psd, w.psj, nbr, dist, w.flags, w.qflag, w.tile_ptr, QT};
             const int64_t ftiles_max = (N + kFQ - 1) / kFQ + B;
             const int64_t fblocks = (ftiles_max + slots + kWavesPerGroup - 1) / kWavesPerGroup;
