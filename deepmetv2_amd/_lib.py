@@ -24,7 +24,7 @@ SIGNATURES = {
     "dmet_device_available": (_i, []),
     "dmet_knn_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
     "dmet_knn_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
-    "dmet_knn_flagged_tiles": (_i64, [_vp, _i64, _i, _i, _i, _vp]),
+    "dmet_knn_fallback_stats": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
     "dmet_radius_f32": (_i, [_vp, _vp, _i, _i64, _i, _f, _i, _vp, _vp, _vp]),
     "dmet_edgeconv_linear_workspace_bytes": (_sz, [_i64, _i]),
     "dmet_edgeconv_linear_max_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

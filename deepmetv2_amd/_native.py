@@ -99,7 +99,8 @@ GATHER_MAX_FORM = os.environ.get("DMET_GATHER_MAX_FORM", "auto")
 # ---- K1 ------------------------------------------------------------------------------------------------------
 def knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """nbr[N,k] int32 (global ids, -1 padded), dist[N,k] fp32.  With a `stats` dict the call synchronises and stores
-    stats['flagged_tiles'] (128-query tiles the matrix-core path handed to the exact kernel; diagnostics only)."""
+    stats['flagged_tiles'] / stats['flagged_queries'] (what the matrix-core path could not certify and recomputed
+    exactly; diagnostics only)."""
     dev = _require_device(x, ptr)
     L = _lib.load()
     x = _f32c(x.detach(), "x")
@@ -119,7 +120,11 @@ def knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict] = None
         _t.record(torch.cuda.current_stream(dev))
     if stats is not None and N > 0 and B > 0:
         with torch.cuda.device(dev):
-            stats["flagged_tiles"] = int(L.dmet_knn_flagged_tiles(ws.data_ptr(), N, B, D, k, _stream(dev)))
+            import ctypes
+            out = (ctypes.c_int64 * 2)()
+            _lib.check(L.dmet_knn_fallback_stats(ws.data_ptr(), N, B, D, k, ctypes.cast(out, ctypes.c_void_p),
+                                                 _stream(dev)), "dmet_knn_fallback_stats")
+            stats["flagged_tiles"], stats["flagged_queries"] = int(out[0]), int(out[1])
             stats["tiles"] = (N + 127) // 128
     return nbr, dist
 

@@ -1126,12 +1126,8 @@ inline KnnWorkspace carve_workspace(void *ws, int64_t N, int B, int KP)
 // of uncertified tiles (diagnostics: output may then be wrong); anything else: filter when eligible + fallback
 inline int filter_mode()
 {
-    static int cached = -1;
-    if (cached < 0) {
-        const char *e = getenv("DMET_KNN_PATH");
-        cached = (e && strcmp(e, "exact") == 0) ? 0 : (e && strcmp(e, "filter_only") == 0) ? 2 : 1;
-    }
-    return cached;
+    const char *e = getenv("DMET_KNN_PATH");   // read per call: tests switch paths inside one process
+    return (e && strcmp(e, "exact") == 0) ? 0 : (e && strcmp(e, "filter_only") == 0) ? 2 : 1;
 }
 
 template <int DP, int KP>
@@ -1146,12 +1142,13 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
                        w.tile_ptr, w.plan);
     DMET_LAUNCH_CHECK("knn_plan_kernel");
     KnnArgs a{x, ptr, B, N, D, k, nbr, dist, w.wsd, w.wsj, w.plan, w.order, w.tile_ptr, w.psd, w.psj, nullptr, 0};
+    // uncertified-query counters: zero for every call, so dmet_knn_fallback_stats is meaningful on any path
+    if (hipMemsetAsync(w.flags, 0, w.zero_bytes, st) != hipSuccess) return hip_fail(hipGetLastError(), "hipMemsetAsync");
 
     // matrix-core filter + exact re-rank for the hot shape (D = 32, k <= 32); the exact kernel then only recomputes
     // the tiles the re-rank could not certify
     if constexpr (DP == 32 && KP <= 16) {
         if (D == 32 && aligned16(x) && filter_mode() != 0) {
-            if (hipMemsetAsync(w.flags, 0, w.zero_bytes, st) != hipSuccess) return hip_fail(hipGetLastError(), "memset");
             hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, x, ptr, B, N, w.nrm,
                                w.xs);
             DMET_LAUNCH_CHECK("knn_prep_kernel");
@@ -1291,23 +1288,22 @@ extern "C" int dmet_knn_f32(const float *x, const int64_t *ptr, int B, int64_t N
     return dispatch_k<64>(x, ptr, B, N, D, k, nbr, dist, ws, st);
 }
 
-extern "C" int64_t dmet_knn_flagged_tiles(const void *ws, int64_t N, int B, int D, int k, dmet_stream_t stream)
+extern "C" int dmet_knn_fallback_stats(const void *ws, int64_t N, int B, int D, int k, int64_t *out, dmet_stream_t stream)
 {
     (void)D;
-    if (N <= 0 || B <= 0 || k < 1 || k > DMET_MAX_K || !ws) return -1;
+    DMET_REQUIRE(N > 0 && B > 0 && k >= 1 && k <= DMET_MAX_K && ws && out, "dmet_knn_fallback_stats: bad arguments");
     const KnnWorkspace w = carve_workspace(const_cast<void *>(ws), N, B, padded_k(k));
     const int64_t n = exact_tiles_max(N, B);
     int32_t *host = static_cast<int32_t *>(malloc(sizeof(int32_t) * (size_t)n));
-    if (!host) return -1;
+    DMET_REQUIRE(host != nullptr, "dmet_knn_fallback_stats: out of host memory");
     hipStream_t st = as_stream(stream);
-    int64_t count = -1;
-    if (hipMemcpyAsync(host, w.flags, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st) == hipSuccess &&
-        hipStreamSynchronize(st) == hipSuccess) {
-        count = 0;
-        for (int64_t i = 0; i < n; ++i) count += host[i] != 0;
-    }
+    hipError_t e = hipMemcpyAsync(host, w.flags, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { free(host); return hip_fail(e, "dmet_knn_fallback_stats"); }
+    out[0] = 0; out[1] = 0;
+    for (int64_t i = 0; i < n; ++i) { out[0] += host[i] != 0; out[1] += host[i]; }
     free(host);
-    return count;
+    return 0;
 }
 
 extern "C" int dmet_radius_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr,

@@ -54,12 +54,13 @@ size_t dmet_knn_workspace_bytes(int64_t N, int B, int D, int k);
 int dmet_knn_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,
                  float *dist, void *ws, size_t ws_bytes, dmet_stream_t stream);
 
-/* Diagnostics of the matrix-core kNN path (D = 32, k <= 32): dmet_knn_f32 first ranks candidates with a fp32-MFMA
- * filter, re-ranks the kept ones with the exact R1 chain and certifies every query; 128-query tiles holding an
- * uncertified query are recomputed by the exact VALU kernel.  This returns how many tiles the LAST dmet_knn_f32 call
- * on this workspace flagged for recomputation (synchronises the stream; -1 on error; 0 when the exact kernel ran
- * alone).  Environment: DMET_KNN_PATH=exact forces the exact kernel for everything. */
-int64_t dmet_knn_flagged_tiles(const void *ws, int64_t N, int B, int D, int k, dmet_stream_t stream);
+/* Diagnostics of the matrix-core kNN path (D = 32, k <= 16): dmet_knn_f32 first ranks candidates with a bf16-split
+ * MFMA filter, re-ranks the kept ones with the exact R1 chain and certifies every query; uncertified queries are
+ * recomputed exactly (one at a time when their 128-query tile has at most 8 of them, by the exact tile kernel
+ * otherwise).  For the LAST dmet_knn_f32 call on this workspace: out[0] = tiles holding an uncertified query,
+ * out[1] = uncertified queries (both 0 when the exact kernel ran alone).  Synchronises the stream.
+ * Environment: DMET_KNN_PATH=exact forces the exact kernel for everything. */
+int dmet_knn_fallback_stats(const void *ws, int64_t N, int B, int D, int k, int64_t *out, dmet_stream_t stream);
 
 /* ---- N1: radius graph build ----------------------------------------------------------------------
  * replaces torch_cluster.radius_graph   call sites: train.py:48, evaluate.py:88, plt_weight.py:122

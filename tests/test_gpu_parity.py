@@ -92,6 +92,86 @@ def test_knn_ragged_config5_full_size(dev):
         assert torch.equal(nbr[s:e], ref + s) and torch.equal(dist[s:e], dref)
 
 
+def _knn_with_stats(x, ptr, k):
+    from deepmetv2_amd import _native
+    st = {}
+    nbr, dist = _native.knn(x, ptr, k, stats=st)
+    return nbr.cpu(), dist.cpu(), st
+
+
+@pytest.mark.parametrize("case", ["gaussian", "outliers", "clusters", "identical", "lattice", "tiny_events"])
+def test_knn_matrix_core_path_certification(dev, case):
+    """K1, D = 32: the matrix-core filter + exact re-rank must return the oracle's bits on benign data WITHOUT falling
+    back (flagged_tiles == 0), and on adversarial data (mass ties) through the certified fallback."""
+    from oracle import ref_ops
+    g = torch.Generator().manual_seed(7)
+    k = 16
+    if case == "tiny_events":
+        sizes = [int(v) for v in torch.randint(0, 9, (700,), generator=g)]       # many events smaller than k, some empty
+    else:
+        sizes = [900, 37, 1500]
+    N = sum(sizes)
+    x = torch.randn(N, 32, generator=g)
+    if case == "outliers":
+        x[::97] *= 300.0                              # huge norms elsewhere in the event must not loosen the bound
+    elif case == "clusters":
+        centers = torch.randn(12, 32, generator=g) * 4
+        x = centers[torch.randint(0, 12, (N,), generator=g)] + 1e-3 * torch.randn(N, 32, generator=g)
+    elif case == "identical":
+        x = torch.ones(N, 32) * 0.37                  # every distance ties: nothing can be certified
+    elif case == "lattice":
+        x = torch.round(x)                            # integer coordinates: many exact ties at the k-th distance
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.tensor(sizes).cumsum(0)])
+    nbr_ref, dist_ref = ref_ops.knn_table(x, ptr, k)
+    nbr, dist, st = _knn_with_stats(x.to(dev), ptr.to(dev), k)
+    assert torch.equal(nbr, nbr_ref) and torch.equal(dist, dist_ref)
+    if case == "gaussian":
+        assert st["flagged_queries"] == 0, st
+    if case == "outliers":    # only the outlier queries themselves (1 in 97) may be beyond bf16-split certification
+        assert st["flagged_queries"] <= N // 97 + 1, st
+    if case == "identical":
+        assert st["flagged_tiles"] > 0, st            # the fallback really ran
+
+
+def test_knn_matrix_core_vs_exact_kernel_full_size(dev, monkeypatch):
+    """BASELINE configs[1] shape (64 x 4500 x 32, k = 16): filter path == oracle on two events and structurally sound
+    on all; flagged tiles stay rare on generic data."""
+    from oracle import ref_ops
+    g = torch.Generator().manual_seed(123)
+    B, n, k = 64, 4500, 16
+    x = torch.randn(B * n, 32, generator=g)
+    ptr = torch.arange(0, (B + 1) * n, n, dtype=torch.int64)
+    nbr, dist, st = _knn_with_stats(x.to(dev), ptr.to(dev), k)
+    assert st["flagged_tiles"] <= 8, st
+    for b in (0, 63):
+        ref, dref = ref_ops.knn_table(x[b * n:(b + 1) * n], torch.tensor([0, n]), k)
+        assert torch.equal(nbr[b * n:(b + 1) * n], ref + b * n) and torch.equal(dist[b * n:(b + 1) * n], dref)
+    assert torch.equal(nbr[:, 0], torch.arange(B * n, dtype=torch.int32))
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all())
+    ev = torch.arange(B * n).view(-1, 1) // n
+    assert bool(((nbr // n) == ev).all())
+
+
+def test_knn_oversized_event_goes_to_exact_kernel(dev, monkeypatch):
+    """An event of more than 65535 nodes does not fit the filter's 16-bit candidate ids: every query of it must be
+    handed to the exact kernel (and a normal event next to it still takes the matrix-core path).  Reference: the
+    exact kernel alone (DMET_KNN_PATH=exact; itself pinned to the oracle by test_knn_bit_exact), oracle on the small
+    event."""
+    from oracle import ref_ops
+    g = torch.Generator().manual_seed(5)
+    sizes = [66000, 700]
+    x = torch.randn(sum(sizes), 32, generator=g)
+    ptr = torch.tensor([0, 66000, 66700])
+    nbr, dist, st = _knn_with_stats(x.to(dev), ptr.to(dev), 16)
+    assert st["flagged_queries"] >= 66000 and st["flagged_queries"] < 66000 + 16, st
+    monkeypatch.setenv("DMET_KNN_PATH", "exact")
+    nbr_x, dist_x, st_x = _knn_with_stats(x.to(dev), ptr.to(dev), 16)
+    assert st_x["flagged_queries"] == 0
+    assert torch.equal(nbr, nbr_x) and torch.equal(dist, dist_x)
+    ref, dref = ref_ops.knn_table(x[66000:], torch.tensor([0, 700]), 16)
+    assert torch.equal(nbr[66000:], ref + 66000) and torch.equal(dist[66000:], dref)
+
+
 def test_radius_graph(dev):
     import deepmetv2_amd as dm
     from oracle import ref_ops
