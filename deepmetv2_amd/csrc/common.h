@@ -45,6 +45,17 @@ __device__ __forceinline__ int find_event(const int64_t *__restrict__ ptr, int B
     return lo;
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): remap so that the workgroups of one XCD
+// cover one contiguous chunk of the grid (rows an event shares then stay in one L2).
+__device__ __forceinline__ int xcd_swizzle(int bid, int nblk)
+{
+    // bijective remap: blocks sharing an XCD (bid % 8) get one contiguous chunk of the grid
+    const int q = nblk / kNumXcd, rm = nblk % kNumXcd;
+    const int xcd = bid % kNumXcd, idx = bid / kNumXcd;
+    const int base = (xcd < rm) ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q;
+    return base + idx;
+}
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll

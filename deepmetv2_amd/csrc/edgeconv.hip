@@ -20,16 +20,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ int xcd_swizzle(int bid, int nblk)
-{
-    // bijective remap: blocks sharing an XCD (bid % 8) get one contiguous chunk of the grid
-    const int q = nblk / kNumXcd, rm = nblk % kNumXcd;
-    const int xcd = bid % kNumXcd, idx = bid / kNumXcd;
-    const int base = (xcd < rm) ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q;
-    return base + idx;
-}
-
-
 // ---------------------------------------------------------------------------------------------------------
 // node_linear_split: one wavefront computes [32 nodes] x [HOUT] for both P and Q with 32x32x2 fp32 MFMAs.
 // MFMA operand maps (32x32x2): lane l holds A[row l&31][k l>>5], B[k l>>5][col l&31];

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const KnnArgs a, int til
 //      one wavefront per query when a 128-query tile has few of them, the exact tile kernel above otherwise.
 // Result: bit-identical output at a fraction of the VALU work.
 constexpr int kFQ = 64;             // queries per filter work item: two 32-column MFMA blocks
-constexpr int kFilterMaxSplit = 2;  // tail balancing of the filter: at most 2 candidate sub-sweeps
+constexpr int kFilterMaxSplit = 2;  // tail balancing of the filter: at most 2 candidate sub-sweeps (the re-rank assumes 2)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -561,34 +561,32 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float f)   // finite inputs
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
-__global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__ x, const int64_t *__restrict__ ptr,
-                                                        int B, int64_t N, float *__restrict__ nrm,
+// Squared norms and the bf16 split of x: 8 lanes per row (one float4 each), so loads and stores are contiguous.
+__global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__ x, int64_t N, float *__restrict__ nrm,
                                                         unsigned short *__restrict__ xs)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < N;
-    if (!live) i = N - 1;
-    const float4 *row = reinterpret_cast<const float4 *>(x + i * 32);
-    uint2 *hi = reinterpret_cast<uint2 *>(xs + i * 64), *mid = hi + 8;
-    float s = 0.0f;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = t >> 3;
+    const int part = (int)(t & 7);
+    const bool live = row < N;
+    const int64_t r = live ? row : N - 1;
+    const float4 v = reinterpret_cast<const float4 *>(x + r * 32)[part];
+    float s = v.x * v.x;
+    s = __builtin_fmaf(v.y, v.y, s); s = __builtin_fmaf(v.z, v.z, s); s = __builtin_fmaf(v.w, v.w, s);
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);   // fixed order: deterministic
+    const float f[4] = {v.x, v.y, v.z, v.w};
+    unsigned h[4], m[4];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const float4 v = row[c];
-        s = __builtin_fmaf(v.x, v.x, s); s = __builtin_fmaf(v.y, v.y, s);
-        s = __builtin_fmaf(v.z, v.z, s); s = __builtin_fmaf(v.w, v.w, s);
-        const float f[4] = {v.x, v.y, v.z, v.w};
-        unsigned h[4], m[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            h[u] = bf16_rne_bits(f[u]);
-            m[u] = bf16_rne_bits(f[u] - __uint_as_float(h[u] << 16));   // the subtraction is exact
-        }
-        if (live) {
-            hi[c] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-            mid[c] = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-        }
+    for (int u = 0; u < 4; ++u) {
+        h[u] = bf16_rne_bits(f[u]);
+        m[u] = bf16_rne_bits(f[u] - __uint_as_float(h[u] << 16));   // the subtraction is exact
     }
-    if (live) nrm[i] = s;
+    if (live) {
+        uint2 *dst = reinterpret_cast<uint2 *>(xs + r * 64);
+        dst[part] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        dst[8 + part] = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+        if (part == 0) nrm[r] = s;
+    }
 }
 
 // One 32(candidates) x 32(queries) block: acc = cinit + sum over both 16-feature k-blocks of  h.h' + h.m' + m.h'.
@@ -858,101 +856,132 @@ __device__ __forceinline__ float chain_dist32(const float *__restrict__ xj, cons
     return acc;
 }
 
-// Exact R1 chain for the kept candidates of one query (32 lanes per query), top-k by (d, j), verification.
+// Exact R1 chain for the kept candidates of one query, top-k by (d, j), certification.  M lanes per query (one kept
+// candidate each; split tiles take a second round), 64 / M queries per wavefront; workgroups of one XCD walk one
+// contiguous range of queries so the candidate rows they gather stay in that XCD's L2.
 template <int KP>
 __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
 {
     constexpr int M = filter_list_len(KP);
     constexpr int MS = (M + 1 + 3) & ~3;
+    constexpr int QPW = kWave / M;                       // queries per wavefront (3 for M = 20)
+    constexpr int QPB = 4 * QPW;                         // per workgroup
     constexpr int EMAX = kFilterMaxSplit * M;            // entries per query at most
-    constexpr int EL = (EMAX + 31) / 32;                 // entries per lane at most
-    __shared__ float sc[8][EMAX];
-    __shared__ int32_t sj[8][EMAX];
-    __shared__ float skth[8];
-    const int hw = threadIdx.x >> 5, l = threadIdx.x & 31;
-    const int64_t q = (int64_t)blockIdx.x * 8 + hw;
-    const bool active = q < a.N;
-    const int64_t qq = active ? q : 0;
-    const int ev = find_event(a.ptr, a.B, qq);
-    const int pos = a.pos_of[ev];
-    const int64_t ev_lo = a.ptr[ev];
+    __shared__ float sc[QPB][EMAX];
+    __shared__ int32_t sj[QPB][EMAX];
+    __shared__ float skth[QPB];
+    __shared__ int sfail[QPB];
+    __shared__ float qbuf[QPB][32];
+    constexpr int PARTS = (kFQ + QPB - 1) / QPB;         // workgroups per 64-query filter tile
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qw = lane / M, l = lane - qw * M;          // query slot of the wavefront, lane within the query
+    const int slot = wv * QPW + min(qw, QPW - 1);
+    // workgroup -> (filter tile, part): the event lookup is per workgroup (wave-uniform: scalar loads), not per lane
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int ft = bid / PARTS, part = bid - ft * PARTS;
+    if (ft >= a.plan->total_tiles) return;
+    const int pos = find_tile_event(a.tile_ptr, a.B, ft);
+    const int ev = a.order[pos];
+    const int64_t ev_lo = a.ptr[ev], ev_hi = a.ptr[ev + 1];
+    const int qoff = part * QPB + wv * QPW + qw;         // query within the tile
+    const int64_t q = ev_lo + (int64_t)(ft - a.tile_ptr[pos]) * kFQ + qoff;
+    const bool active = qw < QPW && qoff < kFQ && q < ev_hi;
+    const int64_t qq = active ? q : ev_lo;
     const int n_full = a.plan->n_full, split = a.plan->split;
-    const int ft = a.tile_ptr[pos] + (int)((qq - ev_lo) / kFQ);
     int nsub = 1;
     const float *bd;
     const int32_t *bj;
     if (ft >= n_full) {
         nsub = split;
-        const int64_t slot = (int64_t)(ft - n_full) * kFQ + (qq - ev_lo) % kFQ;
-        bd = a.psd + slot * nsub * MS;
-        bj = a.psj + slot * nsub * MS;
+        const int64_t fslot = (int64_t)(ft - n_full) * kFQ + (active ? qoff : 0);
+        bd = a.psd + fslot * nsub * MS;
+        bj = a.psj + fslot * nsub * MS;
     } else {
         bd = a.fd + qq * MS;
         bj = a.fj + qq * MS;
     }
     const int E = nsub * M;
 
-    float qrow[32];
-    {
-        const float4 *g = reinterpret_cast<const float4 *>(a.x + qq * 32);
+    // issue every independent load up front: the kernel is bound by its chain of dependent memory round trips
+    int32_t myj[kFilterMaxSplit];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float4 v = g[c];
-            qrow[4 * c] = v.x; qrow[4 * c + 1] = v.y; qrow[4 * c + 2] = v.z; qrow[4 * c + 3] = v.w;
-        }
+    for (int t = 0; t < kFilterMaxSplit; ++t) myj[t] = (active && t < nsub) ? bj[t * MS + l] : -1;
+    float vtau = kKnnSentinel, vnx = 0.0f;
+    bool voverflow = false;
+    if (active && l < nsub) { vtau = bd[l * MS + M]; voverflow = bj[l * MS + M] != 0; vnx = a.nrm[qq]; }
+    // the wavefront's query rows go through LDS (read back as broadcasts): 32 fewer VGPRs, twice the resident waves
+    if (lane < QPW * 8) {
+        const int w = lane >> 3;
+        const int64_t qrow_id = min(ev_lo + (int64_t)(ft - a.tile_ptr[pos]) * kFQ + part * QPB + wv * QPW + w, ev_hi - 1);
+        *reinterpret_cast<float4 *>(&qbuf[wv * QPW + w][4 * (lane & 7)]) =
+            reinterpret_cast<const float4 *>(a.x + qrow_id * 32)[lane & 7];
     }
-    float myc[EL];
-    int32_t myj[EL];
+    float myc[kFilterMaxSplit];
+    wave_sync();
+#pragma unroll 1
+    for (int t = 0; t < kFilterMaxSplit; ++t) {
+        float ct = kKnnSentinel;
+        const int32_t j = (t == 0) ? myj[0] : myj[kFilterMaxSplit - 1];
+        if (active && t < nsub) {
+            const int idx = t * M + l;
+            if (j >= 0) {
+                const float4 *g = reinterpret_cast<const float4 *>(a.x + (int64_t)j * 32);
+                float4 crow[8];
 #pragma unroll
-    for (int t = 0; t < EL; ++t) {
-        const int idx = l + 32 * t;
-        myc[t] = kKnnSentinel; myj[t] = -1;
-        if (active && idx < E) {
-            const int32_t j = bj[(idx / M) * MS + (idx % M)];
-            myj[t] = j;
-            if (j >= 0) myc[t] = chain_dist32(a.x + (int64_t)j * 32, qrow);
-            sc[hw][idx] = myc[t];
-            sj[hw][idx] = (j >= 0) ? j : (0x7fffffff - idx);   // missing entries sort last, all distinct
+                for (int c = 0; c < 8; ++c) crow[c] = g[c];
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float4 v = crow[c];
+                    const float4 qv = *reinterpret_cast<const float4 *>(&qbuf[slot][4 * c]);
+                    float df;
+                    df = v.x - qv.x; acc = __builtin_fmaf(df, df, acc);
+                    df = v.y - qv.y; acc = __builtin_fmaf(df, df, acc);
+                    df = v.z - qv.z; acc = __builtin_fmaf(df, df, acc);
+                    df = v.w - qv.w; acc = __builtin_fmaf(df, df, acc);
+                }
+                ct = acc;
+            }
+            sc[slot][idx] = ct;
+            sj[slot][idx] = (j >= 0) ? j : (0x7fffffff - idx);   // missing entries sort last, all distinct
         }
+        if (t == 0) myc[0] = ct; else myc[kFilterMaxSplit - 1] = ct;
     }
-    if (l == 0) skth[hw] = -1.0f;
+    if (active && l == 0) { skth[slot] = -1.0f; sfail[slot] = 0; }
     wave_sync();
     const int k = a.k;
 #pragma unroll
-    for (int t = 0; t < EL; ++t) {
-        const int idx = l + 32 * t;
-        if (active && idx < E) {
+    for (int t = 0; t < kFilterMaxSplit; ++t) {
+        if (active && t < nsub) {
+            const int idx = t * M + l;
             const float c = myc[t];
             const int32_t jj = (myj[t] >= 0) ? myj[t] : (0x7fffffff - idx);
             int rank = 0;
             for (int e = 0; e < E; ++e) {
-                const float ce = sc[hw][e];
-                const int32_t je = sj[hw][e];
+                const float ce = sc[slot][e];
+                const int32_t je = sj[slot][e];
                 rank += (ce < c || (ce == c && je < jj)) ? 1 : 0;
             }
             if (rank < k) {
                 a.nbr[q * k + rank] = myj[t];
                 a.dist[q * k + rank] = (myj[t] >= 0) ? c : kKnnSentinel;
-                if (rank == k - 1 && myj[t] >= 0) skth[hw] = c;
+                if (rank == k - 1 && myj[t] >= 0) skth[slot] = c;
             }
         }
     }
     wave_sync();
-    // verification (one lane per partial list): a list that saw at least M keys dropped only keys >= its threshold
-    bool fail = false;
+    // certification (one lane per partial list): a list that saw at least M keys dropped only keys >= its threshold
     if (active && l < nsub) {
-        const float tau = bd[l * MS + M];
-        const bool overflow = bj[l * MS + M] != 0;
-        const float kth = skth[hw];
-        const float nx = a.nrm[qq];
-        const float an = __builtin_sqrtf(nx) * 1.000001f;
+        const float kth = skth[slot];
+        const float an = __builtin_sqrtf(vnx) * 1.000001f;
         const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
         const float slack = 2.0f * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1e-30f;
-        const bool full = tau < kKnnSentinel;
+        const bool full = vtau < kKnnSentinel;
         // kth < 0 (fewer than k kept candidates) cannot coincide with a full list (M >= k)
-        fail = overflow || (full && !(tau + nx - slack > kth));
+        if (voverflow || (full && !(vtau + vnx - slack > kth))) sfail[slot] = 1;
     }
-    if (fail) {
+    wave_sync();
+    if (active && l == 0 && sfail[slot] != 0) {      // count the query once
         const int xt = a.xtile_ptr[pos] + (int)((qq - ev_lo) / a.xtile_queries);
         a.qflag[qq] = 1;
         atomicAdd(a.flags + xt, 1);   // a count: order-independent
@@ -1149,8 +1178,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     // the tiles the re-rank could not certify
     if constexpr (DP == 32 && KP <= 16) {
         if (D == 32 && aligned16(x) && filter_mode() != 0) {
-            hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, x, ptr, B, N, w.nrm,
-                               w.xs);
+            hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((N * 8 + 255) / 256)), dim3(256), 0, st, x, N, w.nrm, w.xs);
             DMET_LAUNCH_CHECK("knn_prep_kernel");
             const int slots = simds * 2;   // two filter wavefronts per SIMD
             hipLaunchKernelGGL(knn_plan_kernel, dim3(1), dim3(256), 0, st, ptr, B, kFQ, slots, kFilterMaxSplit, w.forder,
@@ -1162,7 +1190,9 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
             const int64_t fblocks = (ftiles_max + slots + kWavesPerGroup - 1) / kWavesPerGroup;
             hipLaunchKernelGGL((knn_filter_kernel<KP>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
             DMET_LAUNCH_CHECK("knn_filter_kernel");
-            hipLaunchKernelGGL((knn_rerank_kernel<KP>), dim3((unsigned)((N + 7) / 8)), dim3(256), 0, st, f);
+            constexpr int kRerankQpb = 4 * (kWave / filter_list_len(KP));
+            constexpr int kRerankParts = (kFQ + kRerankQpb - 1) / kRerankQpb;
+            hipLaunchKernelGGL((knn_rerank_kernel<KP>), dim3((unsigned)(ftiles_max * kRerankParts)), dim3(256), 0, st, f);
             DMET_LAUNCH_CHECK("knn_rerank_kernel");
             if (filter_mode() == 2) return 0;
             const int64_t xtiles_max = (N + QT - 1) / QT + B;
