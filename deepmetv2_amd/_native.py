@@ -509,3 +509,47 @@ def encode_bwd(x_cont: torch.Tensor, x_cat: torch.Tensor, params, h: torch.Tenso
                                          h.data_ptr(), g_h.data_ptr(), *[g.data_ptr() for g in grads], ws.data_ptr(),
                                          ws.numel(), _stream(dev)), "dmet_encode_bwd_f32")
     return grads
+
+
+def bn_fwd(x: torch.Tensor, residual: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+           momentum: float, running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], training: bool):
+    """BatchNorm1d over rows (+ residual): returns (y, save_mean, save_invstd); running stats updated in place."""
+    dev = _require_device(x, gamma, beta)
+    L = _lib.load()
+    x = _f32c(x, "x")
+    N, H = x.shape
+    if residual is not None:
+        residual = _f32c(residual, "residual")
+        if residual.shape != x.shape:
+            raise ValueError("bn_fwd: residual must have the shape of x")
+    for t in (running_mean, running_var):
+        if t is not None and (not t.is_contiguous() or t.dtype != torch.float32 or t.numel() != H):
+            raise ValueError("bn_fwd: running statistics must be contiguous float32 [H]")
+    gamma = _f32c(gamma, "gamma"); beta = _f32c(beta, "beta")
+    y = torch.empty_like(x)
+    stats = torch.empty((2, H), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _ws(L.dmet_bn_workspace_bytes(N, H), dev)
+        _lib.check(L.dmet_bn_fwd_f32(x.data_ptr(), residual.data_ptr() if residual is not None else None, N, H,
+                                     gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum),
+                                     running_mean.data_ptr() if running_mean is not None else None,
+                                     running_var.data_ptr() if running_var is not None else None,
+                                     1 if training else 0, y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                                     ws.data_ptr(), ws.numel(), _stream(dev)), "dmet_bn_fwd_f32")
+    return y, stats[0], stats[1]
+
+
+def bn_bwd(x: torch.Tensor, g_y: torch.Tensor, gamma: torch.Tensor, save_mean: torch.Tensor, save_invstd: torch.Tensor):
+    """(g_x, g_gamma, g_beta) of the training-mode BatchNorm1d."""
+    dev = _require_device(x, g_y, gamma)
+    L = _lib.load()
+    x = _f32c(x, "x"); g_y = _f32c(g_y, "g_y"); gamma = _f32c(gamma, "gamma")
+    N, H = x.shape
+    g_x = torch.empty_like(x)
+    gg = torch.empty((2, H), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _ws(L.dmet_bn_workspace_bytes(N, H), dev)
+        _lib.check(L.dmet_bn_bwd_f32(x.data_ptr(), g_y.data_ptr(), N, H, gamma.data_ptr(), save_mean.data_ptr(),
+                                     save_invstd.data_ptr(), g_x.data_ptr(), gg[0].data_ptr(), gg[1].data_ptr(),
+                                     ws.data_ptr(), ws.numel(), _stream(dev)), "dmet_bn_bwd_f32")
+    return g_x, gg[0], gg[1]

@@ -79,3 +79,47 @@ def encode(x_cont: torch.Tensor, x_cat: torch.Tensor, *params: torch.Tensor) -> 
     """h[N,32] = ELU(Wa [ELU(Wk [Echg[chg+1] | Epdg[remap |pdg|] | Epv[pv]] + bk) | ELU(Wc x_cont + bc)] + ba);
     params = (Wc, bc, Wk, bk, Wa, ba, Echg, Epdg, Epv) in torch layouts."""
     return _Encode.apply(x_cont, x_cat, *params)
+
+
+class _BatchNorm(torch.autograd.Function):
+    """BatchNorm1d over the rows of x[N,H] (+ residual) on the HIP kernels of csrc/norm.hip."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps):
+        y, mean, invstd = _native.bn_fwd(x, residual, weight.detach(), bias.detach(), eps, momentum,
+                                         running_mean, running_var, training)
+        ctx.save_for_backward(x, weight, mean, invstd)
+        ctx.training = training
+        ctx.has_residual = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        x, weight, mean, invstd = ctx.saved_tensors
+        g_y = g_y.contiguous()
+        if ctx.training:
+            g_x, g_w, g_b = _native.bn_bwd(x, g_y, weight.detach(), mean, invstd)
+        else:   # running statistics are constants: a per-channel affine map
+            scale = weight.detach() * invstd
+            g_x = g_y * scale
+            g_w = (g_y * (x - mean) * invstd).sum(0)
+            g_b = g_y.sum(0)
+        return g_x, (g_y if ctx.has_residual else None), g_w, g_b, None, None, None, None, None
+
+
+def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """residual + bn(x) (residual optional) for a torch.nn.BatchNorm1d module `bn` over x[N,H]: same parameters,
+    buffers and train/eval semantics as calling the module (momentum=None, no affine or H not a multiple of 4 up to
+    64 take the module itself)."""
+    H = x.shape[1] if x.dim() == 2 else -1
+    ok = (x.dim() == 2 and x.dtype == torch.float32 and H % 4 == 0 and 4 <= H <= 64 and bn.affine
+          and bn.momentum is not None and x.shape[0] > 1 and (bn.training or bn.track_running_stats))
+    if not ok:
+        y = bn(x)
+        return y if residual is None else residual + y
+    training = bn.training or not bn.track_running_stats
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BatchNorm.apply(x, residual, bn.weight, bn.bias, rm, rv, training, float(bn.momentum), float(bn.eps))

@@ -68,7 +68,7 @@ class GraphMETNetwork(nn.Module):
             lc, lk, la = self.embed_continuous[0], self.embed_categorical[0], self.encode_all[0]
             h = dense.encode(x_cont, x_cat, lc.weight, lc.bias, lk.weight, lk.bias, la.weight, la.bias,
                              self.embed_charge.weight, self.embed_pdgid.weight, self.embed_pv.weight)
-            return self.bn_all(h)
+            return dense.batch_norm(h, self.bn_all)
         e_cont = _run(self.embed_continuous, x_cont)
         e_chrg = dense.embedding(x_cat[:, 1] + 1, self.embed_charge.weight)
         e_pv = dense.embedding(x_cat[:, 2], self.embed_pv.weight)
@@ -77,13 +77,13 @@ class GraphMETNetwork(nn.Module):
             pdg = torch.where(pdg == val, torch.full_like(pdg, cls), pdg)
         e_pdg = dense.embedding(pdg, self.embed_pdgid.weight)
         e_cat = _run(self.embed_categorical, torch.cat([e_chrg, e_pdg, e_pv], dim=1))
-        return self.bn_all(_run(self.encode_all, torch.cat([e_cat, e_cont], dim=1)))
+        return dense.batch_norm(_run(self.encode_all, torch.cat([e_cat, e_cont], dim=1)), self.bn_all)
 
     def forward(self, x_cont, x_cat, edge_index, batch):
         emb = self.embed(x_cont, x_cat)
         for conv, norm in self.conv_continuous:
             msg = conv(emb, batch) if self.graph == "dynamic" else conv(emb, edge_index)
-            emb = emb + norm(msg)
+            emb = dense.batch_norm(msg, norm, residual=emb)   # emb + norm(msg) in one streaming kernel
         return _run(self.output, emb).squeeze(-1)
 
 

@@ -194,6 +194,21 @@ int dmet_encode_bwd_f32(const float *x, int64_t x_stride, const int64_t *x_cat, 
                         float *gbc, float *gWk, float *gbk, float *gWa, float *gba, float *gEchg, float *gEpdg,
                         float *gEpv, void *ws, size_t ws_bytes, dmet_stream_t stream);
 
+/* ---- N3 (third piece): BatchNorm1d over the nodes, optionally fused with the residual add ---------------
+ * model/graph_met_network.py:32,39,58,66: bn_all(...) and emb + bn(conv(...)).  x[N,H] row-major, H a multiple of 4
+ * up to 64.  training != 0: batch statistics (biased variance for the normalisation, unbiased for running_var, like
+ * torch.nn.BatchNorm1d); running_mean/var (optional pair) are updated in place with `momentum`.  training == 0:
+ * running statistics.  y = (x - mean) * gamma / sqrt(var + eps) + beta (+ residual when not NULL).
+ * save_mean / save_invstd [H] are written for the backward.  Column sums use fixed row ranges per workgroup and are
+ * combined in order: bitwise reproducible.  Backward (training statistics): g_x, g_gamma, g_beta (written). */
+size_t dmet_bn_workspace_bytes(int64_t N, int H);
+int dmet_bn_fwd_f32(const float *x, const float *residual, int64_t N, int H, const float *gamma, const float *beta,
+                    float eps, float momentum, float *running_mean, float *running_var, int training, float *y,
+                    float *save_mean, float *save_invstd, void *ws, size_t ws_bytes, dmet_stream_t stream);
+int dmet_bn_bwd_f32(const float *x, const float *g_y, int64_t N, int H, const float *gamma, const float *save_mean,
+                    const float *save_invstd, float *g_x, float *g_gamma, float *g_beta, void *ws, size_t ws_bytes,
+                    dmet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -179,7 +179,33 @@ def encode_bwd(x_cont, x_cat, params, h, g_h):
     return list(torch.autograd.grad(out, ps, g_h))
 
 
-_NAMES = ["encode_fwd", "encode_bwd", "knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
+def bn_fwd(x, residual, gamma, beta, eps, momentum, running_mean, running_var, training):
+    if training:
+        mean = x.mean(0)
+        var = x.var(0, unbiased=False)
+        if running_mean is not None:
+            n = x.shape[0]
+            running_mean.mul_(1 - momentum).add_(momentum * mean)
+            running_var.mul_(1 - momentum).add_(momentum * var * n / max(n - 1, 1))
+    else:
+        mean, var = running_mean.clone(), running_var.clone()
+    invstd = (var + eps).rsqrt()
+    y = (x - mean) * (gamma * invstd) + beta
+    if residual is not None:
+        y = y + residual
+    return y, mean, invstd
+
+
+def bn_bwd(x, g_y, gamma, mean, invstd):
+    xh = (x - mean) * invstd
+    g_b = g_y.sum(0)
+    g_w = (g_y * xh).sum(0)
+    n = x.shape[0]
+    g_x = gamma * invstd * (g_y - g_b / n - xh * (g_w / n))
+    return g_x, g_w, g_b
+
+
+_NAMES = ["bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
           "edge_features_bwd", "segment_max", "segment_sum", "segment_max_bwd", "segment_sum_bwd", "met_reduce",
           "met_reduce_bwd", "segment_sum_1d", "batch_to_ptr", "xty", "onehot_xty", "edgeconv_fused_lds"]
 

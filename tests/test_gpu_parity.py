@@ -450,6 +450,46 @@ def test_fused_encoder_fwd_bwd(dev, N):
         assert torch.equal(p.grad, q.grad)
 
 
+@pytest.mark.parametrize("N,H,residual,training", [(5000, 32, True, True), (70001, 32, False, True), (3, 8, True, True),
+                                                   (1000, 64, True, False), (4097, 16, False, True)])
+def test_batch_norm_residual_fwd_bwd(dev, N, H, residual, training):
+    """N3: csrc/norm.hip vs torch.nn.BatchNorm1d in float64 on the CPU (same module state, running statistics
+    included), with a large common offset in x to exercise the shifted-sum statistics."""
+    from deepmetv2_amd import dense
+    g = torch.Generator().manual_seed(N + H)
+    x = torch.randn(N, H, generator=g) * 0.7 + 3.0
+    r = torch.randn(N, H, generator=g) if residual else None
+    gup = torch.randn(N, H, generator=g)
+    ref = torch.nn.BatchNorm1d(H).double()
+    with torch.no_grad():
+        ref.weight.copy_(torch.rand(H, generator=g) + 0.5); ref.bias.copy_(torch.randn(H, generator=g))
+        ref.running_mean.copy_(torch.randn(H, generator=g)); ref.running_var.copy_(torch.rand(H, generator=g) + 0.5)
+    bn = torch.nn.BatchNorm1d(H)
+    bn.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in ref.state_dict().items()})
+    bn = bn.to(dev)
+    ref.train(training); bn.train(training)
+    x64 = x.double().requires_grad_(True)
+    r64 = r.double().requires_grad_(True) if residual else None
+    y_ref = ref(x64) + (r64 if residual else 0.0)
+    y_ref.backward(gup.double())
+    xd = x.to(dev).requires_grad_(True)
+    rd = r.to(dev).requires_grad_(True) if residual else None
+    y = dense.batch_norm(xd, bn, residual=rd)
+    y.backward(gup.to(dev))
+    torch.testing.assert_close(y.detach().cpu().double(), y_ref.detach(), rtol=2e-5, atol=2e-5)
+    gs = float(x64.grad.abs().max())
+    torch.testing.assert_close(xd.grad.cpu().double(), x64.grad, rtol=1e-4, atol=2e-5 * max(gs, 1.0))
+    if residual:
+        assert torch.equal(rd.grad.cpu(), gup)
+    torch.testing.assert_close(bn.weight.grad.cpu().double(), ref.weight.grad, rtol=1e-4,
+                               atol=1e-5 * max(1.0, float(ref.weight.grad.abs().max())))
+    torch.testing.assert_close(bn.bias.grad.cpu().double(), ref.bias.grad, rtol=1e-4,
+                               atol=1e-5 * max(1.0, float(ref.bias.grad.abs().max())))
+    torch.testing.assert_close(bn.running_mean.cpu().double(), ref.running_mean, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(bn.running_var.cpu().double(), ref.running_var, rtol=1e-5, atol=1e-5)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
 def test_dense_linear_embedding_autograd(dev):
     from deepmetv2_amd import dense
     g = torch.Generator().manual_seed(0)
