@@ -51,6 +51,8 @@ SIGNATURES = {
     "dmet_xty_workspace_bytes": (_sz, [_i64, _i, _i]),
     "dmet_xty_f32": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _sz, _vp]),
     "dmet_onehot_xty_f32": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _sz, _vp]),
+    "dmet_edgeconv_linear_bwd_workspace_bytes": (_sz, [_i64, _i]),
+    "dmet_edgeconv_linear_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_bn_workspace_bytes": (_sz, [_i64, _i]),
     "dmet_bn_fwd_f32": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_bn_bwd_f32": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -553,3 +553,27 @@ def bn_bwd(x: torch.Tensor, g_y: torch.Tensor, gamma: torch.Tensor, save_mean: t
                                      save_invstd.data_ptr(), g_x.data_ptr(), gg[0].data_ptr(), gg[1].data_ptr(),
                                      ws.data_ptr(), ws.numel(), _stream(dev)), "dmet_bn_bwd_f32")
     return g_x, gg[0], gg[1]
+
+
+def edgeconv_linear_bwd(x: torch.Tensor, weight: torch.Tensor, g_out: torch.Tensor, arg: Optional[torch.Tensor],
+                        gQ: torch.Tensor, want_bias: bool = True):
+    """(gx[N,32], gW[32,64], gb[32] or None) of the fused EdgeConv dense layer (H = 32) from g_out, arg and gQ."""
+    dev = _require_device(x, weight, g_out, gQ)
+    L = _lib.load()
+    x = _f32c(x, "x"); weight = _f32c(weight, "weight"); g_out = _f32c(g_out, "g_out"); gQ = _f32c(gQ, "gQ")
+    N, H = x.shape
+    if H != 32 or tuple(weight.shape) != (32, 64) or g_out.shape != x.shape or gQ.shape != x.shape:
+        raise ValueError("edgeconv_linear_bwd: built for x[N,32], weight[32,64]")
+    if arg is not None and (arg.dtype != torch.uint8 or arg.shape != x.shape or not arg.is_contiguous()):
+        raise ValueError("edgeconv_linear_bwd: arg must be contiguous uint8 [N,32]")
+    gx = torch.empty_like(x)
+    gW = torch.empty_like(weight)
+    gb = torch.empty((H,), dtype=torch.float32, device=dev) if want_bias else None
+    with torch.cuda.device(dev):
+        ws = _ws(L.dmet_edgeconv_linear_bwd_workspace_bytes(N, H), dev)
+        _lib.check(L.dmet_edgeconv_linear_bwd_f32(x.data_ptr(), weight.data_ptr(), g_out.data_ptr(),
+                                                  arg.data_ptr() if arg is not None else None, gQ.data_ptr(), N, H,
+                                                  gx.data_ptr(), gW.data_ptr(), gb.data_ptr() if gb is not None else None,
+                                                  ws.data_ptr(), ws.numel(), _stream(dev)),
+                   "dmet_edgeconv_linear_bwd_f32")
+    return gx, gW, gb

@@ -98,6 +98,12 @@ class _EdgeConvLinearMax(torch.autograd.Function):
         g_out = g_out.contiguous()
         rev_ptr, rev_pos = table.reverse()
         gQ = _native.gather_max_bwd(g_out, arg, rev_ptr, rev_pos, table.k)
+        if H == 32 and tuple(weight.shape) == (32, 64) and g_out.dtype == torch.float32:
+            # one pass over the rows: gx, gW and gb on the fp32 matrix cores (csrc/edgeconv_bwd.hip)
+            gx, gW, gb = _native.edgeconv_linear_bwd(x, weight.detach(), g_out, None if table.dense else arg, gQ,
+                                                     want_bias=ctx.has_bias)
+            return (gx if ctx.needs_input_grad[0] else None, gW if ctx.needs_input_grad[1] else None,
+                    gb if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None, None)
         # nodes without any neighbour produced 0 (R3): no gradient reaches P there
         gP = g_out if table.dense else g_out * (arg != 255).to(g_out.dtype)
         Wd = weight[:, :H] - weight[:, H:]

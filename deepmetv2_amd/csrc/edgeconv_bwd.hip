@@ -1,0 +1,204 @@
+// edgeconv_bwd.hip -- K5: node-level backward of the fused EdgeConv (Linear 2H -> H with max), H = 32, gfx950.
+//
+// After gather_max_bwd_kernel has turned the upstream gradient into gQ (the gradient of the gathered table
+// Q = x.W2^T), what is left of the backward of /root/reference/model/graph_met_network.py:35-37
+// (EdgeConv(nn=Sequential(Linear(2H, H)))) in the split form  out_i = P_i + max_s Q[nbr[i,s]],
+// P = x.(W1-W2)^T + b,  is node-level dense algebra with gP = g_out (masked where the node had no neighbour):
+//     gx = gP.(W1-W2) + gQ.W2                      [N,H]
+//     gW = [ gP^T x  |  gQ^T x - gP^T x ]          [H,2H]   (torch Linear.weight layout)
+//     gb = sum_i gP_i                               [H]
+// Stock torch spends ~330 us per layer on it (two library GEMMs, two tall-skinny reductions, mask/copy/cat/sum
+// elementwise kernels).  Here it is ONE pass over the rows: every wavefront walks 32-node chunks, stages gP, gQ and x
+// of the chunk in LDS with coalesced loads, and runs fp32 MFMAs (32x32x2): gx of the chunk (K = 2H) goes straight
+// back to memory, the weight-gradient tiles (K = nodes) stay in accumulators for the wavefront's whole node range.
+// Fixed node ranges per wavefront + partials summed in order by a second kernel: bitwise reproducible, no atomics.
+#include "common.h"
+
+namespace dmet {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kH = 32;
+constexpr int kChunk = 32;                 // nodes per MFMA row tile
+constexpr int kPad = 36;                   // LDS row stride in floats (16-byte aligned rows, banks spread)
+constexpr int kWavesPerBlock = 4;
+constexpr int kPartial = 2 * 1024 + kH;    // per wavefront: gP^T x, gQ^T x, column sums of gP
+
+__device__ __forceinline__ void ecb_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd_kernel(
+    const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ g_out,
+    const uint8_t *__restrict__ arg, const float *__restrict__ gQ, int64_t N, int64_t nodes_per_wave,
+    float *__restrict__ gx, float *__restrict__ partial)
+{
+    __shared__ float sP[kWavesPerBlock][kChunk * kPad];
+    __shared__ float sQ[kWavesPerBlock][kChunk * kPad];
+    __shared__ float sX[kWavesPerBlock][kChunk * kPad];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = lane & 31, hh = lane >> 5;
+    float *P = sP[wv], *Q = sQ[wv], *X = sX[wv];
+    const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wv;
+    const int64_t lo = wave * nodes_per_wave, hi = min(N, lo + nodes_per_wave);
+
+    // B operand of the gx product: Wst[k][j], k = 0..63 over [gP | gQ] columns, j = input feature:
+    //   k <  32: (W1 - W2)[out k][in j] = W[k][j] - W[k][32 + j];   k >= 32: W2[out k-32][in j] = W[k-32][32 + j]
+    // MFMA step s uses k = 2 s + hh.
+    float wst[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        const int k = 2 * s + hh;
+        wst[s] = (k < kH) ? (W[k * 64 + c] - W[k * 64 + kH + c]) : W[(k - kH) * 64 + kH + c];
+    }
+    f32x16 accP, accQ;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { accP[e] = 0.0f; accQ[e] = 0.0f; }
+    float bsum = 0.0f;
+
+    const int lr = lane >> 3, lp = lane & 7;      // loader role: row within a group of 8, float4 column
+    for (int64_t base = lo; base < hi; base += kChunk) {
+        ecb_wave_sync();                           // previous chunk's tiles are consumed
+#pragma unroll
+        for (int g = 0; g < kChunk / 8; ++g) {
+            const int r = g * 8 + lr;
+            const int64_t i = base + r;
+            float4 vp = make_float4(0.f, 0.f, 0.f, 0.f), vq = vp, vx = vp;
+            if (i < hi) {
+                vp = reinterpret_cast<const float4 *>(g_out + i * kH)[lp];
+                vq = reinterpret_cast<const float4 *>(gQ + i * kH)[lp];
+                vx = reinterpret_cast<const float4 *>(x + i * kH)[lp];
+                if (arg) {   // nodes without any neighbour produced 0 (R3): no gradient reaches P there
+                    const uchar4 a4 = reinterpret_cast<const uchar4 *>(arg + i * kH)[lp];
+                    if (a4.x == 255) vp.x = 0.f;
+                    if (a4.y == 255) vp.y = 0.f;
+                    if (a4.z == 255) vp.z = 0.f;
+                    if (a4.w == 255) vp.w = 0.f;
+                }
+            }
+            *reinterpret_cast<float4 *>(&P[r * kPad + 4 * lp]) = vp;
+            *reinterpret_cast<float4 *>(&Q[r * kPad + 4 * lp]) = vq;
+            *reinterpret_cast<float4 *>(&X[r * kPad + 4 * lp]) = vx;
+        }
+        ecb_wave_sync();
+        // gx tile [32 nodes][32 features] = [gP | gQ] . Wst   (A operand: lane (node c, hh) supplies G[c][2 s + hh])
+        f32x16 accx;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accx[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) accx = __builtin_amdgcn_mfma_f32_32x32x2f32(P[c * kPad + 2 * s + hh], wst[s], accx, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) accx = __builtin_amdgcn_mfma_f32_32x32x2f32(Q[c * kPad + 2 * s + hh], wst[16 + s], accx, 0, 0, 0);
+        // weight-gradient tiles: C[m][j] += sum_node G[node][m] x[node][j]   (K = nodes, step s uses node 2 s + hh)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int node = 2 * s + hh;
+            const float xv = X[node * kPad + c];
+            accP = __builtin_amdgcn_mfma_f32_32x32x2f32(P[node * kPad + c], xv, accP, 0, 0, 0);
+            accQ = __builtin_amdgcn_mfma_f32_32x32x2f32(Q[node * kPad + c], xv, accQ, 0, 0, 0);
+        }
+        // bias gradient: column c of gP, half of the rows per lane half
+        {
+            float t = 0.0f;
+#pragma unroll
+            for (int n = 0; n < 16; ++n) t += P[(hh * 16 + n) * kPad + c];
+            bsum += t;
+        }
+        // store gx: accx[e] = row (e&3) + 8 (e>>2) + 4 hh, column c
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t i = base + (e & 3) + 8 * (e >> 2) + 4 * hh;
+            if (i < hi) gx[i * kH + c] = accx[e];
+        }
+    }
+    float *out = partial + wave * (int64_t)kPartial;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        out[r * 32 + c] = accP[e];
+        out[1024 + r * 32 + c] = accQ[e];
+    }
+    const float b = bsum + __shfl_xor(bsum, 32, 64);
+    if (hh == 0) out[2048 + c] = b;
+}
+
+// gW[o][0:32] = sum gP^T x,  gW[o][32:64] = sum gQ^T x - sum gP^T x,  gb[o] = sum gP.  Partials are added in a fixed
+// order: 32 thread groups each take every 32nd wavefront, then the 32 group sums are added in order.  Blocks 0..31 own
+// 32 elements of both weight tiles, block 32 the bias.
+__global__ __launch_bounds__(1024) void edgeconv_linear_bwd_finalize_kernel(const float *__restrict__ partial,
+                                                                             int64_t nwaves, float *__restrict__ gW,
+                                                                             float *__restrict__ gb)
+{
+    __shared__ float red0[32][33], red1[32][33];
+    const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const bool bias = blockIdx.x == 32;
+    const int idx = bias ? (2048 + e) : (blockIdx.x * 32 + e);
+    float s0 = 0.0f, s1 = 0.0f;
+    for (int64_t w = grp; w < nwaves; w += 32) {
+        s0 += partial[w * kPartial + idx];
+        if (!bias) s1 += partial[w * kPartial + 1024 + idx];
+    }
+    red0[grp][e] = s0; red1[grp][e] = s1;
+    __syncthreads();
+    if (grp != 0) return;
+    s0 = 0.0f; s1 = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { s0 += red0[q][e]; s1 += red1[q][e]; }
+    if (bias) {
+        if (gb) gb[e] = s0;
+    } else {
+        gW[(idx >> 5) * 64 + (idx & 31)] = s0;
+        gW[(idx >> 5) * 64 + 32 + (idx & 31)] = s1 - s0;
+    }
+}
+
+inline int64_t ecb_nodes_per_wave(int64_t N, int64_t *nwaves)
+{
+    const int64_t target = 2048;                   // 256 CUs x 8 resident wavefronts
+    int64_t npw = (N + target - 1) / target;
+    npw = (npw + kChunk - 1) / kChunk * kChunk;
+    if (npw < kChunk) npw = kChunk;
+    int64_t nw = (N + npw - 1) / npw;
+    nw = (nw + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock;
+    *nwaves = nw;
+    return npw;
+}
+
+}  // namespace
+}  // namespace dmet
+
+using namespace dmet;
+
+extern "C" size_t dmet_edgeconv_linear_bwd_workspace_bytes(int64_t N, int H)
+{
+    if (N <= 0 || H != kH) return 0;
+    int64_t nw;
+    (void)ecb_nodes_per_wave(N, &nw);
+    return sizeof(float) * (size_t)nw * kPartial + 512;
+}
+
+extern "C" int dmet_edgeconv_linear_bwd_f32(const float *x, const float *W, const float *g_out, const uint8_t *arg,
+                                            const float *gQ, int64_t N, int H, float *gx, float *gW, float *gb,
+                                            void *ws, size_t ws_bytes, dmet_stream_t stream)
+{
+    DMET_REQUIRE(H == kH, "dmet_edgeconv_linear_bwd_f32: H=%d (only 32 is built)", H);
+    DMET_REQUIRE(N > 0, "dmet_edgeconv_linear_bwd_f32: N=%lld", (long long)N);
+    DMET_REQUIRE(x && W && g_out && gQ && gx && gW && ws, "dmet_edgeconv_linear_bwd_f32: null pointer");
+    DMET_REQUIRE(aligned16(x) && aligned16(g_out) && aligned16(gQ) && aligned16(gx) && (!arg || (reinterpret_cast<uintptr_t>(arg) & 3u) == 0),
+                 "dmet_edgeconv_linear_bwd_f32: rows must be 16-byte aligned");
+    DMET_REQUIRE(ws_bytes >= dmet_edgeconv_linear_bwd_workspace_bytes(N, H), "dmet_edgeconv_linear_bwd_f32: workspace too small");
+    int64_t nw;
+    const int64_t npw = ecb_nodes_per_wave(N, &nw);
+    float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(edgeconv_linear_bwd_kernel, dim3((unsigned)(nw / kWavesPerBlock)), dim3(kWave * kWavesPerBlock), 0, st,
+                       x, W, g_out, arg, gQ, N, npw, gx, partial);
+    DMET_LAUNCH_CHECK("edgeconv_linear_bwd_kernel");
+    hipLaunchKernelGGL(edgeconv_linear_bwd_finalize_kernel, dim3(33), dim3(1024), 0, st, partial, nw, gW, gb);
+    DMET_LAUNCH_CHECK("edgeconv_linear_bwd_finalize_kernel");
+    return 0;
+}

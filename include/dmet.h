@@ -194,6 +194,17 @@ int dmet_encode_bwd_f32(const float *x, int64_t x_stride, const int64_t *x_cat, 
                         float *gbc, float *gWk, float *gbk, float *gWa, float *gba, float *gEchg, float *gEpdg,
                         float *gEpv, void *ws, size_t ws_bytes, dmet_stream_t stream);
 
+/* ---- K5 (node level): backward of the fused EdgeConv dense layer, H = 32 -------------------------------------
+ * With P = x (W1-W2)^T + b, Q = x W2^T, out_i = P_i + max_s Q[nbr[i,s]] (dmet_node_linear_split_f32 +
+ * dmet_gather_max_f32) and gQ from dmet_gather_max_bwd_f32:
+ *   gx = gP (W1-W2) + gQ W2,   gW[H,2H] = [gP^T x | gQ^T x - gP^T x],   gb = sum_i gP_i,
+ * gP = g_out masked to 0 where arg == 255 (node without neighbour; arg may be NULL for dense tables).
+ * One pass over the rows, fp32 MFMA, deterministic (fixed node ranges per wavefront, ordered partial sums). */
+size_t dmet_edgeconv_linear_bwd_workspace_bytes(int64_t N, int H);
+int dmet_edgeconv_linear_bwd_f32(const float *x, const float *W, const float *g_out, const uint8_t *arg,
+                                 const float *gQ, int64_t N, int H, float *gx, float *gW, float *gb, void *ws,
+                                 size_t ws_bytes, dmet_stream_t stream);
+
 /* ---- N3 (third piece): BatchNorm1d over the nodes, optionally fused with the residual add ---------------
  * model/graph_met_network.py:32,39,58,66: bn_all(...) and emb + bn(conv(...)).  x[N,H] row-major, H a multiple of 4
  * up to 64.  training != 0: batch statistics (biased variance for the normalisation, unbiased for running_var, like

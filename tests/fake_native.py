@@ -205,7 +205,17 @@ def bn_bwd(x, g_y, gamma, mean, invstd):
     return g_x, g_w, g_b
 
 
-_NAMES = ["bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
+def edgeconv_linear_bwd(x, weight, g_out, arg, gQ, want_bias=True):
+    H = x.shape[1]
+    gP = g_out if arg is None else g_out * (arg != 255).to(g_out.dtype)
+    Wd, W2 = weight[:, :H] - weight[:, H:], weight[:, H:]
+    gx = gP @ Wd + gQ @ W2
+    gWd = gP.t() @ x
+    gW = torch.cat([gWd, gQ.t() @ x - gWd], dim=1)
+    return gx, gW, (gP.sum(0) if want_bias else None)
+
+
+_NAMES = ["edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
           "edge_features_bwd", "segment_max", "segment_sum", "segment_max_bwd", "segment_sum_bwd", "met_reduce",
           "met_reduce_bwd", "segment_sum_1d", "batch_to_ptr", "xty", "onehot_xty", "edgeconv_fused_lds"]
 
