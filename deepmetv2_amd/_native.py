@@ -577,3 +577,23 @@ def edgeconv_linear_bwd(x: torch.Tensor, weight: torch.Tensor, g_out: torch.Tens
                                                   ws.data_ptr(), ws.numel(), _stream(dev)),
                    "dmet_edgeconv_linear_bwd_f32")
     return gx, gW, gb
+
+
+def gather_max_bwd_lds(g_out: torch.Tensor, arg: torch.Tensor, nbr: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:
+    """gQ[N,32] by per-event LDS scatter with exact integer sums (no reverse index); see include/dmet.h."""
+    dev = _require_device(g_out, arg, nbr, ptr)
+    L = _lib.load()
+    g_out = _f32c(g_out, "g_out")
+    N, H = g_out.shape
+    if arg.dtype != torch.uint8 or not arg.is_contiguous() or nbr.dtype != torch.int32 or not nbr.is_contiguous():
+        raise TypeError("gather_max_bwd_lds: arg must be contiguous uint8, nbr contiguous int32")
+    B = ptr.numel() - 1
+    gQ = torch.empty((N, H), dtype=torch.float32, device=dev)
+    _t = timer.record('gather_max_bwd', dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_gather_max_bwd_lds_f32(g_out.data_ptr(), arg.data_ptr(), nbr.data_ptr(), ptr.data_ptr(), B, N,
+                                                 nbr.shape[1], H, gQ.data_ptr(), _stream(dev)),
+                   "dmet_gather_max_bwd_lds_f32")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
+    return gQ

@@ -53,6 +53,7 @@ def _as_fusable_linear(nn_module) -> Optional[torch.nn.Linear]:
 # "fused": both in one launch (edgeconv_fused_lds_kernel).  End to end the two are within 1 % of each other at
 # config 2 (58 us vs 34 + 45 us per layer of a 8 ms step); "split" is the default because its gather+max kernel is
 # the one BASELINE.md's roofline definition describes.
+GATHER_BWD_FORM = os.environ.get("DMET_GATHER_BWD", "lds")   # "reverse": radix-sorted reverse index route
 EDGECONV_FORM = os.environ.get("DMET_EDGECONV_FORM", "split")
 _LDS_MAX_EVENT_NODES = 5119                                      # 160 KB LDS / 32 B per node, minus the -inf row
 
@@ -96,8 +97,12 @@ class _EdgeConvLinearMax(torch.autograd.Function):
         table: NeighborTable = ctx.table
         H = x.shape[1]
         g_out = g_out.contiguous()
-        rev_ptr, rev_pos = table.reverse()
-        gQ = _native.gather_max_bwd(g_out, arg, rev_ptr, rev_pos, table.k)
+        if H == 32 and g_out.dtype == torch.float32 and table.cnt is None and GATHER_BWD_FORM != "reverse":
+            # per-event LDS scatter with exact integer sums: no reverse index (radix sort) needed
+            gQ = _native.gather_max_bwd_lds(g_out, arg, table.nbr, table.ptr)
+        else:
+            rev_ptr, rev_pos = table.reverse()
+            gQ = _native.gather_max_bwd(g_out, arg, rev_ptr, rev_pos, table.k)
         if H == 32 and tuple(weight.shape) == (32, 64) and g_out.dtype == torch.float32:
             # one pass over the rows: gx, gW and gb on the fp32 matrix cores (csrc/edgeconv_bwd.hip)
             gx, gW, gb = _native.edgeconv_linear_bwd(x, weight.detach(), g_out, None if table.dense else arg, gQ,

@@ -168,6 +168,89 @@ inline int64_t ecb_nodes_per_wave(int64_t N, int64_t *nwaves)
     return npw;
 }
 
+// ---- gQ without a reverse index: per-event scatter into LDS with exact (order-independent) integer sums -----------
+// gQ[j,c] = sum over (i,s) with nbr[i,s] == j and arg[i,c] == s of g_out[i,c].  The reverse-index route costs a stable
+// radix sort of N*k keys per layer (~250 us at N*k = 4.6M) plus an L2 gather per reverse edge.  Here a workgroup owns
+// (event, 4 channels): every node's winner j is looked up in its nbr row and the gradient is ADDED INTO LDS at
+// [j][channel] as a 64-bit fixed-point integer.  Integer addition is associative, so the result does not depend on
+// the order in which the lanes' atomics land: bitwise reproducible without any sorting.  The fixed-point scale is a
+// power of two chosen per workgroup from max |g| over its slice (30 value bits, 33 bits of headroom: up to 2^33
+// terms per cell); a term is rounded once to 2^-30 of that maximum, the sum is exact.
+// Events larger than the LDS window are done in several passes over fewer channels / a range of j.
+constexpr int kBwdThreads = 1024;
+constexpr int kBwdCells = 18432;             // 64-bit cells in LDS (144 KB)
+
+__global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const float *__restrict__ g_out,
+                                                                          const uint8_t *__restrict__ arg,
+                                                                          const int32_t *__restrict__ nbr,
+                                                                          const int64_t *__restrict__ ptr, int B, int k,
+                                                                          float *__restrict__ gQ)
+{
+    extern __shared__ unsigned long long cells[];
+    __shared__ float red[kBwdThreads / kWave];
+    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int ev = bid >> 3, slice = bid & 7;
+    if (ev >= B) return;
+    const int c0 = 4 * slice;
+    const int64_t lo = ptr[ev], hi = ptr[ev + 1];
+    const int n = (int)(hi - lo);
+    if (n <= 0) return;
+    const int tid = threadIdx.x;
+
+    // scale: 2^(30 - e) with 2^e > max |g| over the slice (exactly representable, so the final rescale is exact)
+    float m = 0.0f;
+    for (int i = tid; i < n; i += kBwdThreads) {
+        const float4 g = reinterpret_cast<const float4 *>(g_out + (lo + i) * kH + c0)[0];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int w = 1; w < kBwdThreads / kWave; ++w) m = fmaxf(m, red[w]);
+    int ex = 0;
+    (void)frexpf(m, &ex);                       // m = f * 2^ex, f in [0.5, 1)
+    const float scale = ldexpf(1.0f, 30 - ex), inv_scale = ldexpf(1.0f, ex - 30);
+
+    // window: CH channels x JW nodes of accumulators
+    const int CH = (n <= kBwdCells / 4) ? 4 : (n <= kBwdCells / 2) ? 2 : 1;
+    const int JW = kBwdCells / CH;
+    for (int cb = 0; cb < 4; cb += CH) {
+        for (int j0 = 0; j0 < n; j0 += JW) {
+            const int jn = min(JW, n - j0);
+            __syncthreads();
+            for (int t = tid; t < jn * CH; t += kBwdThreads) cells[t] = 0ull;
+            __syncthreads();
+            if (m > 0.0f) {
+                for (int i = tid; i < n; i += kBwdThreads) {
+                    const int64_t gi = lo + i;
+                    const uchar4 a4 = reinterpret_cast<const uchar4 *>(arg + gi * kH + c0)[0];
+                    const float4 g4 = reinterpret_cast<const float4 *>(g_out + gi * kH + c0)[0];
+                    const uint8_t as[4] = {a4.x, a4.y, a4.z, a4.w};
+                    const float gs[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (u >= cb && u < cb + CH && as[u] != 255) {
+                            const int j = nbr[gi * k + as[u]] - (int)lo - j0;
+                            if (j >= 0 && j < jn) {
+                                const long long q = __float2ll_rn(gs[u] * scale);
+                                atomicAdd(&cells[j * CH + (u - cb)], (unsigned long long)q);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int t = tid; t < jn * CH; t += kBwdThreads) {
+                const int j = t / CH, u = t - j * CH;
+                gQ[(lo + j0 + j) * kH + c0 + cb + u] = (float)(long long)cells[t] * inv_scale;
+            }
+        }
+    }
+}
+
 }  // namespace
 }  // namespace dmet
 
@@ -200,5 +283,29 @@ extern "C" int dmet_edgeconv_linear_bwd_f32(const float *x, const float *W, cons
     DMET_LAUNCH_CHECK("edgeconv_linear_bwd_kernel");
     hipLaunchKernelGGL(edgeconv_linear_bwd_finalize_kernel, dim3(33), dim3(1024), 0, st, partial, nw, gW, gb);
     DMET_LAUNCH_CHECK("edgeconv_linear_bwd_finalize_kernel");
+    return 0;
+}
+
+extern "C" int dmet_gather_max_bwd_lds_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr,
+                                           const int64_t *ptr, int B, int64_t N, int k, int H, float *gQ,
+                                           dmet_stream_t stream)
+{
+    DMET_REQUIRE(H == kH, "dmet_gather_max_bwd_lds_f32: H=%d (only 32 is built)", H);
+    DMET_REQUIRE(N >= 0 && B >= 0 && k >= 1 && k <= 255, "dmet_gather_max_bwd_lds_f32: bad sizes");
+    if (N == 0 || B == 0) return 0;
+    DMET_REQUIRE(g_out && arg && nbr && ptr && gQ, "dmet_gather_max_bwd_lds_f32: null pointer");
+    DMET_REQUIRE(aligned16(g_out) && aligned16(gQ) && (reinterpret_cast<uintptr_t>(arg) & 3u) == 0,
+                 "dmet_gather_max_bwd_lds_f32: rows must be 16-byte aligned");
+    static bool attr_set = false;
+    const size_t lds = sizeof(unsigned long long) * (size_t)kBwdCells;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gather_max_bwd_lds_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gather_max_bwd_lds_kernel)");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gather_max_bwd_lds_kernel, dim3((unsigned)B * 8u), dim3(kBwdThreads), lds, as_stream(stream), g_out,
+                       arg, nbr, ptr, B, k, gQ);
+    DMET_LAUNCH_CHECK("gather_max_bwd_lds_kernel");
     return 0;
 }

@@ -117,6 +117,12 @@ int dmet_gather_max_bf16q(const float *P, const uint16_t *Qh, const int32_t *nbr
 int dmet_gather_max_bwd_f32(const float *g_out, const uint8_t *arg, const int32_t *rev_ptr,
                             const int32_t *rev_slot, int64_t N, int k, int H, float *gQ,
                             dmet_stream_t stream);
+/* The same gQ without a reverse index (H = 32, node-sorted events as in ptr[B+1]; every nbr entry of a node lies in
+ * the node's own event): a workgroup per (event, 4 channels) scatter-adds into LDS with 64-bit fixed-point integer
+ * atomics -- integer sums are order-independent, hence bitwise reproducible; each term is rounded once to 2^-30 of the
+ * slice's max |g_out|, the sums are exact.  Replaces the radix sort + L2 gather of the route above on the hot path. */
+int dmet_gather_max_bwd_lds_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr, const int64_t *ptr, int B,
+                                int64_t N, int k, int H, float *gQ, dmet_stream_t stream);
 /* Reverse index: a stable sort of the positions 0..M-1 of an int32 key array by key value.
  *   rev_ptr[num_keys+1]: rev_pos[rev_ptr[j] .. rev_ptr[j+1]-1] = the positions holding key j, ascending.
  * Keys outside [0, num_keys) (the -1 "no neighbour" entries) sort last and are not indexed.

@@ -215,7 +215,18 @@ def edgeconv_linear_bwd(x, weight, g_out, arg, gQ, want_bias=True):
     return gx, gW, (gP.sum(0) if want_bias else None)
 
 
-_NAMES = ["edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
+def gather_max_bwd_lds(g_out, arg, nbr, ptr):
+    N, H = g_out.shape
+    gQ = torch.zeros_like(g_out)
+    a = arg.long()
+    valid = a != 255
+    j = torch.gather(nbr.long(), 1, a.clamp(max=nbr.shape[1] - 1))        # [N,H] winner source per channel
+    cols = torch.arange(H).expand(N, H)
+    gQ.index_put_((j[valid], cols[valid]), g_out[valid], accumulate=True)
+    return gQ
+
+
+_NAMES = ["gather_max_bwd_lds", "edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
           "edge_features_bwd", "segment_max", "segment_sum", "segment_max_bwd", "segment_sum_bwd", "met_reduce",
           "met_reduce_bwd", "segment_sum_1d", "batch_to_ptr", "xty", "onehot_xty", "edgeconv_fused_lds"]
 

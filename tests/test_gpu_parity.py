@@ -318,6 +318,36 @@ def test_edgeconv_static_graph_from_radius(dev):
     _close(out.detach().cpu(), ref.detach())
 
 
+@pytest.mark.parametrize("sizes", [[300, 1, 0, 77], [4700, 50], [9500], [19000, 3]])
+def test_gather_max_bwd_lds_matches_reverse_index_route(dev, sizes):
+    """K5: the LDS fixed-point scatter (no reverse index) against the sorted reverse-index kernel (itself pinned to
+    the oracle by the EdgeConv backward tests): 1e-6 of max|g| per cell (each term is rounded to 2^-30 of the
+    slice maximum), bitwise reproducible, all window shapes (4 / 2 / 1 channels, several j windows)."""
+    from deepmetv2_amd import _native
+    g = torch.Generator().manual_seed(sum(sizes))
+    N, k, H = sum(sizes), 16, 32
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.tensor(sizes).cumsum(0)])
+    nbr = torch.empty(N, k, dtype=torch.int32)
+    for b, n in enumerate(sizes):
+        if n:
+            lo = int(ptr[b])
+            # skewed in-degrees: half of the slots point at the first 5 nodes of the event
+            r = torch.randint(0, n, (n, k), generator=g)
+            hot = torch.randint(0, min(n, 5), (n, k), generator=g)
+            nbr[lo:lo + n] = (torch.where(torch.rand(n, k, generator=g) < 0.5, hot, r) + lo).int()
+    arg = torch.randint(0, k, (N, H), generator=g).to(torch.uint8)
+    arg[::7, 3] = 255
+    g_out = torch.randn(N, H, generator=g) * torch.logspace(-3, 2, H)
+    nd, ad, gd, pd = nbr.to(dev), arg.to(dev), g_out.to(dev), ptr.to(dev)
+    rev_ptr, rev_pos = _native.reverse_index(nd.view(-1), N)
+    ref = _native.gather_max_bwd(gd, ad, rev_ptr, rev_pos, k)
+    got = _native.gather_max_bwd_lds(gd, ad, nd, pd)
+    got2 = _native.gather_max_bwd_lds(gd, ad, nd, pd)
+    assert torch.equal(got, got2)
+    scale = g_out.abs().amax(0).to(dev) * float(max(sizes)) * 1e-6 + 1e-12
+    assert bool(((got - ref).abs() <= scale + 1e-5 * ref.abs()).all())
+
+
 def test_max_ties_and_empty_rows(dev):
     """R3: empty target -> 0.  R4: gradient to the lowest edge position among exact ties."""
     import deepmetv2_amd as dm
