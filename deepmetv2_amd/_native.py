@@ -597,3 +597,21 @@ def gather_max_bwd_lds(g_out: torch.Tensor, arg: torch.Tensor, nbr: torch.Tensor
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))
     return gQ
+
+
+def met_loss(met: torch.Tensor, truth: torch.Tensor):
+    """(loss[1], d loss / d met [B,2]) of 0.5 * mean((met + truth)^2 summed over px, py)."""
+    dev = _require_device(met, truth)
+    L = _lib.load()
+    met = _f32c(met, "met"); truth = _f32c(truth, "truth")
+    if met.dim() != 2 or met.shape[1] != 2 or truth.shape[0] != met.shape[0] or truth.shape[1] < 2:
+        raise ValueError("met_loss: met must be [B,2], truth [B,>=2]")
+    if truth.shape[1] != 2:
+        truth = truth[:, :2].contiguous()
+    B = met.shape[0]
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    g = torch.empty_like(met)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_met_loss_f32(met.data_ptr(), truth.data_ptr(), B, loss.data_ptr(), g.data_ptr(), _stream(dev)),
+                   "dmet_met_loss_f32")
+    return loss, g

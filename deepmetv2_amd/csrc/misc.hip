@@ -151,6 +151,40 @@ extern "C" int dmet_segment_sum_1d_f32(const float *src, const int64_t *ptr, int
     return 0;
 }
 
+// loss = 0.5 * mean_b((met_x + true_x)^2 + (met_y + true_y)^2)  (model/net.py:58-61) and d loss / d met in one launch;
+// one workgroup, fixed summation order.
+__global__ __launch_bounds__(256) void met_loss_kernel(const float *__restrict__ met, const float *__restrict__ truth,
+                                                        int B, float *__restrict__ loss, float *__restrict__ g_met)
+{
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    const float invB = 1.0f / (float)B;
+    float s = 0.0f;
+    for (int b = tid; b < B; b += 256) {
+        const float rx = met[2 * b] + truth[2 * b], ry = met[2 * b + 1] + truth[2 * b + 1];
+        s += rx * rx + ry * ry;
+        g_met[2 * b] = rx * invB;
+        g_met[2 * b + 1] = ry * invB;
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] += red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) loss[0] = 0.5f * red[0] * invB;
+}
+
+extern "C" int dmet_met_loss_f32(const float *met, const float *truth, int B, float *loss, float *g_met,
+                                 dmet_stream_t stream)
+{
+    DMET_REQUIRE(B > 0, "dmet_met_loss_f32: B=%d", B);
+    DMET_REQUIRE(met && truth && loss && g_met, "dmet_met_loss_f32: null pointer");
+    hipLaunchKernelGGL(met_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), met, truth, B, loss, g_met);
+    DMET_LAUNCH_CHECK("met_loss_kernel");
+    return 0;
+}
+
 extern "C" int dmet_met_reduce_bwd_f32(const float *g_met, const float *x, int64_t x_stride, const int64_t *ptr,
                                        int B, int64_t N, float *g_w, dmet_stream_t stream)
 {

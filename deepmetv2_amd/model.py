@@ -18,7 +18,7 @@ from torch import nn
 
 from . import dense
 from .conv import DynamicEdgeConv, EdgeConv
-from .scatter import met_reduce
+from .scatter import met_loss, met_reduce
 
 PDG_CLASSES = (1, 2, 11, 13, 22, 130, 211)  # graph_met_network.py:45
 
@@ -104,7 +104,7 @@ def loss_fn(weights: torch.Tensor, prediction: torch.Tensor, truth: torch.Tensor
     """net.py:49-62 with the two scatter_add calls fused into one MET reduction:
     0.5 * mean_b((METx + true_px)^2 + (METy + true_py)^2)."""
     met = met_reduce(weights, prediction, batch, ptr=ptr, num_events=truth.shape[0])
-    return 0.5 * ((met[:, 0] + truth[:, 0]) ** 2 + (met[:, 1] + truth[:, 1]) ** 2).mean()
+    return met_loss(met, truth)
 
 
 def split_features(x: torch.Tensor):

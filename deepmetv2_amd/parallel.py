@@ -36,8 +36,9 @@ def balanced_shards(costs: Sequence[float], world: int) -> List[List[int]]:
 class FlatModule:
     """Re-homes every parameter (and its gradient) of `module` into two contiguous fp32 buffers.
 
-    `flat_param` / `flat_grad` alias the module's parameters, so one optimizer tensor, one zero_() and one
-    all_reduce() cover the whole model.  Parameter names/shapes (state_dict) are unchanged.
+    `flat_param` aliases the module's parameters and `flat_grad` collects their gradients after every backward
+    (`gather_grads`), so one optimizer tensor and one all_reduce() cover the whole model.  Parameter names/shapes
+    (state_dict) are unchanged.
     """
 
     def __init__(self, module: torch.nn.Module):
@@ -50,12 +51,14 @@ class FlatModule:
         self.flat_param = torch.nn.Parameter(torch.empty(total, device=dev, dtype=dt))
         self.flat_param.grad = torch.zeros(total, device=dev, dtype=dt)
         off = 0
+        self.grad_views = []
         with torch.no_grad():
             for p in params:
                 n = p.numel()
                 self.flat_param.data[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_param.data[off:off + n].view_as(p)
-                p.grad = self.flat_param.grad[off:off + n].view_as(p)
+                self.grad_views.append(self.flat_param.grad[off:off + n].view_as(p))
+                p.grad = None
                 off += n
         self.params = params
         self.numel = total
@@ -65,7 +68,18 @@ class FlatModule:
         return self.flat_param.grad
 
     def zero_grad(self) -> None:
-        self.flat_param.grad.zero_()
+        """Drop the per-parameter gradients: backward then hands each parameter a fresh tensor (no accumulate kernel
+        per parameter), and `gather_grads` moves them into the flat buffer in one multi-tensor copy."""
+        for p in self.params:
+            p.grad = None
+
+    def gather_grads(self) -> None:
+        """flat_grad <- the parameters' gradients of the last backward (zeros where a parameter got none)."""
+        pairs = [(v, p.grad) for v, p in zip(self.grad_views, self.params) if p.grad is not None]
+        if len(pairs) != len(self.params):
+            self.flat_param.grad.zero_()
+        if pairs:
+            torch._foreach_copy_([v for v, _ in pairs], [g for _, g in pairs])
 
     def buffers(self) -> List[torch.Tensor]:
         return [b for b in self.module.buffers()]
@@ -107,6 +121,7 @@ def train_step(model: torch.nn.Module, flat: FlatModule, sync: GradSync, optimiz
     weights = model(x_cont, x_cat, edge_index, batch)
     loss = loss_fn(weights, x, y, batch, ptr=ptr)
     loss.backward()
+    flat.gather_grads()
     sync.average_gradients()
     optimizer.step()
     return loss.detach()

@@ -136,3 +136,21 @@ def met_reduce(weights: torch.Tensor, x: torch.Tensor, batch: Optional[torch.Ten
     if ptr is None:
         ptr = batch_info(batch, weights.numel(), weights.device, num_events).ptr
     return _MetReduce.apply(weights, x, ptr)
+
+
+class _MetLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, met, truth):
+        loss, g = _native.met_loss(met, truth)
+        ctx.save_for_backward(g)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (g,) = ctx.saved_tensors
+        return g * g_loss, None
+
+
+def met_loss(met: torch.Tensor, truth: torch.Tensor) -> torch.Tensor:
+    """0.5 * mean_b((met[b,0] + truth[b,0])^2 + (met[b,1] + truth[b,1])^2) (model/net.py:58-61) in one kernel."""
+    return _MetLoss.apply(met, truth)

@@ -165,6 +165,9 @@ int dmet_met_reduce_f32(const float *w, const float *x, int64_t x_stride, const 
                         float *met, dmet_stream_t stream);
 int dmet_met_reduce_bwd_f32(const float *g_met, const float *x, int64_t x_stride, const int64_t *ptr,
                             int B, int64_t N, float *g_w, dmet_stream_t stream);
+/* loss[0] = 0.5 * mean_b((met[b,0] + truth[b,0])^2 + (met[b,1] + truth[b,1])^2)  (model/net.py:58-61) and
+ * g_met[B,2] = d loss / d met, one launch, fixed summation order. */
+int dmet_met_loss_f32(const float *met, const float *truth, int B, float *loss, float *g_met, dmet_stream_t stream);
 /* Generic sorted-index form used by the scatter_add(src, batch) drop-in: out[b] = sum_{i in b} src[i]. */
 int dmet_segment_sum_1d_f32(const float *src, const int64_t *ptr, int B, float *out,
                             dmet_stream_t stream);

@@ -226,7 +226,12 @@ def gather_max_bwd_lds(g_out, arg, nbr, ptr):
     return gQ
 
 
-_NAMES = ["gather_max_bwd_lds", "edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
+def met_loss(met, truth):
+    r = met + truth[:, :2]
+    return 0.5 * (r * r).sum(1).mean().view(1), r / met.shape[0]
+
+
+_NAMES = ["met_loss", "gather_max_bwd_lds", "edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
           "edge_features_bwd", "segment_max", "segment_sum", "segment_max_bwd", "segment_sum_bwd", "met_reduce",
           "met_reduce_bwd", "segment_sum_1d", "batch_to_ptr", "xty", "onehot_xty", "edgeconv_fused_lds"]
 

@@ -91,6 +91,7 @@ def test_two_rank_gloo_training_step(tmp_path):
             flat.flat_param.copy_(r[0]["p0"])
         x, y, batch = _make(events)
         loss_fn(model(*split_features(x), None, batch), x, y, batch).backward()
+        flat.gather_grads()
         grads.append(flat.flat_grad.clone())
     expect = (grads[0] + grads[1]) / 2
     torch.testing.assert_close(r[0]["grad"], expect, rtol=1e-5, atol=1e-6 * float(expect.abs().max()))
