@@ -615,3 +615,51 @@ def met_loss(met: torch.Tensor, truth: torch.Tensor):
         _lib.check(L.dmet_met_loss_f32(met.data_ptr(), truth.data_ptr(), B, loss.data_ptr(), g.data_ptr(), _stream(dev)),
                    "dmet_met_loss_f32")
     return loss, g
+
+
+def _head_params(params, dev):
+    shapes = [(16, 32), (16,), (1, 16), (1,)]
+    if len(params) != 4:
+        raise ValueError("head: expected (W1, b1, W2, b2)")
+    out = []
+    for t, shp in zip(params, shapes):
+        if tuple(t.shape) != shp or t.device != dev:
+            raise ValueError(f"head: parameter of shape {tuple(t.shape)}, expected {shp} on the device of emb")
+        out.append(_f32c(t, "param"))
+    return out
+
+
+def head_fwd(emb: torch.Tensor, params) -> torch.Tensor:
+    """sigmoid(W2 . ELU(W1 . emb + b1) + b2) per node: [N] from emb[N,32]."""
+    dev = _require_device(emb)
+    L = _lib.load()
+    emb = _f32c(emb, "emb")
+    if emb.dim() != 2 or emb.shape[1] != 32:
+        raise ValueError("head: emb must be [N,32]")
+    ps = _head_params(params, dev)
+    N = emb.shape[0]
+    out = torch.empty((N,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_head_fwd_f32(emb.data_ptr(), N, *[t.data_ptr() for t in ps], out.data_ptr(), _stream(dev)),
+                   "dmet_head_fwd_f32")
+    return out
+
+
+def head_bwd(emb: torch.Tensor, params, out: torch.Tensor, g_out: torch.Tensor):
+    """(g_emb, gW1, gb1, gW2, gb2) of head_fwd."""
+    dev = _require_device(emb, out, g_out)
+    L = _lib.load()
+    emb = _f32c(emb, "emb"); out = _f32c(out, "out"); g_out = _f32c(g_out, "g_out")
+    ps = _head_params(params, dev)
+    N = emb.shape[0]
+    g_emb = torch.empty_like(emb)
+    grads = [torch.empty_like(t) for t in ps]
+    if N == 0:
+        return [g_emb] + [g.zero_() for g in grads]
+    with torch.cuda.device(dev):
+        ws = _ws(L.dmet_head_bwd_workspace_bytes(N), dev)
+        _lib.check(L.dmet_head_bwd_f32(emb.data_ptr(), N, ps[0].data_ptr(), ps[1].data_ptr(), ps[2].data_ptr(),
+                                       out.data_ptr(), g_out.data_ptr(), g_emb.data_ptr(),
+                                       *[g.data_ptr() for g in grads], ws.data_ptr(), ws.numel(), _stream(dev)),
+                   "dmet_head_bwd_f32")
+    return [g_emb] + grads

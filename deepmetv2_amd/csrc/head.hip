@@ -1,0 +1,258 @@
+// head.hip -- N3: the per-node output head + sigmoid as one kernel each way (gfx950).
+//
+// /root/reference/model/graph_met_network.py:41-44,67 and model/net.py:46:
+//     weight_i = sigmoid( W2 . ELU(W1 . emb_i + b1) + b2 ),   W1[16,32], W2[1,16]
+// Stock torch: 2 library GEMMs + 3 elementwise kernels forward, 2 GEMMs + 2 tall-skinny weight-gradient reductions +
+// bias sums + elementwise kernels backward (~260 us per step at N = 288k).  Here: a forward kernel (emb tile through
+// LDS with coalesced loads, weights as scalar loads) and a backward kernel that recomputes the hidden layer,
+// back-propagates per node and reduces all four parameter gradients in-kernel on the fp32 matrix cores
+// (fixed node ranges per wavefront, ordered partial sums: bitwise reproducible).
+#include "common.h"
+
+namespace dmet {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kHin = 32, kHid = 16;
+constexpr int kXPad = 36;                      // emb tile row stride (floats)
+constexpr int kAPad = 20;                      // [g_z1 (16) | g_z | 0 0 0] and [h1 (16) | 1 | 0 0 0] tiles
+constexpr int kHeadWaves = 4;
+constexpr int kHeadPartial = 2 * 1024;         // per wavefront: A^T.emb tile, A^T.[h1|1] tile
+
+__device__ __forceinline__ void head_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float head_elu(float z) { return z > 0.0f ? z : (__expf(z) - 1.0f); }
+
+// coalesced copy of 64 emb rows into the wavefront's LDS tile (rows past `hi` read as the last valid row)
+__device__ __forceinline__ void head_load_tile(float *__restrict__ X, const float *__restrict__ emb, int64_t base,
+                                               int64_t hi, int lane)
+{
+    const int lr = lane >> 3, lp = lane & 7;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int r = g * 8 + lr;
+        const int64_t i = min(base + r, hi - 1);
+        *reinterpret_cast<float4 *>(&X[r * kXPad + 4 * lp]) = reinterpret_cast<const float4 *>(emb + i * kHin)[lp];
+    }
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__ emb, int64_t N,
+                                                        const float *__restrict__ W1, const float *__restrict__ b1,
+                                                        const float *__restrict__ W2, const float *__restrict__ b2,
+                                                        float *__restrict__ out)
+{
+    __shared__ float sX[4][64 * kXPad];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *X = sX[wv];
+    const int64_t base = ((int64_t)blockIdx.x * 4 + wv) * 64;
+    if (base >= N) return;
+    head_load_tile(X, emb, base, N, lane);
+    head_wave_sync();
+    float xr[32];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float4 v = *reinterpret_cast<const float4 *>(&X[lane * kXPad + 4 * c]);
+        xr[4 * c] = v.x; xr[4 * c + 1] = v.y; xr[4 * c + 2] = v.z; xr[4 * c + 3] = v.w;
+    }
+    float z = b2[0];
+#pragma unroll
+    for (int o = 0; o < kHid; ++o) {
+        float a = b1[o];
+#pragma unroll
+        for (int f = 0; f < kHin; ++f) a = __builtin_fmaf(W1[o * kHin + f], xr[f], a);
+        z = __builtin_fmaf(W2[o], head_elu(a), z);
+    }
+    if (base + lane < N) out[base + lane] = 1.0f / (1.0f + __expf(-z));
+}
+
+// C += A^T B over the 64 staged nodes; A tile [64][kAPad] (columns >= kAPad are zero), B = emb tile or the second A-like tile
+template <int BPAD>
+__device__ __forceinline__ void head_mma(f32x16 &acc, const float *__restrict__ A, const float *__restrict__ Bm, int lane)
+{
+    const int c = lane & 31, hh = lane >> 5;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) {
+        const int node = 2 * s + hh;
+        const float a = (c < kAPad) ? A[node * kAPad + c] : 0.0f;
+        const float b = (c < BPAD) ? Bm[node * BPAD + c] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(64 * kHeadWaves, 2) void head_bwd_kernel(const float *__restrict__ emb, int64_t N,
+                                                                      const float *__restrict__ W1,
+                                                                      const float *__restrict__ b1,
+                                                                      const float *__restrict__ W2,
+                                                                      const float *__restrict__ wout,
+                                                                      const float *__restrict__ g_w,
+                                                                      int64_t nodes_per_wave, float *__restrict__ g_emb,
+                                                                      float *__restrict__ partial)
+{
+    __shared__ float sX[kHeadWaves][64 * kXPad];
+    __shared__ float sA[kHeadWaves][64 * kAPad];
+    __shared__ float sB[kHeadWaves][64 * kAPad];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *X = sX[wv], *A = sA[wv], *Bt = sB[wv];
+    const int64_t wave = (int64_t)blockIdx.x * kHeadWaves + wv;
+    const int64_t lo = wave * nodes_per_wave, hi = min(N, lo + nodes_per_wave);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
+    for (int64_t base = lo; base < hi; base += 64) {
+        // opaque zero offset: keeps the (loop-invariant) scalar weight loads inside the loop (see encoder.hip)
+        int zero = 0;
+        asm volatile("" : "+s"(zero));
+        const float *__restrict__ w1 = W1 + zero, *__restrict__ pb1 = b1 + zero, *__restrict__ w2 = W2 + zero;
+        head_wave_sync();
+        head_load_tile(X, emb, base, hi, lane);
+        head_wave_sync();
+        const int64_t i = base + lane;
+        const bool live = i < hi;
+        float xr[32];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 v = *reinterpret_cast<const float4 *>(&X[lane * kXPad + 4 * c]);
+            xr[4 * c] = v.x; xr[4 * c + 1] = v.y; xr[4 * c + 2] = v.z; xr[4 * c + 3] = v.w;
+        }
+        const float w = live ? wout[i] : 0.0f;
+        const float gz = live ? g_w[i] * w * (1.0f - w) : 0.0f;          // through the sigmoid
+        float gz1[kHid];
+#pragma unroll
+        for (int o = 0; o < kHid; ++o) {
+            float a = pb1[o];
+#pragma unroll
+            for (int f = 0; f < kHin; ++f) a = __builtin_fmaf(w1[o * kHin + f], xr[f], a);
+            const float h = head_elu(a);
+            gz1[o] = gz * w2[o] * (a > 0.0f ? 1.0f : h + 1.0f);          // through Linear 2 and the ELU
+            A[lane * kAPad + o] = gz1[o];
+            Bt[lane * kAPad + o] = h;
+        }
+        A[lane * kAPad + 16] = gz; A[lane * kAPad + 17] = 0.0f; A[lane * kAPad + 18] = 0.0f; A[lane * kAPad + 19] = 0.0f;
+        Bt[lane * kAPad + 16] = 1.0f; Bt[lane * kAPad + 17] = 0.0f; Bt[lane * kAPad + 18] = 0.0f; Bt[lane * kAPad + 19] = 0.0f;
+        // g_emb row = W1^T g_z1 (rows of W1 read sequentially)
+        float gx[32];
+#pragma unroll
+        for (int f = 0; f < kHin; ++f) gx[f] = 0.0f;
+#pragma unroll
+        for (int o = 0; o < kHid; ++o)
+#pragma unroll
+            for (int f = 0; f < kHin; ++f) gx[f] = __builtin_fmaf(w1[o * kHin + f], gz1[o], gx[f]);
+        head_wave_sync();
+        head_mma<kXPad>(acc0, A, X, lane);            // rows 0..15: gW1 = g_z1^T emb
+        head_mma<kAPad>(acc1, A, Bt, lane);           // row 16: [gW2 | gb2];  column 16 of rows 0..15: gb1
+        head_wave_sync();
+        // g_emb through the (now free) emb tile for coalesced stores
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            *reinterpret_cast<float4 *>(&X[lane * kXPad + 4 * c]) = make_float4(gx[4 * c], gx[4 * c + 1], gx[4 * c + 2], gx[4 * c + 3]);
+        head_wave_sync();
+        {
+            const int lr = lane >> 3, lp = lane & 7;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int r = g * 8 + lr;
+                if (base + r < hi)
+                    reinterpret_cast<float4 *>(g_emb + (base + r) * kHin)[lp] = *reinterpret_cast<const float4 *>(&X[r * kXPad + 4 * lp]);
+            }
+        }
+    }
+    float *out = partial + wave * (int64_t)kHeadPartial;
+    const int c = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        out[r * 32 + c] = acc0[e];
+        out[1024 + r * 32 + c] = acc1[e];
+    }
+}
+
+// ordered sum of the wavefront partials (32 thread groups, then 32 group sums) and routing to the four gradients
+__global__ __launch_bounds__(1024) void head_bwd_finalize_kernel(const float *__restrict__ partial, int64_t nwaves,
+                                                                  float *__restrict__ gW1, float *__restrict__ gb1,
+                                                                  float *__restrict__ gW2, float *__restrict__ gb2)
+{
+    __shared__ float red[32][33];
+    const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + e;            // element of the 2 x [32][32] partial; a block owns one tile row
+    float s = 0.0f;
+    for (int64_t w = grp; w < nwaves; w += 32) s += partial[w * kHeadPartial + idx];
+    red[grp][e] = s;
+    __syncthreads();
+    if (grp != 0) return;
+    s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) s += red[q][e];
+    const int t = idx >> 10, r = (idx & 1023) >> 5, c = idx & 31;
+    if (t == 0) {
+        if (r < kHid) gW1[r * kHin + c] = s;
+    } else {
+        if (r < kHid && c == 16) gb1[r] = s;
+        else if (r == 16 && c < kHid) gW2[c] = s;
+        else if (r == 16 && c == 16) gb2[0] = s;
+    }
+}
+
+inline int64_t head_nodes_per_wave(int64_t N, int64_t *nwaves)
+{
+    const int64_t target = 2048;
+    int64_t npw = (N + target - 1) / target;
+    npw = (npw + 63) / 64 * 64;
+    if (npw < 64) npw = 64;
+    int64_t nw = (N + npw - 1) / npw;
+    nw = (nw + kHeadWaves - 1) / kHeadWaves * kHeadWaves;
+    *nwaves = nw;
+    return npw;
+}
+
+}  // namespace
+}  // namespace dmet
+
+using namespace dmet;
+
+extern "C" int dmet_head_fwd_f32(const float *emb, int64_t N, const float *W1, const float *b1, const float *W2,
+                                 const float *b2, float *out, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0, "dmet_head_fwd_f32: N=%lld", (long long)N);
+    if (N == 0) return 0;
+    DMET_REQUIRE(emb && W1 && b1 && W2 && b2 && out, "dmet_head_fwd_f32: null pointer");
+    DMET_REQUIRE(aligned16(emb), "dmet_head_fwd_f32: emb must be 16-byte aligned");
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), emb, N, W1, b1,
+                       W2, b2, out);
+    DMET_LAUNCH_CHECK("head_fwd_kernel");
+    return 0;
+}
+
+extern "C" size_t dmet_head_bwd_workspace_bytes(int64_t N)
+{
+    if (N <= 0) return 0;
+    int64_t nw;
+    (void)head_nodes_per_wave(N, &nw);
+    return sizeof(float) * (size_t)nw * kHeadPartial + 512;
+}
+
+extern "C" int dmet_head_bwd_f32(const float *emb, int64_t N, const float *W1, const float *b1, const float *W2,
+                                 const float *out, const float *g_out, float *g_emb, float *gW1, float *gb1,
+                                 float *gW2, float *gb2, void *ws, size_t ws_bytes, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N > 0, "dmet_head_bwd_f32: N=%lld", (long long)N);
+    DMET_REQUIRE(emb && W1 && b1 && W2 && out && g_out && g_emb && gW1 && gb1 && gW2 && gb2 && ws,
+                 "dmet_head_bwd_f32: null pointer");
+    DMET_REQUIRE(aligned16(emb) && aligned16(g_emb), "dmet_head_bwd_f32: emb / g_emb must be 16-byte aligned");
+    DMET_REQUIRE(ws_bytes >= dmet_head_bwd_workspace_bytes(N), "dmet_head_bwd_f32: workspace too small");
+    int64_t nw;
+    const int64_t npw = head_nodes_per_wave(N, &nw);
+    float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)(nw / kHeadWaves)), dim3(64 * kHeadWaves), 0, st, emb, N, W1, b1, W2,
+                       out, g_out, npw, g_emb, partial);
+    DMET_LAUNCH_CHECK("head_bwd_kernel");
+    hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(kHeadPartial / 32), dim3(1024), 0, st, partial, nw, gW1, gb1, gW2, gb2);
+    DMET_LAUNCH_CHECK("head_bwd_finalize_kernel");
+    return 0;
+}

@@ -123,3 +123,25 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, residual: Optional[tor
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return _BatchNorm.apply(x, residual, bn.weight, bn.bias, rm, rv, training, float(bn.momentum), float(bn.eps))
+
+
+class _Head(torch.autograd.Function):
+    """sigmoid(Linear(16,1)(ELU(Linear(32,16)(emb)))) per node as one HIP kernel each way (csrc/head.hip)."""
+
+    @staticmethod
+    def forward(ctx, emb, W1, b1, W2, b2):
+        out = _native.head_fwd(emb, [W1.detach(), b1.detach(), W2.detach(), b2.detach()])
+        ctx.save_for_backward(emb, W1, b1, W2, b2, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        emb, W1, b1, W2, b2, out = ctx.saved_tensors
+        g_emb, gW1, gb1, gW2, gb2 = _native.head_bwd(emb, [W1.detach(), b1.detach(), W2.detach(), b2.detach()], out,
+                                                     g_out.contiguous())
+        return g_emb, gW1, gb1, gW2, gb2
+
+
+def head(emb: torch.Tensor, W1: torch.Tensor, b1: torch.Tensor, W2: torch.Tensor, b2: torch.Tensor) -> torch.Tensor:
+    """Per-node weight of model/net.py:46: sigmoid(W2 . ELU(W1 . emb + b1) + b2), [N]."""
+    return _Head.apply(emb, W1, b1, W2, b2)

@@ -79,12 +79,23 @@ class GraphMETNetwork(nn.Module):
         e_cat = _run(self.embed_categorical, torch.cat([e_chrg, e_pdg, e_pv], dim=1))
         return dense.batch_norm(_run(self.encode_all, torch.cat([e_cat, e_cont], dim=1)), self.bn_all)
 
-    def forward(self, x_cont, x_cat, edge_index, batch):
+    def _fused_head_ok(self, emb: torch.Tensor) -> bool:
+        l1, l2 = self.output[0], self.output[2]
+        return (self.fused_encoder and emb.dtype == torch.float32 and emb.shape[1] == 32 and l1.bias is not None
+                and l2.bias is not None and tuple(l1.weight.shape) == (16, 32) and tuple(l2.weight.shape) == (1, 16))
+
+    def forward(self, x_cont, x_cat, edge_index, batch, apply_sigmoid: bool = False):
+        """Per-node logit (graph_met_network.py:60-69); apply_sigmoid=True returns sigmoid(logit) instead (what
+        Net does), which lets the standard head shape run as one HIP kernel each way (csrc/head.hip)."""
         emb = self.embed(x_cont, x_cat)
         for conv, norm in self.conv_continuous:
             msg = conv(emb, batch) if self.graph == "dynamic" else conv(emb, edge_index)
             emb = dense.batch_norm(msg, norm, residual=emb)   # emb + norm(msg) in one streaming kernel
-        return _run(self.output, emb).squeeze(-1)
+        if apply_sigmoid and self._fused_head_ok(emb):
+            l1, l2 = self.output[0], self.output[2]
+            return dense.head(emb, l1.weight, l1.bias, l2.weight, l2.bias)
+        out = _run(self.output, emb).squeeze(-1)
+        return torch.sigmoid(out) if apply_sigmoid else out
 
 
 class Net(nn.Module):
@@ -96,7 +107,7 @@ class Net(nn.Module):
                                         conv_depth=2, graph=graph, k=k, edge_dtype=edge_dtype)
 
     def forward(self, x_cont, x_cat, edge_index, batch):
-        return torch.sigmoid(self.graphnet(x_cont, x_cat, edge_index, batch))
+        return self.graphnet(x_cont, x_cat, edge_index, batch, apply_sigmoid=True)
 
 
 def loss_fn(weights: torch.Tensor, prediction: torch.Tensor, truth: torch.Tensor, batch: torch.Tensor,

@@ -229,6 +229,17 @@ int dmet_bn_bwd_f32(const float *x, const float *g_y, int64_t N, int H, const fl
                     const float *save_invstd, float *g_x, float *g_gamma, float *g_beta, void *ws, size_t ws_bytes,
                     dmet_stream_t stream);
 
+/* ---- N3 (fourth piece): the output head with its sigmoid ---------------------------------------------------
+ * model/graph_met_network.py:41-44,67 + model/net.py:46:  out_i = sigmoid(W2 . ELU(W1 . emb_i + b1) + b2) with
+ * emb[N,32], W1[16,32], b1[16], W2[1,16], b2[1] (torch layouts).  Backward takes the forward output and g_out[N] and
+ * writes g_emb[N,32] and the four parameter gradients (reduced over the nodes deterministically). */
+int dmet_head_fwd_f32(const float *emb, int64_t N, const float *W1, const float *b1, const float *W2, const float *b2,
+                      float *out, dmet_stream_t stream);
+size_t dmet_head_bwd_workspace_bytes(int64_t N);
+int dmet_head_bwd_f32(const float *emb, int64_t N, const float *W1, const float *b1, const float *W2, const float *out,
+                      const float *g_out, float *g_emb, float *gW1, float *gb1, float *gW2, float *gb2, void *ws,
+                      size_t ws_bytes, dmet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -231,7 +231,26 @@ def met_loss(met, truth):
     return 0.5 * (r * r).sum(1).mean().view(1), r / met.shape[0]
 
 
-_NAMES = ["met_loss", "gather_max_bwd_lds", "edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
+def _head_chain(emb, params):
+    W1, b1, W2, b2 = params
+    F = torch.nn.functional
+    return torch.sigmoid(F.linear(F.elu(F.linear(emb, W1, b1)), W2, b2)).squeeze(-1)
+
+
+def head_fwd(emb, params):
+    with torch.no_grad():
+        return _head_chain(emb, params)
+
+
+def head_bwd(emb, params, out, g_out):
+    e = emb.detach().clone().requires_grad_(True)
+    ps = [p.detach().clone().requires_grad_(True) for p in params]
+    with torch.enable_grad():
+        o = _head_chain(e, ps)
+    return list(torch.autograd.grad(o, [e] + ps, g_out))
+
+
+_NAMES = ["head_fwd", "head_bwd", "met_loss", "gather_max_bwd_lds", "edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
           "edge_features_bwd", "segment_max", "segment_sum", "segment_max_bwd", "segment_sum_bwd", "met_reduce",
           "met_reduce_bwd", "segment_sum_1d", "batch_to_ptr", "xty", "onehot_xty", "edgeconv_fused_lds"]
 

@@ -520,6 +520,32 @@ def test_batch_norm_residual_fwd_bwd(dev, N, H, residual, training):
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
 
 
+@pytest.mark.parametrize("N", [1, 64, 65, 5000, 70001])
+def test_fused_head_fwd_bwd(dev, N):
+    """N3: csrc/head.hip vs sigmoid(Linear(ELU(Linear(emb)))) in float64 on the CPU."""
+    from deepmetv2_amd import dense
+    g = torch.Generator().manual_seed(N)
+    emb = torch.randn(N, 32, generator=g)
+    W1, b1 = torch.randn(16, 32, generator=g) * 0.3, torch.randn(16, generator=g) * 0.3
+    W2, b2 = torch.randn(1, 16, generator=g) * 0.5, torch.randn(1, generator=g)
+    gup = torch.randn(N, generator=g)
+    F = torch.nn.functional
+    ref = [t.double().requires_grad_(True) for t in (emb, W1, b1, W2, b2)]
+    o_ref = torch.sigmoid(F.linear(F.elu(F.linear(ref[0], ref[1], ref[2])), ref[3], ref[4])).squeeze(-1)
+    o_ref.backward(gup.double())
+    got = [t.to(dev).requires_grad_(True) for t in (emb, W1, b1, W2, b2)]
+    o = dense.head(*got)
+    o.backward(gup.to(dev))
+    torch.testing.assert_close(o.detach().cpu().double(), o_ref.detach(), rtol=1e-5, atol=1e-6)
+    for a, r, name in zip(got, ref, ["emb", "W1", "b1", "W2", "b2"]):
+        torch.testing.assert_close(a.grad.cpu().double(), r.grad, rtol=1e-4,
+                                   atol=1e-5 * max(1.0, float(r.grad.abs().max())), msg=lambda m, n=name: f"{n}: {m}")
+    got2 = [t.detach().clone().requires_grad_(True) for t in got]
+    dense.head(*got2).backward(gup.to(dev))
+    for a, b in zip(got, got2):
+        assert torch.equal(a.grad, b.grad)
+
+
 def test_dense_linear_embedding_autograd(dev):
     from deepmetv2_amd import dense
     g = torch.Generator().manual_seed(0)
