@@ -177,11 +177,19 @@ struct KnnArgs {
 // tiles cut into sub-sweeps.  order[p] = event at position p; tile_ptr is indexed by position.
 constexpr int kMaxSortedEvents = 4096;  // beyond this the O(B^2) ranking is skipped (identity order)
 
-__global__ __launch_bounds__(256) void knn_plan_kernel(const int64_t *__restrict__ ptr, int B, int tile_queries,
-                                                        int simds, int max_split, int32_t *__restrict__ order,
-                                                        int32_t *__restrict__ pos_of, int32_t *__restrict__ tile_ptr,
-                                                        KnnPlan *__restrict__ plan)
+struct KnnPlanOut {
+    int tile_queries, simds, max_split;
+    int32_t *order, *pos_of, *tile_ptr;
+    KnnPlan *plan;
+};
+
+// blockIdx.x selects one of up to two plans (exact kernel: 128-query tiles; matrix-core filter: 64-query tiles)
+__global__ __launch_bounds__(256) void knn_plan_kernel(const int64_t *__restrict__ ptr, int B, KnnPlanOut o0, KnnPlanOut o1)
 {
+    const KnnPlanOut o = blockIdx.x == 0 ? o0 : o1;
+    const int tile_queries = o.tile_queries, simds = o.simds, max_split = o.max_split;
+    int32_t *__restrict__ order = o.order, *__restrict__ pos_of = o.pos_of, *__restrict__ tile_ptr = o.tile_ptr;
+    KnnPlan *__restrict__ plan = o.plan;
     __shared__ int part[256];
     const int tid = threadIdx.x;
     if (B <= kMaxSortedEvents) {
@@ -720,6 +728,22 @@ __device__ __forceinline__ void filter_select(FilterLane<M> &L, const f32x16 &ac
     }
 }
 
+__device__ __forceinline__ float chain_dist32(const float *__restrict__ xj, const float (&q)[32])
+{
+    const float4 *g = reinterpret_cast<const float4 *>(xj);
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float4 v = g[c];
+        float df;
+        df = v.x - q[4 * c + 0]; acc = __builtin_fmaf(df, df, acc);
+        df = v.y - q[4 * c + 1]; acc = __builtin_fmaf(df, df, acc);
+        df = v.z - q[4 * c + 2]; acc = __builtin_fmaf(df, df, acc);
+        df = v.w - q[4 * c + 3]; acc = __builtin_fmaf(df, df, acc);
+    }
+    return acc;
+}
+
 template <int KP>
 __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(const KnnFilterArgs a)
 {
@@ -810,17 +834,124 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
         }
     }
     filter_drain<M>(L, Q, lane);
-    if (valid) {
-        float *ld;
-        int32_t *lj;
-        if (nsub == 1) {
-            ld = a.fd + (int64_t)myq * MS;
-            lj = a.fj + (int64_t)myq * MS;
-        } else {
-            const int64_t slot = (int64_t)(tile - n_full) * kFQ + hh * 32 + col;
-            ld = a.psd + (slot * nsub + sub) * MS;
-            lj = a.psj + (slot * nsub + sub) * MS;
+    if (nsub == 1) {
+        // ---- whole-sweep items: exact re-rank right here, while the kept candidates still sit in LDS ----------------
+        // Every lane owns one query and <= QF-8 kept candidates (all keys <= tau, ties included, so every dropped
+        // candidate has key >= tau).  Round c handles candidate c of all 64 queries: the rows are fetched cooperatively
+        // (8 lanes x 16 bytes per row: 8 cache lines per load instruction instead of 64) into the LDS space of the
+        // keys (no longer needed), each lane runs the exact R1 chain on its row and inserts (d, j) into its sorted top-k.
+        const int64_t qrow_id = valid ? myq : ev_lo;
+        float qrow[32];
+        {
+            const float4 *g = reinterpret_cast<const float4 *>(a.x + qrow_id * 32);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 v = g[c];
+                qrow[4 * c] = v.x; qrow[4 * c + 1] = v.y; qrow[4 * c + 2] = v.z; qrow[4 * c + 3] = v.w;
+            }
         }
+        float kd[KP];
+        int32_t kj[KP];
+#pragma unroll
+        for (int p = 0; p < KP; ++p) { kd[p] = kKnnSentinel; kj[p] = -1; }
+        constexpr int kRowPad = 36;
+        static_assert(kWave * kRowPad <= QF * kWave, "row staging must fit the key array");
+        float (*rows)[kRowPad] = reinterpret_cast<float (*)[kRowPad]>(&Q.key[0][0]);
+        const int mycnt = valid ? L.cnt : 0;
+        int maxcnt = mycnt;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, off, 64));
+        // the loop is latency bound (load -> LDS -> chain per round): rows are fetched two rounds ahead into registers
+        auto fetch = [&](int c, float4 (&pv)[8], int32_t &jout) {
+            jout = (c < mycnt) ? ev_lo + (int32_t)Q.id[c < QF ? c : 0][lane] : -1;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int32_t jr = __shfl(jout, 8 * r + (lane >> 3), 64);
+                pv[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (jr >= 0) pv[r] = reinterpret_cast<const float4 *>(a.x + (int64_t)jr * 32)[lane & 7];
+            }
+        };
+        auto round = [&](const float4 (&pv)[8], int32_t j, bool have) {
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) *reinterpret_cast<float4 *>(&rows[8 * r + (lane >> 3)][4 * (lane & 7)]) = pv[r];
+            wave_sync();
+            if (have) {
+                float dc = 0.0f;
+#pragma unroll
+                for (int c4 = 0; c4 < 8; ++c4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(&rows[lane][4 * c4]);
+                    float df;
+                    df = v.x - qrow[4 * c4 + 0]; dc = __builtin_fmaf(df, df, dc);
+                    df = v.y - qrow[4 * c4 + 1]; dc = __builtin_fmaf(df, df, dc);
+                    df = v.z - qrow[4 * c4 + 2]; dc = __builtin_fmaf(df, df, dc);
+                    df = v.w - qrow[4 * c4 + 3]; dc = __builtin_fmaf(df, df, dc);
+                }
+                // sorted insert by (d, j) (R2)
+#pragma unroll
+                for (int p = KP - 1; p >= 1; --p) {
+                    const bool gq = kd[p - 1] > dc || (kd[p - 1] == dc && kj[p - 1] > j);
+                    const bool gp = kd[p] > dc || (kd[p] == dc && kj[p] > j);
+                    const float dn = gq ? kd[p - 1] : (gp ? dc : kd[p]);
+                    const int32_t jn = gq ? kj[p - 1] : (gp ? j : kj[p]);
+                    kd[p] = dn; kj[p] = jn;
+                }
+                if (kd[0] > dc || (kd[0] == dc && kj[0] > j)) { kd[0] = dc; kj[0] = j; }
+            }
+        };
+        float4 pa[8], pb[8];
+        int32_t ja = -1, jb = -1;
+        fetch(0, pa, ja);
+        fetch(1, pb, jb);
+        for (int c = 0; c < maxcnt; c += 2) {
+            {
+                float4 cur[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) cur[r] = pa[r];
+                const int32_t jc = ja;
+                if (c + 2 < maxcnt) fetch(c + 2, pa, ja);
+                round(cur, jc, c < mycnt);
+            }
+            if (c + 1 < maxcnt) {
+                float4 cur[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) cur[r] = pb[r];
+                const int32_t jc = jb;
+                if (c + 3 < maxcnt) fetch(c + 3, pb, jb);
+                round(cur, jc, c + 1 < mycnt);
+            }
+        }
+        if (valid) {
+            const int k = a.k;
+            float kth = -1.0f;
+#pragma unroll
+            for (int p = 0; p < KP; ++p) {
+                if (p < k) {
+                    a.nbr[(int64_t)myq * k + p] = kj[p];
+                    a.dist[(int64_t)myq * k + p] = kd[p];
+                }
+                if (p == k - 1 && kj[p] >= 0) kth = kd[p];
+            }
+            // certificate: a list that saw at least M keys dropped only keys >= tau
+            const float tau = L.tk[M - 1];
+            const float nx = a.nrm[myq];
+            const float an = __builtin_sqrtf(nx) * 1.000001f;
+            const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
+            const float slack = 2.0f * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1e-30f;
+            const bool full = tau < kKnnSentinel;
+            if (L.overflow || !fits || (full && !(tau + nx - slack > kth))) {
+                const int xt = a.xtile_ptr[pos] + (myq - ev_lo) / a.xtile_queries;
+                a.qflag[myq] = 1;
+                atomicAdd(a.flags + xt, 1);   // a count: order-independent
+            }
+        }
+        return;
+    }
+    // ---- split (tail) items: hand the partial list to knn_rerank_kernel, which merges the sub-sweeps ---------------
+    if (valid) {
+        const int64_t slot = (int64_t)(tile - n_full) * kFQ + hh * 32 + col;
+        float *ld = a.psd + (slot * nsub + sub) * MS;
+        int32_t *lj = a.psj + (slot * nsub + sub) * MS;
         // keys below the threshold first, then ties at the threshold until the list is full (a dropped tie has
         // key == threshold, which is what the certification assumes of dropped candidates)
         const float tfin = L.tk[M - 1];
@@ -840,21 +971,6 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
     }
 }
 
-__device__ __forceinline__ float chain_dist32(const float *__restrict__ xj, const float (&q)[32])
-{
-    const float4 *g = reinterpret_cast<const float4 *>(xj);
-    float acc = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const float4 v = g[c];
-        float df;
-        df = v.x - q[4 * c + 0]; acc = __builtin_fmaf(df, df, acc);
-        df = v.y - q[4 * c + 1]; acc = __builtin_fmaf(df, df, acc);
-        df = v.z - q[4 * c + 2]; acc = __builtin_fmaf(df, df, acc);
-        df = v.w - q[4 * c + 3]; acc = __builtin_fmaf(df, df, acc);
-    }
-    return acc;
-}
 
 // Exact R1 chain for the kept candidates of one query, top-k by (d, j), certification.  M lanes per query (one kept
 // candidate each; split tiles take a second round), 64 / M queries per wavefront; workgroups of one XCD walk one
@@ -877,8 +993,11 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
     const int qw = lane / M, l = lane - qw * M;          // query slot of the wavefront, lane within the query
     const int slot = wv * QPW + min(qw, QPW - 1);
     // workgroup -> (filter tile, part): the event lookup is per workgroup (wave-uniform: scalar loads), not per lane
-    const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int ft = bid / PARTS, part = bid - ft * PARTS;
+    // no XCD remap here: the grid is a worst-case bound and the live tiles are its first few hundred workgroups,
+    // which the round-robin dispatch already spreads over all XCDs
+    const int bid = blockIdx.x;
+    const int n_full = a.plan->n_full, split = a.plan->split;
+    const int ft = n_full + bid / PARTS, part = bid % PARTS;   // only the split (tail) tiles come here
     if (ft >= a.plan->total_tiles) return;
     const int pos = find_tile_event(a.tile_ptr, a.B, ft);
     const int ev = a.order[pos];
@@ -887,19 +1006,10 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
     const int64_t q = ev_lo + (int64_t)(ft - a.tile_ptr[pos]) * kFQ + qoff;
     const bool active = qw < QPW && qoff < kFQ && q < ev_hi;
     const int64_t qq = active ? q : ev_lo;
-    const int n_full = a.plan->n_full, split = a.plan->split;
-    int nsub = 1;
-    const float *bd;
-    const int32_t *bj;
-    if (ft >= n_full) {
-        nsub = split;
-        const int64_t fslot = (int64_t)(ft - n_full) * kFQ + (active ? qoff : 0);
-        bd = a.psd + fslot * nsub * MS;
-        bj = a.psj + fslot * nsub * MS;
-    } else {
-        bd = a.fd + qq * MS;
-        bj = a.fj + qq * MS;
-    }
+    const int nsub = split;
+    const int64_t fslot = (int64_t)(ft - n_full) * kFQ + (active ? qoff : 0);
+    const float *bd = a.psd + fslot * nsub * MS;
+    const int32_t *bj = a.psj + fslot * nsub * MS;
     const int E = nsub * M;
 
     // issue every independent load up front: the kernel is bound by its chain of dependent memory round trips
@@ -1167,8 +1277,12 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     constexpr int QT = kWave * TQ;
     int simds = num_simds();
     if (simds > kMaxSimds) simds = kMaxSimds;
-    hipLaunchKernelGGL(knn_plan_kernel, dim3(1), dim3(256), 0, st, ptr, B, QT, simds, kMaxSplit, w.order, w.pos_of,
-                       w.tile_ptr, w.plan);
+    bool use_filter = false;
+    if constexpr (DP == 32 && KP <= 16) use_filter = D == 32 && aligned16(x) && filter_mode() != 0;
+    const int slots = simds * 2;   // two filter wavefronts per SIMD
+    const KnnPlanOut px{QT, simds, kMaxSplit, w.order, w.pos_of, w.tile_ptr, w.plan};
+    const KnnPlanOut pf{kFQ, slots, kFilterMaxSplit, w.forder, w.fpos_of, w.ftile_ptr, w.fplan};
+    hipLaunchKernelGGL(knn_plan_kernel, dim3(use_filter ? 2 : 1), dim3(256), 0, st, ptr, B, px, pf);
     DMET_LAUNCH_CHECK("knn_plan_kernel");
     KnnArgs a{x, ptr, B, N, D, k, nbr, dist, w.wsd, w.wsj, w.plan, w.order, w.tile_ptr, w.psd, w.psj, nullptr, 0};
     // uncertified-query counters: zero for every call, so dmet_knn_fallback_stats is meaningful on any path
@@ -1177,13 +1291,9 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     // matrix-core filter + exact re-rank for the hot shape (D = 32, k <= 32); the exact kernel then only recomputes
     // the tiles the re-rank could not certify
     if constexpr (DP == 32 && KP <= 16) {
-        if (D == 32 && aligned16(x) && filter_mode() != 0) {
+        if (use_filter) {
             hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((N * 8 + 255) / 256)), dim3(256), 0, st, x, N, w.nrm, w.xs);
             DMET_LAUNCH_CHECK("knn_prep_kernel");
-            const int slots = simds * 2;   // two filter wavefronts per SIMD
-            hipLaunchKernelGGL(knn_plan_kernel, dim3(1), dim3(256), 0, st, ptr, B, kFQ, slots, kFilterMaxSplit, w.forder,
-                               w.fpos_of, w.ftile_ptr, w.fplan);
-            DMET_LAUNCH_CHECK("knn_plan_kernel");
             KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.xs, w.wsd, w.wsj, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
                             w.psd, w.psj, nbr, dist, w.flags, w.qflag, w.tile_ptr, QT};
             const int64_t ftiles_max = (N + kFQ - 1) / kFQ + B;
@@ -1192,7 +1302,9 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
             DMET_LAUNCH_CHECK("knn_filter_kernel");
             constexpr int kRerankQpb = 4 * (kWave / filter_list_len(KP));
             constexpr int kRerankParts = (kFQ + kRerankQpb - 1) / kRerankQpb;
-            hipLaunchKernelGGL((knn_rerank_kernel<KP>), dim3((unsigned)(ftiles_max * kRerankParts)), dim3(256), 0, st, f);
+            // only the split tail tiles (fewer than `slots`) need the separate re-rank: whole sweeps re-rank in place
+            const int64_t tail_max = ftiles_max < slots ? ftiles_max : slots;
+            hipLaunchKernelGGL((knn_rerank_kernel<KP>), dim3((unsigned)(tail_max * kRerankParts)), dim3(256), 0, st, f);
             DMET_LAUNCH_CHECK("knn_rerank_kernel");
             if (filter_mode() == 2) return 0;
             const int64_t xtiles_max = (N + QT - 1) / QT + B;
