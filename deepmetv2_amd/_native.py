@@ -663,3 +663,38 @@ def head_bwd(emb: torch.Tensor, params, out: torch.Tensor, g_out: torch.Tensor):
                                        *[g.data_ptr() for g in grads], ws.data_ptr(), ws.numel(), _stream(dev)),
                    "dmet_head_bwd_f32")
     return [g_emb] + grads
+
+
+def table_rowptr(nbr: torch.Tensor, cnt: Optional[torch.Tensor]) -> torch.Tensor:
+    """rowptr[N+1] int32: exclusive prefix sum of the number of valid entries per row of a neighbour table."""
+    dev = _require_device(nbr)
+    L = _lib.load()
+    N, k = nbr.shape
+    rowptr = torch.zeros((N + 1,), dtype=torch.int32, device=dev)
+    if N:
+        deg = torch.empty((N,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.dmet_table_degree(nbr.data_ptr(), cnt.data_ptr() if cnt is not None else None, N, k,
+                                           deg.data_ptr(), _stream(dev)), "dmet_table_degree")
+        torch.cumsum(deg, 0, dtype=torch.int32, out=rowptr[1:])
+    return rowptr
+
+
+def table_edges(nbr: torch.Tensor, cnt: Optional[torch.Tensor], rowptr: torch.Tensor, num_edges: int, swap: bool,
+                want_index64: bool, want_int32: bool):
+    """(edge_index [2,E] int64 or None, src32 [E] or None, tgt32 [E] or None) of a neighbour table."""
+    dev = _require_device(nbr, rowptr)
+    L = _lib.load()
+    N, k = nbr.shape
+    ei = torch.empty((2, num_edges), dtype=torch.int64, device=dev) if want_index64 else None
+    s32 = torch.empty((num_edges,), dtype=torch.int32, device=dev) if want_int32 else None
+    t32 = torch.empty((num_edges,), dtype=torch.int32, device=dev) if want_int32 else None
+    if N and num_edges:
+        with torch.cuda.device(dev):
+            _lib.check(L.dmet_table_edges(nbr.data_ptr(), cnt.data_ptr() if cnt is not None else None, rowptr.data_ptr(),
+                                          N, k, 1 if swap else 0,
+                                          ei[0].data_ptr() if ei is not None else None,
+                                          ei[1].data_ptr() if ei is not None else None,
+                                          s32.data_ptr() if s32 is not None else None,
+                                          t32.data_ptr() if t32 is not None else None, _stream(dev)), "dmet_table_edges")
+    return ei, s32, t32

@@ -97,7 +97,7 @@ class _EdgeConvLinearMax(torch.autograd.Function):
         table: NeighborTable = ctx.table
         H = x.shape[1]
         g_out = g_out.contiguous()
-        if H == 32 and g_out.dtype == torch.float32 and table.cnt is None and GATHER_BWD_FORM != "reverse":
+        if H == 32 and g_out.dtype == torch.float32 and table.ptr is not None and GATHER_BWD_FORM != "reverse":
             # per-event LDS scatter with exact integer sums: no reverse index (radix sort) needed
             gQ = _native.gather_max_bwd_lds(g_out, arg, table.nbr, table.ptr)
         else:

@@ -258,3 +258,69 @@ extern "C" int dmet_reverse_index(const int32_t *keys, int64_t M, int64_t num_ke
     DMET_LAUNCH_CHECK("rev_ptr_kernel");
     return 0;
 }
+
+// ---- neighbour table -> edge list (N1/N2: what knn_graph / radius_graph hand back to the caller) ---------------------
+// deg[i] = number of valid (>= 0) entries among the first cnt[i] (or all k) slots of row i.
+__global__ __launch_bounds__(256) void table_degree_kernel(const int32_t *__restrict__ nbr,
+                                                           const int32_t *__restrict__ cnt, int64_t N, int k,
+                                                           int32_t *__restrict__ deg)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int m = cnt ? min(k, cnt[i]) : k;
+    const int32_t *row = nbr + i * k;
+    int d = 0;
+    for (int s = 0; s < m; ++s) d += row[s] >= 0 ? 1 : 0;
+    deg[i] = d;
+}
+
+// Edge e = rowptr[i] + (rank of slot s among the valid slots of row i): first[e] / second[e] = (source, target) of the
+// edge as int64 (flow source_to_target) or swapped; src32 / tgt32 (optional) = the same as int32.
+__global__ __launch_bounds__(256) void table_edges_kernel(const int32_t *__restrict__ nbr,
+                                                          const int32_t *__restrict__ cnt,
+                                                          const int32_t *__restrict__ rowptr, int64_t N, int k,
+                                                          int swap, int64_t *__restrict__ first,
+                                                          int64_t *__restrict__ second, int32_t *__restrict__ src32,
+                                                          int32_t *__restrict__ tgt32)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int m = cnt ? min(k, cnt[i]) : k;
+    const int32_t *row = nbr + i * k;
+    int64_t e = rowptr[i];
+    for (int s = 0; s < m; ++s) {
+        const int32_t j = row[s];
+        if (j >= 0) {
+            if (first) { first[e] = swap ? i : (int64_t)j; second[e] = swap ? (int64_t)j : i; }
+            if (src32) { src32[e] = j; tgt32[e] = (int32_t)i; }
+            ++e;
+        }
+    }
+}
+
+extern "C" int dmet_table_degree(const int32_t *nbr, const int32_t *cnt, int64_t N, int k, int32_t *deg,
+                                 dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && k >= 1, "dmet_table_degree: bad sizes");
+    if (N == 0) return 0;
+    DMET_REQUIRE(nbr && deg, "dmet_table_degree: null pointer");
+    hipLaunchKernelGGL(table_degree_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), nbr, cnt, N,
+                       k, deg);
+    DMET_LAUNCH_CHECK("table_degree_kernel");
+    return 0;
+}
+
+extern "C" int dmet_table_edges(const int32_t *nbr, const int32_t *cnt, const int32_t *rowptr, int64_t N, int k,
+                                int swap, int64_t *first, int64_t *second, int32_t *src32, int32_t *tgt32,
+                                dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && k >= 1, "dmet_table_edges: bad sizes");
+    if (N == 0) return 0;
+    DMET_REQUIRE(nbr && rowptr && ((first && second) || (src32 && tgt32)), "dmet_table_edges: null pointer");
+    DMET_REQUIRE((first == nullptr) == (second == nullptr) && (src32 == nullptr) == (tgt32 == nullptr),
+                 "dmet_table_edges: outputs come in pairs");
+    hipLaunchKernelGGL(table_edges_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), nbr, cnt,
+                       rowptr, N, k, swap, first, second, src32, tgt32);
+    DMET_LAUNCH_CHECK("table_edges_kernel");
+    return 0;
+}

@@ -167,6 +167,7 @@ class NeighborTable:
         self.dense = dense          # True: no -1 entries anywhere (every row has exactly k neighbours)
         self.dist = dist
         self._rev = None
+        self._rp = None
         self._edges = None
         self._edge_index = {}
 
@@ -184,30 +185,30 @@ class NeighborTable:
                 self._rev = (rev_ptr, pos[rev_e[: keys.numel()].long()].contiguous())
         return self._rev
 
+    def _rowptr(self):
+        """(rowptr[N+1] int32, E): one host sync to learn the edge count (upstream returns exact-size tensors too)."""
+        if self._rp is None:
+            if self.dense:
+                N, k = self.num_nodes, self.k
+                self._rp = (torch.arange(0, (N + 1) * k, k, dtype=torch.int32, device=self.nbr.device), N * k)
+            else:
+                rp = _native.table_rowptr(self.nbr, self.cnt)
+                self._rp = (rp, int(rp[-1].item()) if self.num_nodes else 0)
+        return self._rp
+
     def edge_list(self) -> EdgeList:
         if self._edges is None:
-            N, k = self.num_nodes, self.k
-            dev = self.nbr.device
-            tgt_all = torch.arange(N, dtype=torch.int32, device=dev).repeat_interleave(k)
-            src_all = self.nbr.reshape(-1)
-            if self.dense:
-                rowptr = torch.arange(0, (N + 1) * k, k, dtype=torch.int32, device=dev)
-                self._edges = EdgeList(src_all, tgt_all, rowptr, N)
-            else:
-                keep = src_all >= 0
-                deg = keep.view(N, k).sum(1, dtype=torch.int32)
-                rowptr = torch.zeros(N + 1, dtype=torch.int32, device=dev)
-                rowptr[1:] = deg.cumsum(0)
-                self._edges = EdgeList(src_all[keep].contiguous(), tgt_all[keep].contiguous(), rowptr, N)
+            rowptr, E = self._rowptr()
+            _ei, src, tgt = _native.table_edges(self.nbr, self.cnt, rowptr, E, False, False, True)
+            self._edges = EdgeList(src, tgt, rowptr, self.num_nodes)
         return self._edges
 
     def edge_index(self, flow: str = "source_to_target") -> torch.Tensor:
         """int64 [2,E] in PyG orientation (R5); registered so EdgeConv can find this table again."""
         ei = self._edge_index.get(flow)
         if ei is None:
-            el = self.edge_list()
-            src, tgt = el.src.to(torch.int64), el.tgt.to(torch.int64)
-            ei = torch.stack([src, tgt], 0) if flow == "source_to_target" else torch.stack([tgt, src], 0)
+            rowptr, E = self._rowptr()
+            ei, _s, _t = _native.table_edges(self.nbr, self.cnt, rowptr, E, flow != "source_to_target", True, False)
             self._edge_index[flow] = ei
             _registry_put(_graph_registry, ei, (self, flow))
         return ei

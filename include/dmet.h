@@ -171,6 +171,13 @@ int dmet_met_loss_f32(const float *met, const float *truth, int B, float *loss, 
 /* Generic sorted-index form used by the scatter_add(src, batch) drop-in: out[b] = sum_{i in b} src[i]. */
 int dmet_segment_sum_1d_f32(const float *src, const int64_t *ptr, int B, float *out,
                             dmet_stream_t stream);
+/* Neighbour table -> edge list (what knn_graph / radius_graph return): deg[i] = valid entries of row i (among the
+ * first cnt[i] slots when cnt is given); with rowptr = exclusive prefix sum of deg, dmet_table_edges writes the edges
+ * grouped by target i in slot order: first/second [E] int64 = (source, target), or (target, source) when swap != 0,
+ * and/or src32/tgt32 [E] int32. */
+int dmet_table_degree(const int32_t *nbr, const int32_t *cnt, int64_t N, int k, int32_t *deg, dmet_stream_t stream);
+int dmet_table_edges(const int32_t *nbr, const int32_t *cnt, const int32_t *rowptr, int64_t N, int k, int swap,
+                     int64_t *first, int64_t *second, int32_t *src32, int32_t *tgt32, dmet_stream_t stream);
 /* ptr[B+1] from a SORTED int64 batch vector (ptr[b] = first i with batch[i] >= b). */
 int dmet_batch_to_ptr(const int64_t *batch, int64_t N, int B, int64_t *ptr, dmet_stream_t stream);
 

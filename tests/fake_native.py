@@ -250,7 +250,30 @@ def head_bwd(emb, params, out, g_out):
     return list(torch.autograd.grad(o, [e] + ps, g_out))
 
 
-_NAMES = ["head_fwd", "head_bwd", "met_loss", "gather_max_bwd_lds", "edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
+def table_rowptr(nbr, cnt):
+    N, k = nbr.shape
+    valid = nbr >= 0
+    if cnt is not None:
+        valid = valid & (torch.arange(k).view(1, -1) < cnt.view(-1, 1))
+    rowptr = torch.zeros(N + 1, dtype=torch.int32)
+    rowptr[1:] = valid.sum(1).cumsum(0).int()
+    return rowptr
+
+
+def table_edges(nbr, cnt, rowptr, num_edges, swap, want_index64, want_int32):
+    N, k = nbr.shape
+    valid = nbr >= 0
+    if cnt is not None:
+        valid = valid & (torch.arange(k).view(1, -1) < cnt.view(-1, 1))
+    tgt = torch.arange(N, dtype=torch.int32).view(-1, 1).expand(N, k)[valid]
+    src = nbr[valid]
+    ei = None
+    if want_index64:
+        ei = torch.stack([tgt.long(), src.long()] if swap else [src.long(), tgt.long()], 0)
+    return ei, (src.contiguous() if want_int32 else None), (tgt.contiguous() if want_int32 else None)
+
+
+_NAMES = ["table_rowptr", "table_edges", "head_fwd", "head_bwd", "met_loss", "gather_max_bwd_lds", "edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
           "edge_features_bwd", "segment_max", "segment_sum", "segment_max_bwd", "segment_sum_bwd", "met_reduce",
           "met_reduce_bwd", "segment_sum_1d", "batch_to_ptr", "xty", "onehot_xty", "edgeconv_fused_lds"]
 
