@@ -129,7 +129,7 @@ def knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict] = None
     return nbr, dist
 
 
-def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int) -> Tuple[torch.Tensor, torch.Tensor]:
+def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int, skip_self: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     dev = _require_device(x, ptr)
     L = _lib.load()
     x = _f32c(x.detach(), "x")
@@ -138,8 +138,8 @@ def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int) -> Tuple[
     nbr = torch.empty((N, max_nbr), dtype=torch.int32, device=dev)
     cnt = torch.empty((N,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(L.dmet_radius_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, float(r), max_nbr, nbr.data_ptr(),
-                                     cnt.data_ptr(), _stream(dev)), "dmet_radius_f32")
+        _lib.check(L.dmet_radius_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, float(r), max_nbr, 1 if skip_self else 0,
+                                     nbr.data_ptr(), cnt.data_ptr(), _stream(dev)), "dmet_radius_f32")
     return nbr, cnt
 
 

@@ -77,12 +77,10 @@ def radius_table(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None
     x = _check_x(x)
     if x.shape[1] > 8:
         raise ValueError("radius_graph supports up to 8 coordinates")
+    # upstream's loop=False: search max_num_neighbors + 1 and drop the node itself (done inside the kernel)
     m = max_num_neighbors if loop else max_num_neighbors + 1
     info = batch_info(batch, x.shape[0], x.device, num_events)
-    nbr, _cnt = _native.radius(x, info.ptr, r, m)
-    if not loop:
-        self_id = torch.arange(x.shape[0], dtype=torch.int32, device=x.device).view(-1, 1)
-        nbr = torch.where(nbr == self_id, torch.full_like(nbr, -1), nbr)
+    nbr, _cnt = _native.radius(x, info.ptr, r, m, skip_self=not loop)
     return NeighborTable(nbr, info.ptr, dense=False, max_nodes=info.max_nodes, cnt=_cnt)
 
 

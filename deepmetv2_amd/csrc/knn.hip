@@ -1349,55 +1349,91 @@ int dispatch_k(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
 }
 
 // ---- radius graph (N1): first max_nbr candidates in ascending index with d < r^2 ------------------------
-// One lane per query, candidates broadcast from LDS exactly as above; no selection state beyond a counter.
+// One lane per query, four independent wavefronts per workgroup (no workgroup barrier).  Candidates are staged per
+// wavefront in LDS as [pair][feature][2] so that one broadcast read yields a feature of two candidates in adjacent
+// registers: the R1 chain then runs on v_pk_add_f32 / v_pk_fma_f32 (each half an exact IEEE op in feature order, same
+// bits as the scalar oracle).  The table is pre-filled with -1 by a memset; the kernel only writes the hits.
+// `skip_self` reproduces upstream's loop=False: the search limit counts the node itself, the node is not stored.
+constexpr int kRadTile = 64;   // candidates per LDS tile and wavefront
+
 template <int DP>
-__global__ __launch_bounds__(kWave) void radius_kernel(const float *__restrict__ x,
-                                                        const int64_t *__restrict__ ptr, int B, int64_t N, int D,
-                                                        float r2, int max_nbr, int32_t *__restrict__ nbr,
-                                                        int32_t *__restrict__ cntout)
+__global__ __launch_bounds__(kWave * 4) void radius_kernel(const float *__restrict__ x,
+                                                            const int64_t *__restrict__ ptr, int B, int64_t N, int D,
+                                                            float r2, int max_nbr, int skip_self,
+                                                            int32_t *__restrict__ nbr, int32_t *__restrict__ cntout)
 {
-    __shared__ float tile[kTileC * DP];
-    const int lane = threadIdx.x;
-    const int64_t q_first = (int64_t)blockIdx.x * kWave;
+    __shared__ f2 tile_all[4][(kRadTile / 2) * DP];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f2 *tile = tile_all[wv];
+    const int64_t q_first = ((int64_t)blockIdx.x * 4 + wv) * kWave;
     if (q_first >= N) return;
     const int64_t q_last = min(N, q_first + kWave) - 1;
     const int b_first = find_event(ptr, B, q_first);
     const int b_last = find_event(ptr, B, q_last);
     const int clo = (int)ptr[b_first];
     const int chi = (int)ptr[b_last + 1];
+    const bool one_event = b_first == b_last;          // wave-uniform: no per-lane event window needed
     const int64_t qi = q_first + lane;
     const bool valid = qi < N;
     const int64_t qq = valid ? qi : q_last;
-    int lo = 0, hi = 0;
-    if (valid) { const int b = find_event(ptr, B, qq); lo = (int)ptr[b]; hi = (int)ptr[b + 1]; }
-    float q[DP];
+    int lo = clo, hi = chi;
+    if (!one_event) { const int b = find_event(ptr, B, qq); lo = (int)ptr[b]; hi = (int)ptr[b + 1]; }
+    f2 q[DP];
 #pragma unroll
-    for (int c = 0; c < DP; ++c) q[c] = (c < D) ? x[qq * D + c] : 0.0f;
-    int cnt = 0;
+    for (int c = 0; c < DP; ++c) { const float v = (c < D) ? x[qq * D + c] : 0.0f; q[c].x = v; q[c].y = v; }
+    int stored = 0, seen = valid ? 0 : max_nbr;        // idle lanes are "full" from the start
     int32_t *row = nbr + qq * max_nbr;
-    for (int c0 = clo; c0 < chi; c0 += kTileC) {
-        const int cntc = min(kTileC, chi - c0);
-        __syncthreads();
-        for (int e = lane; e < kTileC * DP; e += kWave) {
+    // hits are rare per lane (a few per thousand pairs): the sweep of a 64-candidate tile only records them as bits
+    // of a lane-private 64-bit mask (compare + select + or per candidate, no branch, no memory traffic); the set
+    // bits are turned into row entries after the tile, in ascending candidate order
+    for (int c0 = clo; c0 < chi; c0 += kRadTile) {
+        const int cntc = min(kRadTile, chi - c0);
+        wave_sync();
+        for (int e = lane; e < kRadTile * DP; e += kWave) {
             const int c = e / DP, dd = e - c * DP;
-            tile[e] = (c < cntc && dd < D) ? x[(int64_t)(c0 + c) * D + dd] : 0.0f;
+            // rows past the range get a coordinate that is farther than any radius from everything
+            const float v = (c < cntc) ? ((dd < D) ? x[(int64_t)(c0 + c) * D + dd] : 0.0f) : 3.0e18f;
+            reinterpret_cast<float *>(tile)[((c >> 1) * DP + dd) * 2 + (c & 1)] = v;
         }
-        __syncthreads();
-        for (int cc = 0; cc < cntc; ++cc) {
-            float acc = 0.0f;
+        wave_sync();
+        if (!__any(seen < max_nbr)) break;             // every query of the wavefront is full
+        unsigned m0 = 0u, m1 = 0u;
+#pragma unroll
+        for (int cc = 0; cc < kRadTile; cc += 2) {
+            f2 acc = {0.0f, 0.0f};
 #pragma unroll
             for (int c = 0; c < DP; ++c) {
-                const float df = tile[cc * DP + c] - q[c];
-                acc = __builtin_fmaf(df, df, acc);
+                const f2 df = tile[(cc >> 1) * DP + c] - q[c];
+                acc = __builtin_elementwise_fma(df, df, acc);
             }
-            const int j = c0 + cc;
-            if (valid && j >= lo && j < hi && acc < r2 && cnt < max_nbr) { row[cnt] = j; ++cnt; }
+            if (cc < 32) {
+                m0 |= (acc.x < r2) ? (1u << cc) : 0u;
+                m0 |= (acc.y < r2) ? (1u << (cc + 1)) : 0u;
+            } else {
+                m1 |= (acc.x < r2) ? (1u << (cc - 32)) : 0u;
+                m1 |= (acc.y < r2) ? (1u << (cc - 31)) : 0u;
+            }
+        }
+        unsigned long long mask = ((unsigned long long)m1 << 32) | m0;
+        if (!one_event) {                               // keep the candidates of the lane's own event only
+            const int a0 = max(lo - c0, 0), a1 = min(hi - c0, 64);
+            const unsigned long long keep = (a1 <= a0) ? 0ull
+                : ((a1 >= 64 ? ~0ull : ((1ull << a1) - 1ull)) & ~((1ull << a0) - 1ull));
+            mask &= keep;
+        }
+        while (__any(mask != 0ull)) {
+            if (mask != 0ull) {
+                const int bit = __ffsll((long long)mask) - 1;
+                mask &= mask - 1ull;
+                const int j = c0 + bit;
+                if (seen < max_nbr) {
+                    if (!(skip_self && j == (int)qq)) { row[stored] = j; ++stored; }
+                    ++seen;
+                }
+            }
         }
     }
-    if (valid) {
-        for (int p = cnt; p < max_nbr; ++p) row[p] = -1;
-        cntout[qi] = cnt;
-    }
+    if (valid) cntout[qi] = stored;
 }
 
 }  // namespace
@@ -1449,7 +1485,7 @@ extern "C" int dmet_knn_fallback_stats(const void *ws, int64_t N, int B, int D, 
 }
 
 extern "C" int dmet_radius_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr,
-                               int32_t *nbr, int32_t *cnt, dmet_stream_t stream)
+                               int skip_self, int32_t *nbr, int32_t *cnt, dmet_stream_t stream)
 {
     DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_radius_f32: N out of range");
     DMET_REQUIRE(D >= 1 && D <= 8, "dmet_radius_f32: D=%d not in [1,8]", D);
@@ -1457,17 +1493,20 @@ extern "C" int dmet_radius_f32(const float *x, const int64_t *ptr, int B, int64_
     if (N == 0 || B == 0) return 0;
     DMET_REQUIRE(x && ptr && nbr && cnt, "dmet_radius_f32: null pointer");
     const float r2 = r * r;
-    const int64_t blocks = (N + kWave - 1) / kWave;
+    const int64_t blocks = (N + 4 * kWave - 1) / (4 * kWave);
     hipStream_t st = as_stream(stream);
+    // empty slots are -1: one coalesced fill instead of per-lane tail stores
+    hipError_t me = hipMemsetAsync(nbr, 0xff, sizeof(int32_t) * (size_t)N * (size_t)max_nbr, st);
+    if (me != hipSuccess) return hip_fail(me, "hipMemsetAsync(nbr)");
     if (D <= 2)
-        hipLaunchKernelGGL((radius_kernel<2>), dim3((unsigned)blocks), dim3(kWave), 0, st, x, ptr, B, N, D, r2,
-                           max_nbr, nbr, cnt);
+        hipLaunchKernelGGL((radius_kernel<2>), dim3((unsigned)blocks), dim3(kWave * 4), 0, st, x, ptr, B, N, D, r2,
+                           max_nbr, skip_self, nbr, cnt);
     else if (D <= 4)
-        hipLaunchKernelGGL((radius_kernel<4>), dim3((unsigned)blocks), dim3(kWave), 0, st, x, ptr, B, N, D, r2,
-                           max_nbr, nbr, cnt);
+        hipLaunchKernelGGL((radius_kernel<4>), dim3((unsigned)blocks), dim3(kWave * 4), 0, st, x, ptr, B, N, D, r2,
+                           max_nbr, skip_self, nbr, cnt);
     else
-        hipLaunchKernelGGL((radius_kernel<8>), dim3((unsigned)blocks), dim3(kWave), 0, st, x, ptr, B, N, D, r2,
-                           max_nbr, nbr, cnt);
+        hipLaunchKernelGGL((radius_kernel<8>), dim3((unsigned)blocks), dim3(kWave * 4), 0, st, x, ptr, B, N, D, r2,
+                           max_nbr, skip_self, nbr, cnt);
     DMET_LAUNCH_CHECK("radius_kernel");
     return 0;
 }

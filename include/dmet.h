@@ -65,8 +65,10 @@ int dmet_knn_fallback_stats(const void *ws, int64_t N, int B, int D, int k, int6
 /* ---- N1: radius graph build ----------------------------------------------------------------------
  * replaces torch_cluster.radius_graph   call sites: train.py:48, evaluate.py:88, plt_weight.py:122
  * For every node i: the FIRST max_nbr nodes j (ascending j) of the same event with d(i,j) < r*r
- * (strict, r*r formed in fp32).  nbr[N,max_nbr] int32 (-1 padded), cnt[N] int32. */
-int dmet_radius_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr,
+ * (strict, r*r formed in fp32).  nbr[N,max_nbr] int32 (-1 padded), cnt[N] int32 = entries stored in the row.
+ * skip_self != 0 reproduces upstream's loop=False (call it with max_nbr = max_num_neighbors + 1): node i counts
+ * towards the search limit when it is met but is not stored. */
+int dmet_radius_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr, int skip_self,
                     int32_t *nbr, int32_t *cnt, dmet_stream_t stream);
 
 /* ---- K2+K3 fused: EdgeConv with nn = Linear(2*Hin -> Hout), aggr = 'max', fixed-width table ---------

@@ -15,7 +15,7 @@ def knn(x, ptr, k):
     return ref_ops.knn_table(x, ptr, k)
 
 
-def radius(x, ptr, r, max_nbr):
+def radius(x, ptr, r, max_nbr, skip_self=False):
     import ctypes  # noqa: F401
     x = x.detach().float().contiguous()
     N, D = x.shape
@@ -24,6 +24,12 @@ def radius(x, ptr, r, max_nbr):
     rc = ref_ops.lib().dmet_oracle_radius_f32(x.data_ptr(), ptr.contiguous().data_ptr(), ptr.numel() - 1, D, float(r),
                                               max_nbr, nbr.data_ptr(), cnt.data_ptr())
     assert rc == 0
+    if skip_self:   # upstream's loop=False: the node counts towards the limit but is not stored
+        self_id = torch.arange(N, dtype=torch.int32).view(-1, 1)
+        keep = (nbr != self_id) & (nbr >= 0)
+        order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)
+        nbr = torch.gather(torch.where(keep, nbr, torch.full_like(nbr, -1)), 1, order)
+        cnt = keep.sum(1).to(torch.int32)
     return nbr, cnt
 
 
