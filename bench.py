@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--ragged", type=int, nargs=2, metavar=("LO", "HI"), default=None,
                     help="BASELINE configs[4]: event sizes drawn uniformly from [LO, HI] (seeded) instead of --nodes")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="replay the step as two hipGraphs around the gradient all-reduce (launch-bound small batches; "
+                         "per-kernel HIP-event timing, hence the roofline block, is not available in this mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-events", type=int, default=0, help="0 = one event per host core (max 16)")
     return ap.parse_args()
@@ -139,7 +142,7 @@ def main():
     flat = FlatModule(model)
     sync = GradSync(flat)
     sync.broadcast_state(0)
-    opt = torch.optim.AdamW([flat.flat_param], lr=1e-3)
+    opt = torch.optim.AdamW([flat.flat_param], lr=1e-3, capturable=args.hip_graph)
 
     if args.mode == "train":
         model.train()
@@ -151,8 +154,14 @@ def main():
             etaphi = torch.cat([x[:, 3][:, None], phi[:, None]], dim=1)
             return dm.radius_graph(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255)
 
-        def step():
-            return train_step(model, flat, sync, opt, x, y, batch, ptr, edge_index=static_graph())
+        if args.hip_graph:
+            if args.graph != "dynamic":
+                raise SystemExit("--hip-graph: the static flow sizes its edge_index on the host (one sync per step)")
+            from deepmetv2_amd.parallel import GraphedTrainStep
+            step = GraphedTrainStep(model, flat, sync, opt, x, y, batch, ptr)
+        else:
+            def step():
+                return train_step(model, flat, sync, opt, x, y, batch, ptr, edge_index=static_graph())
     else:
         model.eval()
 
@@ -237,7 +246,8 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: {B} events/GPU x {n} PF candidates x 11 features, k={k}, "
                                    f"2 DynamicEdgeConv layers (kNN rebuilt per layer in the 32-d embedding), {'fp32' if args.dtype == 'f32' else 'bf16 edge-MLP on MFMA (configs[2])'}, "
                                    f"{args.mode} step", "events_per_gpu": B, "nodes_per_event": n if args.ragged is None else f"U[{args.ragged[0]},{args.ragged[1]}]", "k": k,
-                       "global_batch": B * world, "mode": args.mode, "graph": args.graph, "parallelism": f"dp{world}"},
+                       "global_batch": B * world, "mode": args.mode, "graph": args.graph, "parallelism": f"dp{world}",
+                       "hip_graph": bool(args.hip_graph)},
             "roofline": roof, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

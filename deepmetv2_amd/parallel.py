@@ -125,3 +125,49 @@ def train_step(model: torch.nn.Module, flat: FlatModule, sync: GradSync, optimiz
     sync.average_gradients()
     optimizer.step()
     return loss.detach()
+
+
+class GraphedTrainStep:
+    """The training step as two hipGraphs (torch.cuda.CUDAGraph) around the one collective:
+    graph A = zero_grad .. backward .. gather_grads, then the (eager) gradient all-reduce, then graph B = optimizer
+    step.  Pays off when the step is launch-bound (small batches: ~100 launches per step); at BASELINE config 2 the
+    step is GPU-bound and the two forms time the same.  The inputs are static buffers: refill them with `load`.
+    The optimizer must be built with capturable=True; batch metadata must be registered (no host sync in forward)."""
+
+    def __init__(self, model, flat: FlatModule, sync: GradSync, optimizer, x, y, batch, ptr=None, warmup: int = 3):
+        from .model import loss_fn, split_features
+        self.flat, self.sync, self.opt = flat, sync, optimizer
+        self.x, self.y, self.batch, self.ptr = x, y, batch, ptr
+
+        def fwd_bwd():
+            flat.zero_grad()
+            x_cont, x_cat = split_features(self.x)
+            loss = loss_fn(model(x_cont, x_cat, None, self.batch), self.x, self.y, self.batch, ptr=self.ptr)
+            loss.backward()
+            flat.gather_grads()
+            return loss.detach()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fwd_bwd()
+                sync.average_gradients()
+                optimizer.step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a):
+            self.loss = fwd_bwd()
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b):
+            optimizer.step()
+
+    def load(self, x, y) -> None:
+        """Copy a new batch of the same shape into the captured input buffers."""
+        self.x.copy_(x); self.y.copy_(y)
+
+    def __call__(self) -> torch.Tensor:
+        self.graph_a.replay()
+        self.sync.average_gradients()
+        self.graph_b.replay()
+        return self.loss

@@ -566,6 +566,46 @@ def test_dense_linear_embedding_autograd(dev):
         torch.testing.assert_close(a, r, rtol=1e-4, atol=1e-4 * max(1.0, float(r.abs().max())))
 
 
+def test_graphed_train_step_matches_eager(dev):
+    """H1: the step replayed as two hipGraphs (parallel.GraphedTrainStep) walks the same parameter trajectory as the
+    eager step (every kernel on the path is deterministic, so the comparison is bitwise)."""
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import synth
+    from deepmetv2_amd.model import Net
+    from deepmetv2_amd.parallel import FlatModule, GradSync, GraphedTrainStep, train_step
+    sizes = [700, 90, 1300]
+    x, y, batch, ptr = synth.make_events(sizes, seed=5, device=dev)
+    dm.register_batch(batch, ptr, len(sizes), max_nodes=max(sizes))
+    finals = []
+    for graphed in (False, True):
+        torch.manual_seed(1)
+        model = Net(8, 3, graph="dynamic", k=16).to(dev).train()
+        flat = FlatModule(model); sync = GradSync(flat)
+        opt = torch.optim.AdamW([flat.flat_param], lr=1e-3, capturable=True)
+        if graphed:
+            p0 = flat.flat_param.detach().clone()
+            bufs0 = [b.detach().clone() for b in model.buffers()]
+            step = GraphedTrainStep(model, flat, sync, opt, x, y, batch, ptr, warmup=1)
+            # capture ran warm-up steps: rewind parameters, buffers and optimizer state
+            with torch.no_grad():
+                flat.flat_param.copy_(p0)
+                for b, b0 in zip(model.buffers(), bufs0):
+                    b.copy_(b0)
+                for st in opt.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
+            for _ in range(3):
+                loss = step()
+        else:
+            for _ in range(3):
+                loss = train_step(model, flat, sync, opt, x, y, batch, ptr)
+        torch.cuda.synchronize()
+        finals.append((flat.flat_param.detach().clone(), float(loss)))
+    assert finals[0][1] == finals[1][1]
+    assert torch.equal(finals[0][0], finals[1][0])
+
+
 def test_ops_fail_loudly_without_gpu_tensor(dev):
     import deepmetv2_amd as dm
     with pytest.raises(RuntimeError, match="non-GPU tensor"):
