@@ -479,6 +479,43 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
         }
         float bx = ninf, by = ninf, bz = ninf, bw = ninf;
         int a0 = 255, a1 = 255, a2 = 255, a3 = 255;
+        if (WITH_ARG && GML_MODE != 2 && K4 <= 4) {
+            // all 4*K4 rows of the node in registers (k <= 16; wider tables keep the chain below); max by v_max3 (half an op per value), then the winning slot by an
+            // equality scan from the last slot down, so the LOWEST slot among equal maxima is written last (R4):
+            // 2.5 VALU ops per value instead of the 3 of a compare/select/select chain
+            float4 v[4 * K4];
+#pragma unroll
+            for (int u = 0; u < 4 * K4; ++u) v[u] = qs[off[u]];
+#pragma unroll
+            for (int u = 0; u < 4 * K4; u += 2) {
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(bx) : "v"(v[u].x), "v"(v[u + 1].x));
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(by) : "v"(v[u].y), "v"(v[u + 1].y));
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(bz) : "v"(v[u].z), "v"(v[u + 1].z));
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(bw) : "v"(v[u].w), "v"(v[u + 1].w));
+            }
+#define DMET_EQ_ARG(best, a, val, slot)                                                                           \
+    asm("v_cmp_eq_f32 vcc, %1, %2\n\tv_cndmask_b32_e64 %0, %0, %3, vcc" : "+v"(a) : "v"(val), "v"(best), "n"(slot) : "vcc")
+#define DMET_EQ_CASE(S_) case S_: DMET_EQ_ARG(bx, a0, v[S_].x, S_); DMET_EQ_ARG(by, a1, v[S_].y, S_); \
+                                  DMET_EQ_ARG(bz, a2, v[S_].z, S_); DMET_EQ_ARG(bw, a3, v[S_].w, S_); break;
+#pragma unroll
+            for (int u = 4 * K4 - 1; u >= 0; --u) {
+                switch (u) {   // the slot must be an immediate
+                    DMET_EQ_CASE(0) DMET_EQ_CASE(1) DMET_EQ_CASE(2) DMET_EQ_CASE(3) DMET_EQ_CASE(4) DMET_EQ_CASE(5)
+                    DMET_EQ_CASE(6) DMET_EQ_CASE(7) DMET_EQ_CASE(8) DMET_EQ_CASE(9) DMET_EQ_CASE(10) DMET_EQ_CASE(11)
+                    DMET_EQ_CASE(12) DMET_EQ_CASE(13) DMET_EQ_CASE(14) DMET_EQ_CASE(15) DMET_EQ_CASE(16)
+                    DMET_EQ_CASE(17) DMET_EQ_CASE(18) DMET_EQ_CASE(19) DMET_EQ_CASE(20) DMET_EQ_CASE(21)
+                    DMET_EQ_CASE(22) DMET_EQ_CASE(23) DMET_EQ_CASE(24) DMET_EQ_CASE(25) DMET_EQ_CASE(26)
+                    DMET_EQ_CASE(27) DMET_EQ_CASE(28) DMET_EQ_CASE(29) DMET_EQ_CASE(30) DMET_EQ_CASE(31)
+                }
+            }
+#undef DMET_EQ_CASE
+#undef DMET_EQ_ARG
+            // a channel whose maximum is still -inf had no valid neighbour (all of them then): slot 255
+            if (!(bx > ninf)) a0 = 255;
+            if (!(by > ninf)) a1 = 255;
+            if (!(bz > ninf)) a2 = 255;
+            if (!(bw > ninf)) a3 = 255;
+        } else {
 #pragma unroll
         for (int q0 = 0; q0 < (GML_MODE == 2 ? 0 : K4); q0 += 2) {
             float4 v[8];
@@ -503,6 +540,7 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
                     DMET_MAX_ONLY(bz, v[u].z); DMET_MAX_ONLY(bw, v[u].w);
                 }
             }
+        }
         }
         const bool any = WITH_ARG ? (a0 != 255) : (bx > ninf);
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
