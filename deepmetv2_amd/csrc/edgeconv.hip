@@ -378,6 +378,34 @@ constexpr int kLdsGatherRows = kLdsGatherBytes / (kSliceC * 4);  // 5120 rows: e
         : "+v"(best), "+v"(a) : "v"(v), "n"(slot) : "vcc")
 #define DMET_MAX_ONLY(best, v) asm("v_max_f32 %0, %0, %1" : "+v"(best) : "v"(v))
 
+// The two lanes of a node need the same k ids: each loads one half of the row and the halves are swapped between
+// the lane pair with DPP (quad_perm [1,0,3,2]) -- half the id requests through the texture path.
+__device__ __forceinline__ int dpp_swap_pair(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);   // quad_perm: lane ^ 1
+}
+
+template <int K4>
+__device__ __forceinline__ void load_ids_pair(int4 (&ids)[K4], const int4 *__restrict__ row4, int half)
+{
+    if (K4 % 2 != 0) {
+#pragma unroll
+        for (int q = 0; q < K4; ++q) ids[q] = row4[q];
+        return;
+    }
+    int4 mine[K4 / 2];
+#pragma unroll
+    for (int q = 0; q < K4 / 2; ++q) mine[q] = row4[half * (K4 / 2) + q];
+#pragma unroll
+    for (int q = 0; q < K4 / 2; ++q) {
+        int4 other;
+        other.x = dpp_swap_pair(mine[q].x); other.y = dpp_swap_pair(mine[q].y);
+        other.z = dpp_swap_pair(mine[q].z); other.w = dpp_swap_pair(mine[q].w);
+        ids[q] = half ? other : mine[q];
+        ids[K4 / 2 + q] = half ? mine[q] : other;
+    }
+}
+
 // K4 = number of int4 id loads per node (k == 4*K4).  LDS image: rows 0..n-1 = the event's Q slice, row n = -inf
 // (ids < 0 and anything outside the event map to it, so the gather needs no per-neighbour branch).  Per node all
 // 4*K4 LDS reads are issued before the compare chain; the next node's ids and P slice are prefetched meanwhile.
@@ -451,8 +479,7 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r0 < n) {
         const int4 *row4 = reinterpret_cast<const int4 *>(nbr + (int64_t)(lo + r0) * k);
-#pragma unroll
-        for (int q = 0; q < K4; ++q) ids[q] = row4[q];
+        load_ids_pair<K4>(ids, row4, half);
         pv = P4[(int64_t)(lo + r0) * h4 + col4];
     }
     __builtin_amdgcn_s_waitcnt(0);   // LDS-DMA is counted by vmcnt and is not covered by the barrier itself
@@ -473,8 +500,7 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
         const float4 p = pv;
         if (r + RPI < n) {
             const int4 *row4 = reinterpret_cast<const int4 *>(nbr + (node + RPI) * k);
-#pragma unroll
-            for (int q = 0; q < K4; ++q) ids[q] = row4[q];
+            load_ids_pair<K4>(ids, row4, half);
             pv = P4[(node + RPI) * h4 + col4];
         }
         float bx = ninf, by = ninf, bz = ninf, bw = ninf;
@@ -535,9 +561,11 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
                         DMET_CASE(31)
 #undef DMET_CASE
                     }
-                } else {
-                    DMET_MAX_ONLY(bx, v[u].x); DMET_MAX_ONLY(by, v[u].y);
-                    DMET_MAX_ONLY(bz, v[u].z); DMET_MAX_ONLY(bw, v[u].w);
+                } else if ((u & 1) == 0) {   // two rows per v_max3_f32
+                    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(bx) : "v"(v[u].x), "v"(v[u + 1].x));
+                    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(by) : "v"(v[u].y), "v"(v[u + 1].y));
+                    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(bz) : "v"(v[u].z), "v"(v[u + 1].z));
+                    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(bw) : "v"(v[u].w), "v"(v[u + 1].w));
                 }
             }
         }
