@@ -138,9 +138,15 @@ __global__ __launch_bounds__(1024) void edgeconv_linear_bwd_finalize_kernel(cons
     const bool bias = blockIdx.x == 32;
     const int idx = bias ? (2048 + e) : (blockIdx.x * 32 + e);
     float s0 = 0.0f, s1 = 0.0f;
-    for (int64_t w = grp; w < nwaves; w += 32) {
-        s0 += partial[w * kPartial + idx];
-        if (!bias) s1 += partial[w * kPartial + 1024 + idx];
+    if (bias) {
+#pragma unroll 8   // independent loads: keep eight in flight (the sum order is unchanged)
+        for (int64_t w = grp; w < nwaves; w += 32) s0 += partial[w * kPartial + idx];
+    } else {
+#pragma unroll 8
+        for (int64_t w = grp; w < nwaves; w += 32) {
+            s0 += partial[w * kPartial + idx];
+            s1 += partial[w * kPartial + 1024 + idx];
+        }
     }
     red0[grp][e] = s0; red1[grp][e] = s1;
     __syncthreads();

@@ -296,6 +296,7 @@ __global__ __launch_bounds__(1024) void encode_bwd_finalize_kernel(const float *
     const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int idx = blockIdx.x * 32 + e;
     float s = 0.0f;
+#pragma unroll 8   // independent loads: keep eight in flight (the sum order is unchanged)
     for (int64_t w = grp; w < nwaves; w += 32) s += partial[w * kEncPartial + idx];
     red[grp][e] = s;
     __syncthreads();

@@ -74,6 +74,7 @@ __device__ __forceinline__ void bn_combine(const float *__restrict__ partial, in
     const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
     double a = 0.0, b = 0.0;
     if (c < H)
+#pragma unroll 8   // independent loads: keep eight in flight (the sum order is unchanged)
         for (int blk = grp; blk < nblocks; blk += 16) {
             a += (double)partial[(int64_t)blk * 2 * H + c];
             b += (double)partial[(int64_t)blk * 2 * H + H + c];
