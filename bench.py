@@ -179,6 +179,9 @@ def main():
     for _ in range(args.warmup):
         step()
     ev_overhead_ms = _native.timer.calibrate(dev)
+    # inside the timed region only the graded kernel is bracketed (a bracket is two extra stream commands, ~5-10 us
+    # of GPU idle each); the other native calls are bracketed in a few extra, untimed steps afterwards
+    _native.timer.only = {"gather_max", "edgeconv_fused"}
     _native.timer.enabled = True
     _native.timer.reset()
     barrier()
@@ -189,6 +192,16 @@ def main():
     elapsed = time.perf_counter() - t0
     _native.timer.enabled = False
     ksum = _native.timer.summary()
+    if not args.hip_graph:
+        _native.timer.only = None
+        _native.timer.enabled = True
+        _native.timer.reset()
+        for _ in range(min(5, args.steps)):
+            step()
+        torch.cuda.synchronize(dev)
+        _native.timer.enabled = False
+        for name, v in _native.timer.summary().items():
+            ksum.setdefault(name, v)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -49,13 +49,14 @@ class KernelTimer:
 
     def __init__(self):
         self.enabled = False
+        self.only = None        # optional set of names: bracket just these (every bracket costs two stream commands)
         self._pending = {}
 
     def reset(self) -> None:
         self._pending = {}
 
     def record(self, name: str, dev: torch.device):
-        if not self.enabled:
+        if not self.enabled or (self.only is not None and name not in self.only):
             return None
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
