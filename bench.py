@@ -92,7 +92,7 @@ def cpu_baseline(args, seed: int):
         if args.mode == "train":
             loss.backward()
             opt.step()
-        return float(loss)
+        return float(loss.detach())
 
     step()  # warm-up (builds the C oracle, pages in)
     reps, t0 = 0, time.perf_counter()
@@ -103,6 +103,44 @@ def cpu_baseline(args, seed: int):
     return {"value": n_ev / dt, "unit": "events/s", "cores": cores, "kind": "port",
             "sample": f"{n_ev} events x {args.nodes} nodes, k={args.k}, 2 layers, {args.mode} step, {reps} reps "
                       f"({dt:.2f} s/step); oracle/ref_model.py + C kNN (OpenMP over events) on {cores} threads"}
+
+
+def parity_sample(args, model, dev, seed: int):
+    """The second half of BASELINE.json's metric, on a bounded sample: MET px/py MSE of the HIP path against the CPU
+    oracle (same weights, same seeded events, train-mode BatchNorm statistics) and the number of kNN index mismatches
+    of the first layer's graph against the C oracle (must be 0)."""
+    import torch
+
+    from deepmetv2_amd import _native, synth
+    from deepmetv2_amd.model import split_features
+    from deepmetv2_amd.scatter import met_reduce
+    from oracle import ref_model, ref_ops
+
+    n_ev = 4
+    x, y, batch, ptr = synth.make_events([args.nodes] * n_ev, seed=seed)
+    ref = ref_model.RefNet(8, 3, graph="dynamic", k=args.k)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    ref.train()
+    was_training = model.training
+    model.train()
+    saved = {k: v.detach().clone() for k, v in model.state_dict().items()}   # running statistics are touched below
+    with torch.no_grad():
+        xd, bd, pd = x.to(dev), batch.to(dev), ptr.to(dev)
+        w = model(*split_features(xd), None, bd)
+        met = met_reduce(w, xd, ptr=pd).cpu()
+        emb = model.graphnet.embed(*split_features(xd)).contiguous()
+        nbr, _ = _native.knn(emb, pd, args.k)
+        w_ref = ref(*split_features(x), None, batch)
+        met_ref = ref_ops.met_sums_f64(w_ref, x, ptr)          # float64 sums of the oracle's weights
+        nbr_ref, _ = ref_ops.knn_table(emb.cpu(), ptr, args.k)
+    model.load_state_dict(saved)
+    model.train(was_training)
+    d = met.double() - met_ref.double()
+    scale = float((w_ref.double().abs() * x[:, :2].double().abs().sum(1)).sum() / n_ev)
+    return {"sample": f"{n_ev} events x {args.nodes} nodes, k={args.k}, full 2-layer forward, same weights",
+            "met_mse_vs_ref": float((d * d).sum(1).mean() / 2.0),
+            "met_max_abs_diff": float(d.abs().max()), "met_sum_abs_wp_per_event": scale,
+            "knn_index_mismatches": int((nbr.cpu() != nbr_ref).sum())}
 
 
 def main():
@@ -265,6 +303,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, seed=1234)
+            if args.graph == "dynamic" and args.dtype == "f32":
+                out["parity"] = parity_sample(args, model, dev, seed=4321)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
