@@ -524,14 +524,19 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const KnnArgs a, int til
 // Certification only has to rule out dropped candidates that could beat the k-th kept distance d_k: such a candidate
 // has b <= R_i = a + sqrt(d_k) (otherwise d >= (b - a)^2 > d_k already), so the slack is e_i = 2 E(a, R_i) (2x margin)
 // and depends on the query alone -- an outlier with a huge norm elsewhere in the event does not loosen it.
-//   1. knn_filter_kernel: every query keeps, per partial list (two half-row lanes x candidate sub-sweeps), the KP
-//      smallest keys.
-//   2. knn_rerank_kernel: the exact R1 chain for the <= 2*split*KP kept candidates, top-k by (d, j) (R2).  It is THE
-//      exact answer iff nothing that could belong to the top k was dropped: a dropped candidate of a full list has
-//      key >= that list's largest kept key w, hence d >= w + |x_i|^2 - e_i; if that exceeds the k-th smallest exact
-//      distance among the kept candidates for every full list, the kept top-k is the global top-k.
-//   3. Queries that fail the test (exact ties beyond the list length, duplicates, lattices) are recomputed exactly:
-//      one wavefront per query when a 128-query tile has few of them, the exact tile kernel above otherwise.
+// R1/R2 stay the definition of the RESULT: every returned (d, j) comes from the exact fmaf chain and the (d, j) order;
+// the expansion above only decides which pairs the exact chain is run for, under the proven bound.
+//   1. knn_filter_kernel, sweep: every query (one lane) keeps the M = k + 4 smallest keys of its candidate range and
+//      the candidates themselves (ties at the threshold included) in LDS.
+//   2. exact re-rank: the R1 chain for the kept candidates, top-k by (d, j) (R2) -- in the tail of the filter kernel
+//      for whole-sweep items, in knn_rerank_kernel for the tail tiles whose candidate range was split over two
+//      work items.  It is THE exact answer iff nothing that could belong to the top k was dropped: a dropped
+//      candidate has key >= the list's threshold tau, hence d >= tau + |x_i|^2 - e_i; if that exceeds the k-th
+//      smallest exact distance among the kept candidates (for every partial list that saw at least M keys), the kept
+//      top-k is the global top-k.
+//   3. Queries that fail the test (exact ties beyond the list length, duplicates, lattices, events of more than
+//      65535 nodes) are recomputed exactly: one workgroup per query when a 128-query tile has few of them, the exact
+//      tile kernel above otherwise.
 // Result: bit-identical output at a fraction of the VALU work.
 constexpr int kFQ = 64;             // queries per filter work item: two 32-column MFMA blocks
 constexpr int kFilterMaxSplit = 2;  // tail balancing of the filter: at most 2 candidate sub-sweeps (the re-rank assumes 2)
