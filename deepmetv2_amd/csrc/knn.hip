@@ -656,7 +656,7 @@ struct FilterLane {
     bool overflow;
 };
 
-constexpr int filter_list_len(int KP) { return KP + (KP / 4 > 4 ? KP / 4 : 4); }   // M: k=16 -> 20, k=8 -> 12
+constexpr int filter_list_len(int KP) { return KP + 4; }   // M = kept keys per list: result capacity KP (>= k) + 4
 constexpr int filter_queue_len(int M) { return M + 28; }
 
 // LDS queue of one wavefront: keys and 16-bit event-relative candidate ids in separate arrays (6 bytes per entry:
@@ -1274,6 +1274,26 @@ inline int filter_mode()
     return (e && strcmp(e, "exact") == 0) ? 0 : (e && strcmp(e, "filter_only") == 0) ? 2 : 1;
 }
 
+// prep + filter (+ in-place re-rank) + re-rank of the split tail tiles, for result capacity KF >= k
+template <int KF>
+int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, hipStream_t st)
+{
+    const int slots = simds * 2;   // two filter wavefronts per SIMD
+    hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((f.N * 8 + 255) / 256)), dim3(256), 0, st, f.x, f.N, w.nrm, w.xs);
+    DMET_LAUNCH_CHECK("knn_prep_kernel");
+    const int64_t ftiles_max = (f.N + kFQ - 1) / kFQ + f.B;
+    const int64_t fblocks = (ftiles_max + slots + kWavesPerGroup - 1) / kWavesPerGroup;
+    hipLaunchKernelGGL((knn_filter_kernel<KF>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
+    DMET_LAUNCH_CHECK("knn_filter_kernel");
+    constexpr int kRerankQpb = 4 * (kWave / filter_list_len(KF));
+    constexpr int kRerankParts = (kFQ + kRerankQpb - 1) / kRerankQpb;
+    // only the split tail tiles (fewer than `slots`) need the separate re-rank: whole sweeps re-rank in place
+    const int64_t tail_max = ftiles_max < slots ? ftiles_max : slots;
+    hipLaunchKernelGGL((knn_rerank_kernel<KF>), dim3((unsigned)(tail_max * kRerankParts)), dim3(256), 0, st, f);
+    DMET_LAUNCH_CHECK("knn_rerank_kernel");
+    return 0;
+}
+
 template <int DP, int KP>
 int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr, float *dist,
                const KnnWorkspace &w, hipStream_t st)
@@ -1283,7 +1303,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     int simds = num_simds();
     if (simds > kMaxSimds) simds = kMaxSimds;
     bool use_filter = false;
-    if constexpr (DP == 32 && KP <= 16) use_filter = D == 32 && aligned16(x) && filter_mode() != 0;
+    if constexpr (DP == 32 && KP <= 32) use_filter = D == 32 && k <= 20 && aligned16(x) && filter_mode() != 0;
     const int slots = simds * 2;   // two filter wavefronts per SIMD
     const KnnPlanOut px{QT, simds, kMaxSplit, w.order, w.pos_of, w.tile_ptr, w.plan};
     const KnnPlanOut pf{kFQ, slots, kFilterMaxSplit, w.forder, w.fpos_of, w.ftile_ptr, w.fplan};
@@ -1293,31 +1313,22 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     // uncertified-query counters: zero for every call, so dmet_knn_fallback_stats is meaningful on any path
     if (hipMemsetAsync(w.flags, 0, w.zero_bytes, st) != hipSuccess) return hip_fail(hipGetLastError(), "hipMemsetAsync");
 
-    // matrix-core filter + exact re-rank for the hot shape (D = 32, k <= 32); the exact kernel then only recomputes
+    // matrix-core filter + exact re-rank for the hot shape (D = 32, k <= 20); the exact kernel then only recomputes
     // the tiles the re-rank could not certify
-    if constexpr (DP == 32 && KP <= 16) {
-        if (use_filter) {
-            hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((N * 8 + 255) / 256)), dim3(256), 0, st, x, N, w.nrm, w.xs);
-            DMET_LAUNCH_CHECK("knn_prep_kernel");
-            KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.xs, w.wsd, w.wsj, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
-                            w.psd, w.psj, nbr, dist, w.flags, w.qflag, w.tile_ptr, QT};
-            const int64_t ftiles_max = (N + kFQ - 1) / kFQ + B;
-            const int64_t fblocks = (ftiles_max + slots + kWavesPerGroup - 1) / kWavesPerGroup;
-            hipLaunchKernelGGL((knn_filter_kernel<KP>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
-            DMET_LAUNCH_CHECK("knn_filter_kernel");
-            constexpr int kRerankQpb = 4 * (kWave / filter_list_len(KP));
-            constexpr int kRerankParts = (kFQ + kRerankQpb - 1) / kRerankQpb;
-            // only the split tail tiles (fewer than `slots`) need the separate re-rank: whole sweeps re-rank in place
-            const int64_t tail_max = ftiles_max < slots ? ftiles_max : slots;
-            hipLaunchKernelGGL((knn_rerank_kernel<KP>), dim3((unsigned)(tail_max * kRerankParts)), dim3(256), 0, st, f);
-            DMET_LAUNCH_CHECK("knn_rerank_kernel");
-            if (filter_mode() == 2) return 0;
-            const int64_t xtiles_max = (N + QT - 1) / QT + B;
-            hipLaunchKernelGGL(knn_requery_kernel, dim3((unsigned)xtiles_max), dim3(256), 0, st, f, w.plan);
-            DMET_LAUNCH_CHECK("knn_requery_kernel");
-            a.flags = w.flags;
-            a.flag_min = kRequeryMax + 1;
-        }
+    if (use_filter) {
+        KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.xs, w.wsd, w.wsj, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
+                        w.psd, w.psj, nbr, dist, w.flags, w.qflag, w.tile_ptr, QT};
+        int rc = 0;
+        if constexpr (KP == 8) rc = launch_filter<8>(f, w, simds, st);
+        else if constexpr (KP == 16) rc = launch_filter<16>(f, w, simds, st);
+        else if constexpr (KP == 32) rc = launch_filter<20>(f, w, simds, st);   // 16 < k <= 20 (checked above)
+        if (rc) return rc;
+        if (filter_mode() == 2) return 0;
+        const int64_t xtiles_max = (N + QT - 1) / QT + B;
+        hipLaunchKernelGGL(knn_requery_kernel, dim3((unsigned)xtiles_max), dim3(256), 0, st, f, w.plan);
+        DMET_LAUNCH_CHECK("knn_requery_kernel");
+        a.flags = w.flags;
+        a.flag_min = kRequeryMax + 1;
     }
 
     // worst-case grid (the plan is on the device): every event adds at most one partial tile, and splitting the

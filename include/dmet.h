@@ -54,7 +54,7 @@ size_t dmet_knn_workspace_bytes(int64_t N, int B, int D, int k);
 int dmet_knn_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,
                  float *dist, void *ws, size_t ws_bytes, dmet_stream_t stream);
 
-/* Diagnostics of the matrix-core kNN path (D = 32, k <= 16): dmet_knn_f32 first ranks candidates with a bf16-split
+/* Diagnostics of the matrix-core kNN path (D = 32, k <= 20): dmet_knn_f32 first ranks candidates with a bf16-split
  * MFMA filter, re-ranks the kept ones with the exact R1 chain and certifies every query; uncertified queries are
  * recomputed exactly (one at a time when their 128-query tile has at most 8 of them, by the exact tile kernel
  * otherwise).  For the LAST dmet_knn_f32 call on this workspace: out[0] = tiles holding an uncertified query,

@@ -35,6 +35,9 @@ def _ragged(sizes, D, seed, dup=False):
     ([130, 131], 5, 3),                   # odd D (padded path), small k
     ([400], 64, 33),                      # D=64 (DRN width), k -> 64-wide list
     ([700, 10], 16, 64),                  # maximum k
+    ([900, 300, 21], 32, 20),             # the reference's k=20 (graph_met_network.py:63) on the matrix-core path
+    ([500, 64], 32, 17),                  # 16 < k <= 20: same path, odd k
+    ([600], 32, 24),                      # k > 20 at D = 32: exact kernel
 ])
 def test_knn_bit_exact(dev, sizes, D, k):
     import deepmetv2_amd as dm
