@@ -175,6 +175,38 @@ def test_knn_oversized_event_goes_to_exact_kernel(dev, monkeypatch):
     assert torch.equal(nbr[66000:], ref + 66000) and torch.equal(dist[66000:], dref)
 
 
+def test_knn_paths_agree_fuzz(dev, monkeypatch):
+    """K1: 12 seeded random batches (ragged, tiny and empty events, k in {1, 8, 13, 16, 20}; gaussian, clustered with
+    exact duplicates, heavy-tailed, rank-2 data): the matrix-core path (filter + certified re-rank + fallbacks) must
+    return the exact kernel's bits everywhere (the exact kernel is pinned to the oracle by test_knn_bit_exact)."""
+    g = torch.Generator().manual_seed(99)
+    for it in range(12):
+        B = int(torch.randint(1, 24, (1,), generator=g))
+        hi = [1500, 120, 2500, 40, 700][it % 5]
+        sizes = [int(v) for v in torch.randint(0, hi, (B,), generator=g)]
+        N = sum(sizes)
+        if N == 0:
+            continue
+        k = [16, 8, 20, 13, 1][it % 5]
+        x = torch.randn(N, 32, generator=g)
+        mode = it % 4
+        if mode == 1:
+            c = torch.randn(7, 32, generator=g) * 3
+            x = c[torch.randint(0, 7, (N,), generator=g)] + 1e-2 * torch.randn(N, 32, generator=g)
+            x[N // 2:N // 2 + N // 10] = x[:N // 10]
+        elif mode == 2:
+            x = x * torch.exp(2.0 * torch.randn(N, 1, generator=g))
+        elif mode == 3:
+            x = torch.randn(N, 2, generator=g) @ torch.randn(2, 32, generator=g)
+        ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.tensor(sizes).cumsum(0)]).to(dev)
+        xd = x.to(dev)
+        monkeypatch.setenv("DMET_KNN_PATH", "exact")
+        n0, d0, _ = _knn_with_stats(xd, ptr, k)
+        monkeypatch.delenv("DMET_KNN_PATH")
+        n1, d1, st = _knn_with_stats(xd, ptr, k)
+        assert torch.equal(n0, n1) and torch.equal(d0, d1), (it, sizes[:5], k, mode, st)
+
+
 def test_radius_graph(dev):
     import deepmetv2_amd as dm
     from oracle import ref_ops
