@@ -221,14 +221,15 @@ __global__ __launch_bounds__(256) void knn_plan_kernel(const int64_t *__restrict
         for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
         const int tiles = run;
         int n_full = tiles, split = 1;
-        if (tiles > simds) {
-            const int full = (tiles / simds) * simds;
-            const int rem = tiles - full;
-            if (rem > 0) {
-                int f = simds / rem;
-                if (f > max_split) f = max_split;
-                if (f >= 2) { n_full = full; split = f; }
-            }
+        // the tiles beyond the last full round of `simds` -- ALL tiles when the batch is small -- are cut into
+        // candidate sub-sweeps so that they still fill the chip (unless the events are so small that a sub-sweep
+        // would be a handful of candidates)
+        const int full = (tiles / simds) * simds;
+        const int rem = tiles - full;
+        if (rem > 0 && B > 0 && (ptr[B] - ptr[0]) >= (int64_t)512 * B) {
+            int f = simds / rem;
+            if (f > max_split) f = max_split;
+            if (f >= 2) { n_full = full; split = f; }
         }
         plan->total_tiles = tiles; plan->n_full = n_full; plan->split = split; plan->pad = 0;
         tile_ptr[B] = tiles;
@@ -1344,8 +1345,9 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     else
         hipLaunchKernelGGL((knn_kernel<DP, KP, TQ, false>), dim3((unsigned)blocks), dim3(kWave * kWavesPerGroup), dyn, st, a);
     DMET_LAUNCH_CHECK("knn_kernel");
-    if (tiles_max > simds) {  // only then can the plan have split anything
-        const int64_t slots = (int64_t)simds * QT;
+    {   // split tiles (the tail of a large batch, every tile of a small one) merge their partial lists
+        int64_t slots = (int64_t)simds * QT;
+        if (tiles_max * QT < slots) slots = tiles_max * QT;
         hipLaunchKernelGGL((knn_merge_kernel<KP>), dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, a, QT);
         DMET_LAUNCH_CHECK("knn_merge_kernel");
     }

@@ -48,7 +48,7 @@ int dmet_device_available(void);
  *   d(i,j) = sum_c fmaf(x[j,c]-x[i,c], x[j,c]-x[i,c], acc)  (sequential in c, fp32; rule R1)
  * ordered by (d, j) ascending; ties keep the lower j (rule R2); candidates at d >= 1e10 are never
  * selected (upstream sentinel).  Self is a candidate like any other (loop handling is host-side).
- * nbr[N,k] int32 (required), dist[N,k] fp32 (required; it is also the kernel's running top-k state).
+ * nbr[N,k] int32 (required), dist[N,k] fp32 (required): the k neighbours and their R1 distances.
  * One launch for all ragged events.  1 <= k <= DMET_MAX_K, 1 <= D <= DMET_MAX_KNN_DIM. */
 size_t dmet_knn_workspace_bytes(int64_t N, int B, int D, int k);
 int dmet_knn_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,
