@@ -180,7 +180,8 @@ def main():
     flat = FlatModule(model)
     sync = GradSync(flat)
     sync.broadcast_state(0)
-    opt = torch.optim.AdamW([flat.flat_param], lr=1e-3, capturable=args.hip_graph)
+    # one fused kernel for the whole (flat) parameter vector; it is also graph-capturable
+    opt = torch.optim.AdamW([flat.flat_param], lr=1e-3, fused=True, capturable=args.hip_graph)
 
     if args.mode == "train":
         model.train()
