@@ -300,3 +300,45 @@ def decode_padded_events(x_pad: np.ndarray, y: np.ndarray):
         x = np.clip(np.nan_to_num(x), -5000.0, 5000.0)                      # :81-82
         out.append((torch.from_numpy(x.astype(np.float32)), torch.from_numpy(np.asarray(y[ievt], np.float32)[None])))
     return out
+
+
+# ---- evaluation-side metrics (row N4): /root/reference/model/net.py:64-157, restated for the CPU ----------------------
+def _recoil(vec: torch.Tensor, v_qt: torch.Tensor):
+    """response = v.q / q.q; u_par = |response q| - |q|; u_perp = |v - response q|   (net.py:139-145)"""
+    dot = torch.einsum("bi,bi->b", vec, v_qt)
+    qq = torch.einsum("bi,bi->b", v_qt, v_qt)
+    response = dot / qq
+    v_par = torch.einsum("b,bi->bi", response, v_qt)
+    u_par = torch.sqrt(torch.einsum("bi,bi->b", v_par, v_par)) - torch.sqrt(qq)
+    diff = vec - v_par
+    u_perp = torch.sqrt(torch.einsum("bi,bi->b", diff, diff))
+    return u_perp, u_par, response
+
+
+def u_perp_par_loss(weights, prediction, truth, batch):
+    """net.py:70-90 (q_T built from truth[:,0] twice, as the reference does)."""
+    B = truth.shape[0]
+    v_qt = torch.stack((truth[:, 0], truth[:, 0]), dim=1)
+    mx = -scatter_add(weights * prediction[:, 0], batch, dim_size=B)
+    my = -scatter_add(weights * prediction[:, 1], batch, dim_size=B)
+    u_perp, u_par, _ = _recoil(torch.stack((mx, my), dim=1), v_qt)
+    return 0.5 * (u_par ** 2 + u_perp ** 2).mean()
+
+
+def resolution(weights, prediction, truth, batch):
+    """net.py:92-157."""
+    B = truth.shape[0]
+    v_qt = torch.stack((truth[:, 0], truth[:, 1]), dim=1)
+    mx = scatter_add(weights * prediction[:, 0], batch, dim_size=B)
+    my = scatter_add(weights * prediction[:, 1], batch, dim_size=B)
+
+    def compute(vec):
+        return [t.detach().cpu().numpy() for t in _recoil(vec, v_qt)]
+
+    out = {"MET": compute(-torch.stack((mx, my), dim=1)),
+           "pfMET": compute(torch.stack((truth[:, 2], truth[:, 3]), dim=1)),
+           "puppiMET": compute(torch.stack((truth[:, 4], truth[:, 5]), dim=1))}
+    if truth.shape[1] > 6:
+        out["deepMETResponse"] = compute(torch.stack((truth[:, 6], truth[:, 7]), dim=1))
+        out["deepMETResolution"] = compute(torch.stack((truth[:, 8], truth[:, 9]), dim=1))
+    return out, torch.sqrt(truth[:, 0] ** 2 + truth[:, 1] ** 2).detach().cpu().numpy()

@@ -641,6 +641,37 @@ def test_graphed_train_step_matches_eager(dev):
     assert torch.equal(finals[0][0], finals[1][0])
 
 
+@pytest.mark.parametrize("ncols", [6, 11])
+def test_eval_metrics_match_oracle(dev, ncols):
+    """N4: `resolution`, `u_perp_par_loss` and the `metrics` registry (reference model/net.py:64-161) against the
+    oracle's restatement; the per-event MET sums come from the HIP reduction."""
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import synth
+    from oracle import ref_ops
+    sizes = [500, 3, 1200, 64]
+    x, y, batch, ptr = synth.make_events(sizes, seed=8)
+    y = y[:, :ncols].contiguous()
+    g = torch.Generator().manual_seed(1)
+    w = torch.rand(x.shape[0], generator=g).requires_grad_(True)
+    res_ref, qt_ref = ref_ops.resolution(w, x, y, batch)
+    loss_ref = ref_ops.u_perp_par_loss(w, x, y, batch)
+    loss_ref.backward()
+    wd = w.detach().to(dev).requires_grad_(True)
+    res, qt = dm.metrics["resolution"](wd, x.to(dev), y.to(dev), batch.to(dev))
+    loss = dm.u_perp_par_loss(wd, x.to(dev), y.to(dev), batch.to(dev))
+    loss.backward()
+    assert set(res) == set(res_ref) and (("deepMETResponse" in res) == (ncols > 6))
+    scale = float((w.detach().abs() * x[:, :2].abs().sum(1)).sum() / len(sizes))
+    for name in res_ref:
+        for a, r in zip(res[name], res_ref[name]):
+            import numpy as np
+            np.testing.assert_allclose(a, r, rtol=1e-4, atol=1e-5 * scale)
+    import numpy as np
+    np.testing.assert_allclose(qt, qt_ref, rtol=1e-6)
+    torch.testing.assert_close(loss.detach().cpu(), loss_ref.detach(), rtol=1e-4, atol=1e-6 * scale * scale)
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=1e-3, atol=1e-5 * float(w.grad.abs().max()))
+
+
 def test_ops_fail_loudly_without_gpu_tensor(dev):
     import deepmetv2_amd as dm
     with pytest.raises(RuntimeError, match="non-GPU tensor"):

@@ -53,6 +53,11 @@ def test_full_model():
     P.test_full_model_train_step_matches_oracle(CPU)
 
 
+@pytest.mark.parametrize("ncols", [6, 11])
+def test_eval_metrics(ncols):
+    P.test_eval_metrics_match_oracle(CPU, ncols)
+
+
 def test_product_refuses_cpu_tensors():
     """Without the stand-in the product path must fail loudly on CPU tensors (no silent fallback)."""
     import importlib
