@@ -220,3 +220,19 @@ _graph_registry: Dict[int, Tuple[weakref.ref, int, object]] = {}
 def lookup_graph(edge_index: torch.Tensor):
     """(NeighborTable, flow) if this exact edge_index tensor came from knn_graph / radius_graph, else None."""
     return _registry_get(_graph_registry, edge_index)
+
+
+def to_undirected(edge_index: torch.Tensor, num_nodes: Optional[int] = None) -> torch.Tensor:
+    """torch_geometric.utils.to_undirected for an index-only graph (the call shape of
+    /root/reference/model/dynamic_reduction_network.py:86,94): add every reverse edge, then coalesce -- edges sorted by
+    (row, col), duplicates removed.  int64 [2,E] in, int64 [2,E'] out; plain torch ops (host-side graph bookkeeping,
+    the result takes EdgeConv's irregular-graph path)."""
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
+    if edge_index.numel() == 0:
+        return edge_index
+    n = int(num_nodes) if num_nodes is not None else int(edge_index.max().item()) + 1
+    row = torch.cat([edge_index[0], edge_index[1]])
+    col = torch.cat([edge_index[1], edge_index[0]])
+    key = torch.unique(row * n + col)            # sorted ascending = (row, col) lexicographic
+    return torch.stack([key // n, key % n], 0)

@@ -58,6 +58,25 @@ def test_eval_metrics(ncols):
     P.test_eval_metrics_match_oracle(CPU, ncols)
 
 
+def test_to_undirected_and_drn_call_shape():
+    """The DRN call shape (dynamic_reduction_network.py:86-87): to_undirected(knn_graph(x, k, batch, loop=False)) fed
+    to an add-aggregating EdgeConv with a multi-layer nn; to_undirected itself against a set-based restatement."""
+    import deepmetv2_amd as dm
+    from oracle import ref_ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(60, 5, generator=g)
+    batch = torch.repeat_interleave(torch.arange(3), torch.tensor([25, 5, 30]))
+    ei = dm.knn_graph(x, 4, batch, loop=False)
+    und = dm.to_undirected(ei)
+    pairs = sorted({(int(a), int(b)) for a, b in ei.t().tolist()} | {(int(b), int(a)) for a, b in ei.t().tolist()})
+    assert und.dtype == torch.int64 and und.t().tolist() == [list(p) for p in pairs]
+    nn_ = torch.nn.Sequential(torch.nn.Linear(10, 8), torch.nn.ELU(), torch.nn.Linear(8, 8), torch.nn.ELU())
+    conv = dm.EdgeConv(nn=nn_, aggr="add")
+    out = conv(x, und)
+    ref = ref_ops.edge_conv(x, und, nn_, aggr="add")
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+
+
 def test_product_refuses_cpu_tensors():
     """Without the stand-in the product path must fail loudly on CPU tensors (no silent fallback)."""
     import importlib
