@@ -263,7 +263,7 @@ def main():
             ach = alg_bytes / (ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", f"pmc_{gname}.json")
-            if os.path.exists(tpath):
+            if args.dtype == "f32" and os.path.exists(tpath):   # the counters were collected for the fp32 kernel
                 try:
                     traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
                 except Exception:
