@@ -218,6 +218,7 @@ __global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const f
     for (int w = 1; w < kBwdThreads / kWave; ++w) m = fmaxf(m, red[w]);
     int ex = 0;
     (void)frexpf(m, &ex);                       // m = f * 2^ex, f in [0.5, 1)
+    ex = max(ex, -96);                          // gradients below 2^-96 everywhere: keep the scale finite
     const float scale = ldexpf(1.0f, 30 - ex), inv_scale = ldexpf(1.0f, ex - 30);
 
     // window: CH channels x JW nodes of accumulators
