@@ -135,14 +135,18 @@ __global__ __launch_bounds__(64 * kHeadWaves, 2) void head_bwd_kernel(const floa
         }
         A[lane * kAPad + 16] = gz; A[lane * kAPad + 17] = 0.0f; A[lane * kAPad + 18] = 0.0f; A[lane * kAPad + 19] = 0.0f;
         Bt[lane * kAPad + 16] = 1.0f; Bt[lane * kAPad + 17] = 0.0f; Bt[lane * kAPad + 18] = 0.0f; Bt[lane * kAPad + 19] = 0.0f;
-        // g_emb row = W1^T g_z1 (rows of W1 read sequentially)
+        // g_emb row = W1^T g_z1 (rows of W1 read sequentially).  W1 is re-loaded through a second opaque offset: kept
+        // live from the recompute above, its 512 scalars overflow the SGPR file (546 SGPR spills before this)
+        int zero2 = 0;
+        asm volatile("" : "+s"(zero2));
+        const float *__restrict__ w1b = W1 + zero2;
         float gx[32];
 #pragma unroll
         for (int f = 0; f < kHin; ++f) gx[f] = 0.0f;
 #pragma unroll
         for (int o = 0; o < kHid; ++o)
 #pragma unroll
-            for (int f = 0; f < kHin; ++f) gx[f] = __builtin_fmaf(w1[o * kHin + f], gz1[o], gx[f]);
+            for (int f = 0; f < kHin; ++f) gx[f] = __builtin_fmaf(w1b[o * kHin + f], gz1[o], gx[f]);
         head_wave_sync();
         head_mma<kXPad>(acc0, A, X, lane);            // rows 0..15: gW1 = g_z1^T emb
         head_mma<kAPad>(acc1, A, Bt, lane);           // row 16: [gW2 | gb2];  column 16 of rows 0..15: gb1
