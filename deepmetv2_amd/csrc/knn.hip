@@ -553,13 +553,11 @@ struct KnnFilterArgs {
     int k;
     float *nrm;                 // [N] squared norms
     unsigned short *xs;         // [N][64] bf16 split of x: 32 high terms, then 32 middle terms
-    float *fd;                  // [N][MS] kept keys of the whole-sweep lists (MS = M + threshold slot, padded)
-    int32_t *fj;
     const KnnPlan *plan;        // filter plan (kFQ-query tiles)
     const int32_t *order;
     const int32_t *pos_of;
     const int32_t *tile_ptr;
-    float *psd;                 // split tiles: [(tile-n_full)*kFQ + slot][split][MS]
+    float *psd;                 // split tiles: [(tile-n_full)*kFQ + slot][split][MS], MS = M kept (key, id) + threshold slot
     int32_t *psj;
     int32_t *nbr;
     float *dist;
@@ -1249,9 +1247,8 @@ inline KnnWorkspace carve_workspace(void *ws, int64_t N, int B, int KP)
     w.order = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
     w.pos_of = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
     w.tile_ptr = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
-    // wsd/wsj double as the filter's [N][2][KP] key lists (the exact kernel runs after the re-rank consumed them)
-    w.wsd = reinterpret_cast<float *>(take(sizeof(float) * (size_t)N * KP * 2));
-    w.wsj = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)N * KP * 2));
+    w.wsd = reinterpret_cast<float *>(take(sizeof(float) * (size_t)N * KP));
+    w.wsj = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)N * KP));
     w.psd = reinterpret_cast<float *>(take(sizeof(float) * ps_elems));
     w.psj = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ps_elems));
     w.fplan = reinterpret_cast<KnnPlan *>(take(sizeof(KnnPlan)));
@@ -1317,7 +1314,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     // matrix-core filter + exact re-rank for the hot shape (D = 32, k <= 20); the exact kernel then only recomputes
     // the tiles the re-rank could not certify
     if (use_filter) {
-        KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.xs, w.wsd, w.wsj, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
+        KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.xs, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
                         w.psd, w.psj, nbr, dist, w.flags, w.qflag, w.tile_ptr, QT};
         int rc = 0;
         if constexpr (KP == 8) rc = launch_filter<8>(f, w, simds, st);
