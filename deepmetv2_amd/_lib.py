@@ -24,6 +24,7 @@ SIGNATURES = {
     "dmet_device_available": (_i, []),
     "dmet_knn_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
     "dmet_knn_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "dmet_knn_local_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_knn_fallback_stats": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
     "dmet_radius_f32": (_i, [_vp, _vp, _i, _i64, _i, _f, _i, _i, _vp, _vp, _vp]),
     "dmet_edgeconv_linear_workspace_bytes": (_sz, [_i64, _i]),
@@ -33,6 +34,7 @@ SIGNATURES = {
     "dmet_gather_max_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "dmet_gather_max_counted_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "dmet_gather_max_lds_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
+    "dmet_gather_max_lds16_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "dmet_node_linear_split_bf16": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dmet_gather_max_bf16q": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "dmet_gather_max_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp]),
@@ -55,6 +57,7 @@ SIGNATURES = {
     "dmet_xty_f32": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _sz, _vp]),
     "dmet_onehot_xty_f32": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp, _sz, _vp]),
     "dmet_gather_max_bwd_lds_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp]),
+    "dmet_gather_max_bwd_lds16_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp]),
     "dmet_edgeconv_linear_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "dmet_edgeconv_linear_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_head_fwd_f32": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),

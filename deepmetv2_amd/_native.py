@@ -98,10 +98,7 @@ GATHER_MAX_FORM = os.environ.get("DMET_GATHER_MAX_FORM", "auto")
 
 
 # ---- K1 ------------------------------------------------------------------------------------------------------
-def knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """nbr[N,k] int32 (global ids, -1 padded), dist[N,k] fp32.  With a `stats` dict the call synchronises and stores
-    stats['flagged_tiles'] / stats['flagged_queries'] (what the matrix-core path could not certify and recomputed
-    exactly; diagnostics only)."""
+def _knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict], want_local: bool):
     dev = _require_device(x, ptr)
     L = _lib.load()
     x = _f32c(x.detach(), "x")
@@ -111,12 +108,15 @@ def knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict] = None
     B = ptr.numel() - 1
     nbr = torch.empty((N, k), dtype=torch.int32, device=dev)
     dist = torch.empty((N, k), dtype=torch.float32, device=dev)
+    # uint16 payload in an int16 tensor (torch has no arithmetic on uint16; the kernels only reinterpret the bytes)
+    loc = torch.empty((N, k), dtype=torch.int16, device=dev) if want_local else None
     nb = L.dmet_knn_workspace_bytes(N, B, D, k)
     ws = _ws(nb, dev)
     _t = timer.record('knn', dev)
     with torch.cuda.device(dev):
-        _lib.check(L.dmet_knn_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, k, nbr.data_ptr(), dist.data_ptr(),
-                                  ws.data_ptr(), ws.numel(), _stream(dev)), "dmet_knn_f32")
+        _lib.check(L.dmet_knn_local_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, k, nbr.data_ptr(), dist.data_ptr(),
+                                        loc.data_ptr() if want_local else None, ws.data_ptr(), ws.numel(),
+                                        _stream(dev)), "dmet_knn_local_f32")
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))
     if stats is not None and N > 0 and B > 0:
@@ -127,7 +127,23 @@ def knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict] = None
                                                  _stream(dev)), "dmet_knn_fallback_stats")
             stats["flagged_tiles"], stats["flagged_queries"] = int(out[0]), int(out[1])
             stats["tiles"] = (N + 127) // 128
+    return nbr, dist, loc
+
+
+def knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """nbr[N,k] int32 (global ids, -1 padded), dist[N,k] fp32.  With a `stats` dict the call synchronises and stores
+    stats['flagged_tiles'] / stats['flagged_queries'] (what the matrix-core path could not certify and recomputed
+    exactly; diagnostics only)."""
+    nbr, dist, _ = _knn(x, ptr, k, stats, False)
     return nbr, dist
+
+
+def knn_local(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict] = None
+              ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """knn() plus the same table as event-local uint16 ids (0xFFFF = empty slot; stored in an int16 tensor), written
+    by the same kernels: half the id bytes for the LDS gather kernel.  Rows of events with more than 65535 nodes are
+    unspecified (those events never take the LDS path)."""
+    return _knn(x, ptr, k, stats, True)
 
 
 def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int, skip_self: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -165,8 +181,8 @@ def node_linear_split(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor
 
 
 def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optional[torch.Tensor],
-               want_arg: bool, cnt: Optional[torch.Tensor] = None, lds: bool = False
-               ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+               want_arg: bool, cnt: Optional[torch.Tensor] = None, lds: bool = False,
+               nbr_local: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """out = P + max over the rows of Q listed in nbr (+ uint8 arg).  lds=True: the caller knows every event fits
     the LDS image (<= 5119 nodes, k in {8,16,32}, H % 8 == 0) -> LDS-resident kernel; else gathers come from L2."""
     dev = _require_device(P, Q, nbr)
@@ -186,11 +202,19 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
         return out, arg
     _t = timer.record('gather_max', dev)
     use_lds = (lds or GATHER_MAX_FORM == "lds") and GATHER_MAX_FORM != "l2-only" and ptr is not None and H % 8 == 0
-    fn = L.dmet_gather_max_lds_f32 if use_lds else L.dmet_gather_max_f32
     with torch.cuda.device(dev):
-        _lib.check(fn(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), ptr.data_ptr() if ptr is not None else None,
-                      (ptr.numel() - 1) if ptr is not None else 0, N, k, H, out.data_ptr(),
-                      arg.data_ptr() if want_arg else None, _stream(dev)), "dmet_gather_max_f32")
+        if use_lds and nbr_local is not None and k in (8, 16, 32):
+            if nbr_local.shape != nbr.shape or nbr_local.dtype != torch.int16 or not nbr_local.is_contiguous():
+                raise ValueError("nbr_local must be the contiguous int16 [N, k] table of knn_local()")
+            _lib.check(L.dmet_gather_max_lds16_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), nbr_local.data_ptr(),
+                                                   ptr.data_ptr(), ptr.numel() - 1, N, k, H, out.data_ptr(),
+                                                   arg.data_ptr() if want_arg else None, _stream(dev)),
+                       "dmet_gather_max_lds16_f32")
+        else:
+            fn = L.dmet_gather_max_lds_f32 if use_lds else L.dmet_gather_max_f32
+            _lib.check(fn(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), ptr.data_ptr() if ptr is not None else None,
+                          (ptr.numel() - 1) if ptr is not None else 0, N, k, H, out.data_ptr(),
+                          arg.data_ptr() if want_arg else None, _stream(dev)), "dmet_gather_max_f32")
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))
     return out, arg
@@ -580,7 +604,8 @@ def edgeconv_linear_bwd(x: torch.Tensor, weight: torch.Tensor, g_out: torch.Tens
     return gx, gW, gb
 
 
-def gather_max_bwd_lds(g_out: torch.Tensor, arg: torch.Tensor, nbr: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:
+def gather_max_bwd_lds(g_out: torch.Tensor, arg: torch.Tensor, nbr: torch.Tensor, ptr: torch.Tensor,
+                       nbr_local: Optional[torch.Tensor] = None) -> torch.Tensor:
     """gQ[N,32] by per-event LDS scatter with exact integer sums (no reverse index); see include/dmet.h."""
     dev = _require_device(g_out, arg, nbr, ptr)
     L = _lib.load()
@@ -592,9 +617,13 @@ def gather_max_bwd_lds(g_out: torch.Tensor, arg: torch.Tensor, nbr: torch.Tensor
     gQ = torch.empty((N, H), dtype=torch.float32, device=dev)
     _t = timer.record('gather_max_bwd', dev)
     with torch.cuda.device(dev):
-        _lib.check(L.dmet_gather_max_bwd_lds_f32(g_out.data_ptr(), arg.data_ptr(), nbr.data_ptr(), ptr.data_ptr(), B, N,
-                                                 nbr.shape[1], H, gQ.data_ptr(), _stream(dev)),
-                   "dmet_gather_max_bwd_lds_f32")
+        if nbr_local is not None and (nbr_local.shape != nbr.shape or nbr_local.dtype != torch.int16
+                                      or not nbr_local.is_contiguous()):
+            raise ValueError("nbr_local must be the contiguous int16 [N, k] table of knn_local()")
+        _lib.check(L.dmet_gather_max_bwd_lds16_f32(g_out.data_ptr(), arg.data_ptr(), nbr.data_ptr(),
+                                                   nbr_local.data_ptr() if nbr_local is not None else None,
+                                                   ptr.data_ptr(), B, N, nbr.shape[1], H, gQ.data_ptr(), _stream(dev)),
+                   "dmet_gather_max_bwd_lds16_f32")
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))
     return gQ

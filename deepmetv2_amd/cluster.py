@@ -38,14 +38,19 @@ def knn_table(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loo
     if kk > MAX_K:
         raise ValueError(f"k={k} (searching {kk}) exceeds the supported maximum {MAX_K}")
     info = batch_info(batch, x.shape[0], x.device, num_events)
-    nbr, dist = _native.knn(x, info.ptr, kk)
+    # the LDS gather kernel reads the table as event-local uint16 ids when the kNN kernels wrote them alongside
+    loc = None
+    if loop and kk in (8, 16, 32):
+        nbr, dist, loc = _native.knn_local(x, info.ptr, kk)
+    else:
+        nbr, dist = _native.knn(x, info.ptr, kk)
     # dense <=> no -1 entry: needs every event to have >= kk nodes; unknown without a sync, so only the
     # no-batch single-event case and registered batches with known sizes could claim it.  Stay conservative.
     dense = False
     if not loop:
         self_id = torch.arange(x.shape[0], dtype=torch.int32, device=x.device).view(-1, 1)
         nbr = torch.where(nbr == self_id, torch.full_like(nbr, -1), nbr)
-    return NeighborTable(nbr, info.ptr, dense=dense, dist=dist, max_nodes=info.max_nodes)
+    return NeighborTable(nbr, info.ptr, dense=dense, dist=dist, max_nodes=info.max_nodes, nbr_local=loc)
 
 
 def knn_graph(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loop: bool = False,

@@ -84,7 +84,7 @@ class _EdgeConvLinearMax(torch.autograd.Function):
         else:
             P, Q = _native.node_linear_split(x, weight, bias)
             out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad,
-                                          lds=_lds_eligible(x, weight, table))
+                                          lds=_lds_eligible(x, weight, table), nbr_local=table.nbr_local)
         if need_grad:
             ctx.save_for_backward(x, weight, arg)
             ctx.table = table
@@ -99,7 +99,7 @@ class _EdgeConvLinearMax(torch.autograd.Function):
         g_out = g_out.contiguous()
         if H == 32 and g_out.dtype == torch.float32 and table.ptr is not None and GATHER_BWD_FORM != "reverse":
             # per-event LDS scatter with exact integer sums: no reverse index (radix sort) needed
-            gQ = _native.gather_max_bwd_lds(g_out, arg, table.nbr, table.ptr)
+            gQ = _native.gather_max_bwd_lds(g_out, arg, table.nbr, table.ptr, nbr_local=table.nbr_local)
         else:
             rev_ptr, rev_pos = table.reverse()
             gQ = _native.gather_max_bwd(g_out, arg, rev_ptr, rev_pos, table.k)

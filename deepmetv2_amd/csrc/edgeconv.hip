@@ -406,14 +406,34 @@ __device__ __forceinline__ void load_ids_pair(int4 (&ids)[K4], const int4 *__res
     }
 }
 
+// Event-local uint16 table (dmet_knn_local_f32): a row is 2k bytes = K4 dwords per lane of the pair; half the id bytes
+// of the int32 table, and the ids need no `- lo`.
+template <int K4>
+__device__ __forceinline__ void load_ids16_pair(unsigned (&w)[K4], const uint16_t *__restrict__ row, int half)
+{
+    const unsigned *src = reinterpret_cast<const unsigned *>(row) + half * K4;
+    if (K4 % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < K4 / 4; ++q) {
+            const uint4 v = reinterpret_cast<const uint4 *>(src)[q];
+            w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+        }
+    } else {
+        const uint2 v = *reinterpret_cast<const uint2 *>(src);
+        w[0] = v.x; w[1] = v.y;
+    }
+}
+
 // K4 = number of int4 id loads per node (k == 4*K4).  LDS image: rows 0..n-1 = the event's Q slice, row n = -inf
 // (ids < 0 and anything outside the event map to it, so the gather needs no per-neighbour branch).  Per node all
 // 4*K4 LDS reads are issued before the compare chain; the next node's ids and P slice are prefetched meanwhile.
-template <bool WITH_ARG, int K4, int GML_MODE = 0>
+template <bool WITH_ARG, int K4, int GML_MODE = 0, bool IDS16 = false>
 __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ nbr,
-    const int64_t *__restrict__ ptr, int B, int k, int H, float *__restrict__ out, uint8_t *__restrict__ arg)
+    const uint16_t *__restrict__ nbr16, const int64_t *__restrict__ ptr, int B, int k, int H,
+    float *__restrict__ out, uint8_t *__restrict__ arg)
 {
+    static_assert(!IDS16 || K4 % 2 == 0, "uint16 tables: k must be a multiple of 8");
     __shared__ __attribute__((aligned(16))) float4 qs[kLdsGatherRows * 2];   // [n_b + 1][2] float4 = 8 channels/node
     constexpr int RPI = kLdsGatherThreads / 2;                                // rows per iteration (2 lanes per node)
     const int nsl = H / kSliceC;
@@ -476,10 +496,15 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     }
     // first node's ids and P slice
     int4 ids[K4];
+    unsigned idw[K4];
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r0 < n) {
-        const int4 *row4 = reinterpret_cast<const int4 *>(nbr + (int64_t)(lo + r0) * k);
-        load_ids_pair<K4>(ids, row4, half);
+        if constexpr (IDS16) {
+            load_ids16_pair<K4>(idw, nbr16 + (int64_t)(lo + r0) * k, half);
+        } else {
+            const int4 *row4 = reinterpret_cast<const int4 *>(nbr + (int64_t)(lo + r0) * k);
+            load_ids_pair<K4>(ids, row4, half);
+        }
         pv = P4[(int64_t)(lo + r0) * h4 + col4];
     }
     __builtin_amdgcn_s_waitcnt(0);   // LDS-DMA is counted by vmcnt and is not covered by the barrier itself
@@ -490,17 +515,34 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     for (int r = r0; r < n; r += RPI) {
         const int64_t node = lo + r;
         unsigned off[4 * K4];
+        if constexpr (IDS16) {
+            // this lane holds one half of the row (K4 dwords = 2*K4 ids); the other half comes from the pair lane
 #pragma unroll
-        for (int q = 0; q < K4; ++q) {
-            off[4 * q + 0] = min((unsigned)(ids[q].x - lo), (unsigned)n) * 2 + half;
-            off[4 * q + 1] = min((unsigned)(ids[q].y - lo), (unsigned)n) * 2 + half;
-            off[4 * q + 2] = min((unsigned)(ids[q].z - lo), (unsigned)n) * 2 + half;
-            off[4 * q + 3] = min((unsigned)(ids[q].w - lo), (unsigned)n) * 2 + half;
+            for (int q = 0; q < K4; ++q) {
+                const unsigned mine = idw[q], other = (unsigned)dpp_swap_pair((int)mine);
+                const unsigned a = half ? other : mine, c = half ? mine : other;   // a: ids 2q.., c: ids 2K4+2q..
+                off[2 * q] = min(a & 0xFFFFu, (unsigned)n) * 2 + half;
+                off[2 * q + 1] = min(a >> 16, (unsigned)n) * 2 + half;
+                off[2 * K4 + 2 * q] = min(c & 0xFFFFu, (unsigned)n) * 2 + half;
+                off[2 * K4 + 2 * q + 1] = min(c >> 16, (unsigned)n) * 2 + half;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < K4; ++q) {
+                off[4 * q + 0] = min((unsigned)(ids[q].x - lo), (unsigned)n) * 2 + half;
+                off[4 * q + 1] = min((unsigned)(ids[q].y - lo), (unsigned)n) * 2 + half;
+                off[4 * q + 2] = min((unsigned)(ids[q].z - lo), (unsigned)n) * 2 + half;
+                off[4 * q + 3] = min((unsigned)(ids[q].w - lo), (unsigned)n) * 2 + half;
+            }
         }
         const float4 p = pv;
         if (r + RPI < n) {
-            const int4 *row4 = reinterpret_cast<const int4 *>(nbr + (node + RPI) * k);
-            load_ids_pair<K4>(ids, row4, half);
+            if constexpr (IDS16) {
+                load_ids16_pair<K4>(idw, nbr16 + (node + RPI) * k, half);
+            } else {
+                const int4 *row4 = reinterpret_cast<const int4 *>(nbr + (node + RPI) * k);
+                load_ids_pair<K4>(ids, row4, half);
+            }
             pv = P4[(node + RPI) * h4 + col4];
         }
         float bx = ninf, by = ninf, bz = ninf, bw = ninf;
@@ -1065,8 +1107,9 @@ extern "C" int dmet_gather_max_bf16q(const float *P, const uint16_t *Qh, const i
     return 0;
 }
 
-extern "C" int dmet_gather_max_lds_f32(const float *P, const float *Q, const int32_t *nbr, const int64_t *ptr, int B,
-                                       int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream)
+static int gather_max_lds_impl(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr16,
+                               const int64_t *ptr, int B, int64_t N, int k, int H, float *out, uint8_t *arg,
+                               dmet_stream_t stream)
 {
     DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_gather_max_lds_f32: N out of range");
     DMET_REQUIRE(k >= 1 && k <= 255, "dmet_gather_max_lds_f32: k=%d not in [1,255]", k);
@@ -1074,38 +1117,41 @@ extern "C" int dmet_gather_max_lds_f32(const float *P, const float *Q, const int
                  kSliceC);
     if (N == 0 || B == 0) return 0;
     DMET_REQUIRE(P && Q && nbr && ptr && out, "dmet_gather_max_lds_f32: null pointer");
-    DMET_REQUIRE(aligned16(P) && aligned16(Q) && aligned16(out) && aligned16(nbr),
+    DMET_REQUIRE(aligned16(P) && aligned16(Q) && aligned16(out) && aligned16(nbr) && aligned16(nbr16),
                  "dmet_gather_max_lds_f32: pointers must be 16-B aligned");
     const int nsl = H / kSliceC;
     const int64_t groups = (B + kNumXcd - 1) / kNumXcd;
     const int64_t blocks = groups * kNumXcd * nsl;
     hipStream_t st = as_stream(stream);
+#define DMET_GML_LAUNCH(ARG_, K4_, I16_)                                                                          \
+    hipLaunchKernelGGL((gather_max_lds_kernel<ARG_, K4_, 0, I16_>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), \
+                       0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg)
 #define DMET_GML(K4_)                                                                                          \
     do {                                                                                                       \
-        if (arg)                                                                                               \
-            hipLaunchKernelGGL((gather_max_lds_kernel<true, K4_>), dim3((unsigned)blocks),                     \
-                               dim3(kLdsGatherThreads), 0, st, P, Q, nbr, ptr, B, k, H, out, arg);             \
-        else                                                                                                   \
-            hipLaunchKernelGGL((gather_max_lds_kernel<false, K4_>), dim3((unsigned)blocks),                    \
-                               dim3(kLdsGatherThreads), 0, st, P, Q, nbr, ptr, B, k, H, out, arg);             \
+        if (arg) { if (nbr16) DMET_GML_LAUNCH(true, K4_, true); else DMET_GML_LAUNCH(true, K4_, false); }      \
+        else { if (nbr16) DMET_GML_LAUNCH(false, K4_, true); else DMET_GML_LAUNCH(false, K4_, false); }        \
     } while (0)
-#ifdef DMET_KNN_EXPERIMENT
-    if (const char *e = arg ? getenv("DMET_GML_MODE") : nullptr) {
-        const int m = atoi(e);
-        if (m == 1) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 1>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, ptr, B, k, H, out, arg);
-        else if (m == 2) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 2>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, ptr, B, k, H, out, arg);
-        else DMET_GML(4);
-        DMET_LAUNCH_CHECK("gather_max_lds_kernel");
-        return 0;
-    }
-#endif
     if (k == 8) DMET_GML(2);
     else if (k == 16) DMET_GML(4);
     else if (k == 32) DMET_GML(8);
     else return dmet_gather_max_f32(P, Q, nbr, ptr, B, N, k, H, out, arg, stream);  // other widths: L2 form
 #undef DMET_GML
+#undef DMET_GML_LAUNCH
     DMET_LAUNCH_CHECK("gather_max_lds_kernel");
     return 0;
+}
+
+extern "C" int dmet_gather_max_lds_f32(const float *P, const float *Q, const int32_t *nbr, const int64_t *ptr, int B,
+                                       int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream)
+{
+    return gather_max_lds_impl(P, Q, nbr, nullptr, ptr, B, N, k, H, out, arg, stream);
+}
+
+extern "C" int dmet_gather_max_lds16_f32(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr_local,
+                                         const int64_t *ptr, int B, int64_t N, int k, int H, float *out,
+                                         uint8_t *arg, dmet_stream_t stream)
+{
+    return gather_max_lds_impl(P, Q, nbr, nbr_local, ptr, B, N, k, H, out, arg, stream);
 }
 
 extern "C" int dmet_edgeconv_linear_max_fwd_f32(const float *x, const int32_t *nbr, const int64_t *ptr, int B,

@@ -189,6 +189,7 @@ constexpr int kBwdCells = 18432;             // 64-bit cells in LDS (144 KB)
 __global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const float *__restrict__ g_out,
                                                                           const uint8_t *__restrict__ arg,
                                                                           const int32_t *__restrict__ nbr,
+                                                                          const uint16_t *__restrict__ nbr16,
                                                                           const int64_t *__restrict__ ptr, int B, int k,
                                                                           float *__restrict__ gQ)
 {
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const f
     const int n = (int)(hi - lo);
     if (n <= 0) return;
     const int tid = threadIdx.x;
+    const bool loc16 = nbr16 != nullptr && n <= 65535;   // event-local uint16 table (half the row bytes) when given
 
     // scale: 2^(30 - e) with 2^e > max |g| over the slice (exactly representable, so the final rescale is exact)
     float m = 0.0f;
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const f
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         if (u >= cb && u < cb + CH && as[u] != 255) {
-                            const int j = nbr[gi * k + as[u]] - (int)lo - j0;
+                            const int j = (loc16 ? (int)nbr16[gi * k + as[u]] : nbr[gi * k + as[u]] - (int)lo) - j0;
                             if (j >= 0 && j < jn) {
                                 const long long q = __float2ll_rn(gs[u] * scale);
                                 atomicAdd(&cells[j * CH + (u - cb)], (unsigned long long)q);
@@ -293,9 +295,9 @@ extern "C" int dmet_edgeconv_linear_bwd_f32(const float *x, const float *W, cons
     return 0;
 }
 
-extern "C" int dmet_gather_max_bwd_lds_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr,
-                                           const int64_t *ptr, int B, int64_t N, int k, int H, float *gQ,
-                                           dmet_stream_t stream)
+extern "C" int dmet_gather_max_bwd_lds16_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr,
+                                             const uint16_t *nbr_local, const int64_t *ptr, int B, int64_t N, int k,
+                                             int H, float *gQ, dmet_stream_t stream)
 {
     DMET_REQUIRE(H == kH, "dmet_gather_max_bwd_lds_f32: H=%d (only 32 is built)", H);
     DMET_REQUIRE(N >= 0 && B >= 0 && k >= 1 && k <= 255, "dmet_gather_max_bwd_lds_f32: bad sizes");
@@ -312,7 +314,14 @@ extern "C" int dmet_gather_max_bwd_lds_f32(const float *g_out, const uint8_t *ar
         attr_set = true;
     }
     hipLaunchKernelGGL(gather_max_bwd_lds_kernel, dim3((unsigned)B * 8u), dim3(kBwdThreads), lds, as_stream(stream), g_out,
-                       arg, nbr, ptr, B, k, gQ);
+                       arg, nbr, nbr_local, ptr, B, k, gQ);
     DMET_LAUNCH_CHECK("gather_max_bwd_lds_kernel");
     return 0;
+}
+
+extern "C" int dmet_gather_max_bwd_lds_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr,
+                                           const int64_t *ptr, int B, int64_t N, int k, int H, float *gQ,
+                                           dmet_stream_t stream)
+{
+    return dmet_gather_max_bwd_lds16_f32(g_out, arg, nbr, nullptr, ptr, B, N, k, H, gQ, stream);
 }

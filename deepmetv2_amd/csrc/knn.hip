@@ -160,6 +160,8 @@ struct KnnArgs {
     int D, k;
     int32_t *nbr;
     float *dist;
+    uint16_t *nbr16;       // optional [N][k]: the same table as event-local ids (0xFFFF = none; meaningful for events
+                           // of at most 65535 nodes)
     float *wsd;            // [N][KP] running lists of whole-sweep tiles
     int32_t *wsj;
     const KnnPlan *plan;
@@ -170,6 +172,11 @@ struct KnnArgs {
     const int32_t *flags;  // optional [tiles] = number of uncertified queries per tile (matrix-core path): only
     int flag_min;          // tiles with flags[tile] >= flag_min are computed here
 };
+
+__device__ __forceinline__ uint16_t local_id16(int32_t j, int ev_lo)
+{
+    return (uint16_t)(j >= 0 ? (unsigned)(j - ev_lo) : 0xFFFFu);
+}
 
 // One workgroup: events ordered LONGEST FIRST (a tile of an n-node event costs n candidates, so big events go out
 // first and the split tail consists of the smallest ones), per-position tile counts -> exclusive prefix, then the
@@ -468,6 +475,8 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 3) void knn_kernel(const Kn
                     a.nbr[qq * a.k + p] = lj[t][p];
                 }
             }
+            if (a.nbr16)
+                for (int p = 0; p < a.k; ++p) a.nbr16[qq * a.k + p] = local_id16(lj[t][p], ev_lo);
         }
     }
 }
@@ -508,6 +517,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const KnnArgs a, int til
         for (int s = 0; s < kMaxSplit; ++s) head[s] += (s == bs) ? 1 : 0;
         a.dist[qi * a.k + p] = bd;
         a.nbr[qi * a.k + p] = bj;
+        if (a.nbr16) a.nbr16[qi * a.k + p] = local_id16(bj, (int)a.ptr[ev]);
     }
 }
 
@@ -561,6 +571,7 @@ struct KnnFilterArgs {
     int32_t *psj;
     int32_t *nbr;
     float *dist;
+    uint16_t *nbr16;            // optional event-local copy of nbr (see KnnArgs)
     int32_t *flags;             // [exact tiles] number of uncertified queries of the tile
     uint8_t *qflag;             // [N] 1 = uncertified query
     const int32_t *xtile_ptr;   // tile prefix of the exact kernel's plan (same event order)
@@ -936,6 +947,20 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
                 }
                 if (p == k - 1 && kj[p] >= 0) kth = kd[p];
             }
+            if (a.nbr16) {
+                uint16_t *r16 = a.nbr16 + (int64_t)myq * k;
+                if ((k & 1) == 0) {   // two ids per dword store
+#pragma unroll
+                    for (int p = 0; p + 1 < KP; p += 2)
+                        if (p < k)
+                            reinterpret_cast<unsigned *>(r16)[p >> 1] =
+                                (unsigned)local_id16(kj[p], ev_lo) | ((unsigned)local_id16(kj[p + 1], ev_lo) << 16);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < KP; ++p)
+                        if (p < k) r16[p] = local_id16(kj[p], ev_lo);
+                }
+            }
             // certificate: a list that saw at least M keys dropped only keys >= tau
             const float tau = L.tk[M - 1];
             const float nx = a.nrm[myq];
@@ -1078,6 +1103,7 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
             }
             if (rank < k) {
                 a.nbr[q * k + rank] = myj[t];
+                if (a.nbr16) a.nbr16[q * k + rank] = local_id16(myj[t], ev_lo);
                 a.dist[q * k + rank] = (myj[t] >= 0) ? c : kKnnSentinel;
                 if (rank == k - 1 && myj[t] >= 0) skth[slot] = c;
             }
@@ -1174,11 +1200,16 @@ __global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a,
             const bool found = bj != 0x7fffffff;   // block-uniform
             if (tid == 0) {
                 a.nbr[(int64_t)q * k + r] = found ? bj : -1;
+                if (a.nbr16) a.nbr16[(int64_t)q * k + r] = local_id16(found ? bj : -1, ev_lo);
                 a.dist[(int64_t)q * k + r] = found ? bd : kKnnSentinel;
             }
             if (!found) {
                 if (tid == 0)
-                    for (int rr = r + 1; rr < k; ++rr) { a.nbr[(int64_t)q * k + rr] = -1; a.dist[(int64_t)q * k + rr] = kKnnSentinel; }
+                    for (int rr = r + 1; rr < k; ++rr) {
+                        a.nbr[(int64_t)q * k + rr] = -1;
+                        a.dist[(int64_t)q * k + rr] = kKnnSentinel;
+                        if (a.nbr16) a.nbr16[(int64_t)q * k + rr] = 0xFFFFu;
+                    }
                 break;
             }
             last_d = bd; last_j = bj;
@@ -1294,7 +1325,7 @@ int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, hipS
 
 template <int DP, int KP>
 int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr, float *dist,
-               const KnnWorkspace &w, hipStream_t st)
+               uint16_t *nbr16, const KnnWorkspace &w, hipStream_t st)
 {
     constexpr int TQ = (DP <= 32) ? 2 : 1;
     constexpr int QT = kWave * TQ;
@@ -1307,7 +1338,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     const KnnPlanOut pf{kFQ, slots, kFilterMaxSplit, w.forder, w.fpos_of, w.ftile_ptr, w.fplan};
     hipLaunchKernelGGL(knn_plan_kernel, dim3(use_filter ? 2 : 1), dim3(256), 0, st, ptr, B, px, pf);
     DMET_LAUNCH_CHECK("knn_plan_kernel");
-    KnnArgs a{x, ptr, B, N, D, k, nbr, dist, w.wsd, w.wsj, w.plan, w.order, w.tile_ptr, w.psd, w.psj, nullptr, 0};
+    KnnArgs a{x, ptr, B, N, D, k, nbr, dist, nbr16, w.wsd, w.wsj, w.plan, w.order, w.tile_ptr, w.psd, w.psj, nullptr, 0};
     // uncertified-query counters: zero for every call, so dmet_knn_fallback_stats is meaningful on any path
     if (hipMemsetAsync(w.flags, 0, w.zero_bytes, st) != hipSuccess) return hip_fail(hipGetLastError(), "hipMemsetAsync");
 
@@ -1315,7 +1346,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     // the tiles the re-rank could not certify
     if (use_filter) {
         KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.xs, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
-                        w.psd, w.psj, nbr, dist, w.flags, w.qflag, w.tile_ptr, QT};
+                        w.psd, w.psj, nbr, dist, nbr16, w.flags, w.qflag, w.tile_ptr, QT};
         int rc = 0;
         if constexpr (KP == 8) rc = launch_filter<8>(f, w, simds, st);
         else if constexpr (KP == 16) rc = launch_filter<16>(f, w, simds, st);
@@ -1353,14 +1384,14 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
 
 template <int DP>
 int dispatch_k(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr, float *dist,
-               void *ws, hipStream_t st)
+               uint16_t *nbr16, void *ws, hipStream_t st)
 {
     const int KP = padded_k(k);
     const KnnWorkspace w = carve_workspace(ws, N, B, KP);
-    if (k <= 8) return launch_knn<DP, 8>(x, ptr, B, N, D, k, nbr, dist, w, st);
-    if (k <= 16) return launch_knn<DP, 16>(x, ptr, B, N, D, k, nbr, dist, w, st);
-    if (k <= 32) return launch_knn<DP, 32>(x, ptr, B, N, D, k, nbr, dist, w, st);
-    return launch_knn<DP, 64>(x, ptr, B, N, D, k, nbr, dist, w, st);
+    if (k <= 8) return launch_knn<DP, 8>(x, ptr, B, N, D, k, nbr, dist, nbr16, w, st);
+    if (k <= 16) return launch_knn<DP, 16>(x, ptr, B, N, D, k, nbr, dist, nbr16, w, st);
+    if (k <= 32) return launch_knn<DP, 32>(x, ptr, B, N, D, k, nbr, dist, nbr16, w, st);
+    return launch_knn<DP, 64>(x, ptr, B, N, D, k, nbr, dist, nbr16, w, st);
 }
 
 // ---- radius graph (N1): first max_nbr candidates in ascending index with d < r^2 ------------------------
@@ -1463,22 +1494,29 @@ extern "C" size_t dmet_knn_workspace_bytes(int64_t N, int B, int D, int k)
     return carve_workspace(nullptr, N, B, padded_k(k)).bytes + 512;
 }
 
+extern "C" int dmet_knn_local_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,
+                                  float *dist, uint16_t *nbr16, void *ws, size_t ws_bytes, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647 - 4096, "dmet_knn_f32/dmet_knn_local_f32: N=%lld out of range", (long long)N);
+    DMET_REQUIRE(B >= 0, "dmet_knn_f32/dmet_knn_local_f32: B=%d", B);
+    DMET_REQUIRE(k >= 1 && k <= DMET_MAX_K, "dmet_knn_f32/dmet_knn_local_f32: k=%d not in [1,%d]", k, DMET_MAX_K);
+    DMET_REQUIRE(D >= 1 && D <= DMET_MAX_KNN_DIM, "dmet_knn_f32/dmet_knn_local_f32: D=%d not in [1,%d]", D, DMET_MAX_KNN_DIM);
+    if (N == 0 || B == 0) return 0;
+    DMET_REQUIRE(x && ptr && nbr && dist && ws, "dmet_knn_f32/dmet_knn_local_f32: null pointer");
+    DMET_REQUIRE(ws_bytes >= dmet_knn_workspace_bytes(N, B, D, k), "dmet_knn_f32/dmet_knn_local_f32: workspace too small");
+    DMET_REQUIRE(!nbr16 || (reinterpret_cast<uintptr_t>(nbr16) & 3u) == 0, "dmet_knn_local_f32: nbr_local must be 4-byte aligned");
+    hipStream_t st = as_stream(stream);
+    if (D <= 4) return dispatch_k<4>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
+    if (D <= 8) return dispatch_k<8>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
+    if (D <= 16) return dispatch_k<16>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
+    if (D <= 32) return dispatch_k<32>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
+    return dispatch_k<64>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
+}
+
 extern "C" int dmet_knn_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,
                             float *dist, void *ws, size_t ws_bytes, dmet_stream_t stream)
 {
-    DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647 - 4096, "dmet_knn_f32: N=%lld out of range", (long long)N);
-    DMET_REQUIRE(B >= 0, "dmet_knn_f32: B=%d", B);
-    DMET_REQUIRE(k >= 1 && k <= DMET_MAX_K, "dmet_knn_f32: k=%d not in [1,%d]", k, DMET_MAX_K);
-    DMET_REQUIRE(D >= 1 && D <= DMET_MAX_KNN_DIM, "dmet_knn_f32: D=%d not in [1,%d]", D, DMET_MAX_KNN_DIM);
-    if (N == 0 || B == 0) return 0;
-    DMET_REQUIRE(x && ptr && nbr && dist && ws, "dmet_knn_f32: null pointer");
-    DMET_REQUIRE(ws_bytes >= dmet_knn_workspace_bytes(N, B, D, k), "dmet_knn_f32: workspace too small");
-    hipStream_t st = as_stream(stream);
-    if (D <= 4) return dispatch_k<4>(x, ptr, B, N, D, k, nbr, dist, ws, st);
-    if (D <= 8) return dispatch_k<8>(x, ptr, B, N, D, k, nbr, dist, ws, st);
-    if (D <= 16) return dispatch_k<16>(x, ptr, B, N, D, k, nbr, dist, ws, st);
-    if (D <= 32) return dispatch_k<32>(x, ptr, B, N, D, k, nbr, dist, ws, st);
-    return dispatch_k<64>(x, ptr, B, N, D, k, nbr, dist, ws, st);
+    return dmet_knn_local_f32(x, ptr, B, N, D, k, nbr, dist, nullptr, ws, ws_bytes, stream);
 }
 
 extern "C" int dmet_knn_fallback_stats(const void *ws, int64_t N, int B, int D, int k, int64_t *out, dmet_stream_t stream)

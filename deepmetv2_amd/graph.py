@@ -158,8 +158,10 @@ class NeighborTable:
     """nbr[N,k] int32 global node ids, -1 = empty slot.  Row i lists the message SOURCES of target i."""
 
     def __init__(self, nbr: torch.Tensor, ptr: Optional[torch.Tensor], dense: bool, dist: Optional[torch.Tensor] = None,
-                 max_nodes: Optional[int] = None, cnt: Optional[torch.Tensor] = None):
+                 max_nodes: Optional[int] = None, cnt: Optional[torch.Tensor] = None,
+                 nbr_local: Optional[torch.Tensor] = None):
         self.nbr = nbr
+        self.nbr_local = nbr_local  # optional int16-typed [N,k]: the same table as event-local uint16 ids (knn_local)
         self.ptr = ptr
         self.max_nodes = max_nodes
         self.cnt = cnt              # optional int32 [N]: slots beyond cnt[i] in row i are all -1 (wide, shallow tables)

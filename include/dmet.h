@@ -53,6 +53,11 @@ int dmet_device_available(void);
 size_t dmet_knn_workspace_bytes(int64_t N, int B, int D, int k);
 int dmet_knn_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,
                  float *dist, void *ws, size_t ws_bytes, dmet_stream_t stream);
+/* Same call, additionally writing the table as event-local ids: nbr_local[N,k] uint16 = nbr - ptr[event], 0xFFFF
+ * for an empty slot (4-byte aligned; may be NULL = dmet_knn_f32).  Written by the same kernels that write nbr, for
+ * dmet_gather_max_lds16_f32.  Rows of events with more than 65535 nodes are unspecified. */
+int dmet_knn_local_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,
+                       float *dist, uint16_t *nbr_local, void *ws, size_t ws_bytes, dmet_stream_t stream);
 
 /* Diagnostics of the matrix-core kNN path (D = 32, k <= 20): dmet_knn_f32 first ranks candidates with a bf16-split
  * MFMA filter, re-ranks the kept ones with the exact R1 chain and certifies every query; uncertified queries are
@@ -106,6 +111,13 @@ int dmet_gather_max_counted_f32(const float *P, const float *Q, const int32_t *n
  * same kernel).  Needs ptr/B and H % 8 == 0.  The faster form for events of a few thousand nodes. */
 int dmet_gather_max_lds_f32(const float *P, const float *Q, const int32_t *nbr, const int64_t *ptr, int B,
                             int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream);
+/* Same again with the table ALSO given as event-local uint16 ids (nbr_local from dmet_knn_local_f32; k in {8,16,32},
+ * 16-byte aligned): events that fit the LDS image read their ids from it -- half the id bytes, and every one of the
+ * H/8 slice workgroups of an event re-reads the ids, so this is a third of the kernel's L2 requests.  Larger events
+ * read nbr as before.  Results are identical to dmet_gather_max_lds_f32. */
+int dmet_gather_max_lds16_f32(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr_local,
+                              const int64_t *ptr, int B, int64_t N, int k, int H, float *out, uint8_t *arg,
+                              dmet_stream_t stream);
 /* bf16 variant (BASELINE configs[2]): x and the split weights rounded to bf16 (RNE), multiplied on the bf16 matrix
  * cores with fp32 accumulation; P stays fp32, Q is stored as bf16 (raw bits) and gathered as 64-B rows.
  * Built for Hin = Hout = 32, k in {8,16,32}.  Backward is shared with the fp32 path (arg-based, fp32). */
@@ -125,6 +137,11 @@ int dmet_gather_max_bwd_f32(const float *g_out, const uint8_t *arg, const int32_
  * slice's max |g_out|, the sums are exact.  Replaces the radix sort + L2 gather of the route above on the hot path. */
 int dmet_gather_max_bwd_lds_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr, const int64_t *ptr, int B,
                                 int64_t N, int k, int H, float *gQ, dmet_stream_t stream);
+/* Same, reading the winning neighbour's id from the event-local uint16 table of dmet_knn_local_f32 (nbr_local, may
+ * be NULL) for events of at most 65535 nodes -- 32-byte instead of 64-byte rows under the scattered 2-byte reads. */
+int dmet_gather_max_bwd_lds16_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr,
+                                  const uint16_t *nbr_local, const int64_t *ptr, int B, int64_t N, int k, int H,
+                                  float *gQ, dmet_stream_t stream);
 /* Reverse index: a stable sort of the positions 0..M-1 of an int32 key array by key value.
  *   rev_ptr[num_keys+1]: rev_pos[rev_ptr[j] .. rev_ptr[j+1]-1] = the positions holding key j, ascending.
  * Keys outside [0, num_keys) (the -1 "no neighbour" entries) sort last and are not indexed.

@@ -15,6 +15,15 @@ def knn(x, ptr, k):
     return ref_ops.knn_table(x, ptr, k)
 
 
+def knn_local(x, ptr, k, stats=None):
+    nbr, dist = ref_ops.knn_table(x, ptr, k)
+    counts = (ptr[1:] - ptr[:-1]).long()
+    lo = torch.repeat_interleave(ptr[:-1], counts).to(torch.int32).view(-1, 1)
+    loc = torch.where(nbr >= 0, nbr - lo, torch.full_like(nbr, 0xFFFF))
+    loc = torch.where(loc >= 0x8000, loc - 0x10000, loc).to(torch.int16)      # uint16 payload in an int16 tensor
+    return nbr, dist, loc
+
+
 def radius(x, ptr, r, max_nbr, skip_self=False):
     import ctypes  # noqa: F401
     x = x.detach().float().contiguous()
@@ -42,7 +51,13 @@ def node_linear_split(x, W, b):
     return P.detach(), (x @ W[:, H:].t()).detach()
 
 
-def gather_max(P, Q, nbr, ptr, want_arg, cnt=None, lds=False):
+def gather_max(P, Q, nbr, ptr, want_arg, cnt=None, lds=False, nbr_local=None):
+    if nbr_local is not None:
+        # the local table must describe the same graph (this is what the uint16 kernel would gather)
+        counts = (ptr[1:] - ptr[:-1]).long()
+        lo = torch.repeat_interleave(ptr[:-1], counts).to(torch.int32).view(-1, 1)
+        u = nbr_local.to(torch.int32) & 0xFFFF
+        assert torch.equal(torch.where(u == 0xFFFF, torch.full_like(u, -1), u + lo), nbr)
     N, H = P.shape
     k = nbr.shape[1]
     idx = nbr.long().clamp(min=0)
@@ -221,7 +236,7 @@ def edgeconv_linear_bwd(x, weight, g_out, arg, gQ, want_bias=True):
     return gx, gW, (gP.sum(0) if want_bias else None)
 
 
-def gather_max_bwd_lds(g_out, arg, nbr, ptr):
+def gather_max_bwd_lds(g_out, arg, nbr, ptr, nbr_local=None):
     N, H = g_out.shape
     gQ = torch.zeros_like(g_out)
     a = arg.long()
@@ -279,7 +294,7 @@ def table_edges(nbr, cnt, rowptr, num_edges, swap, want_index64, want_int32):
     return ei, (src.contiguous() if want_int32 else None), (tgt.contiguous() if want_int32 else None)
 
 
-_NAMES = ["table_rowptr", "table_edges", "head_fwd", "head_bwd", "met_loss", "gather_max_bwd_lds", "edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
+_NAMES = ["table_rowptr", "table_edges", "head_fwd", "head_bwd", "met_loss", "gather_max_bwd_lds", "edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "knn_local", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
           "edge_features_bwd", "segment_max", "segment_sum", "segment_max_bwd", "segment_sum_bwd", "met_reduce",
           "met_reduce_bwd", "segment_sum_1d", "batch_to_ptr", "xty", "onehot_xty", "edgeconv_fused_lds"]
 

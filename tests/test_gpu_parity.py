@@ -47,6 +47,9 @@ def test_knn_bit_exact(dev, sizes, D, k):
     t = dm.knn_table(x.to(dev), k, batch.to(dev), loop=True, num_events=len(sizes))
     assert torch.equal(t.nbr.cpu(), nbr_ref)
     assert torch.equal(t.dist.cpu(), dist_ref)  # distances are the same fmaf chain: bit-exact too
+    assert (t.nbr_local is not None) == (k in (8, 16, 32))
+    n2, d2, _ = _knn_with_stats(x.to(dev), ptr.to(dev), k)     # also checks the uint16 local table (any k)
+    assert torch.equal(n2, nbr_ref) and torch.equal(d2, dist_ref)
 
 
 @pytest.mark.parametrize("loop", [True, False])
@@ -95,10 +98,25 @@ def test_knn_ragged_config5_full_size(dev):
         assert torch.equal(nbr[s:e], ref + s) and torch.equal(dist[s:e], dref)
 
 
+def _check_local_table(nbr, loc, ptr):
+    """The uint16 event-local copy of the table (dmet_knn_local_f32) must describe the same graph; rows of events
+    with more than 65535 nodes are unspecified."""
+    nbr, loc, ptr = nbr.cpu(), loc.cpu(), ptr.cpu()
+    counts = ptr[1:] - ptr[:-1]
+    lo = torch.repeat_interleave(ptr[:-1], counts).to(torch.int32).view(-1, 1)
+    rows = torch.repeat_interleave(counts <= 65535, counts)
+    u = loc.to(torch.int32) & 0xFFFF
+    back = torch.where(u == 0xFFFF, torch.full_like(u, -1), u + lo)
+    assert torch.equal(back[rows], nbr[rows])
+
+
 def _knn_with_stats(x, ptr, k):
+    """Every call goes through dmet_knn_local_f32, so each writer of the table (in-place re-rank, tail re-rank,
+    per-query fallback, exact tile kernel, merge) is also checked for the uint16 copy."""
     from deepmetv2_amd import _native
     st = {}
-    nbr, dist = _native.knn(x, ptr, k, stats=st)
+    nbr, dist, loc = _native.knn_local(x, ptr, k, stats=st)
+    _check_local_table(nbr, loc, ptr)
     return nbr.cpu(), dist.cpu(), st
 
 
@@ -379,8 +397,35 @@ def test_gather_max_bwd_lds_matches_reverse_index_route(dev, sizes):
     got = _native.gather_max_bwd_lds(gd, ad, nd, pd)
     got2 = _native.gather_max_bwd_lds(gd, ad, nd, pd)
     assert torch.equal(got, got2)
+    # the uint16 event-local table gives the same bits (integer sums)
+    lo = torch.repeat_interleave(ptr[:-1], torch.tensor(sizes)).to(torch.int32).view(-1, 1)
+    loc = nbr - lo
+    loc = torch.where(loc >= 0x8000, loc - 0x10000, loc).to(torch.int16).to(dev)
+    assert torch.equal(got, _native.gather_max_bwd_lds(gd, ad, nd, pd, nbr_local=loc))
     scale = g_out.abs().amax(0).to(dev) * float(max(sizes)) * 1e-6 + 1e-12
     assert bool(((got - ref).abs() <= scale + 1e-5 * ref.abs()).all())
+
+
+@pytest.mark.parametrize("k", [8, 16, 32])
+def test_gather_max_local_ids_kernel_matches(dev, k):
+    """K3: the LDS gather kernel fed with the uint16 event-local table must return the bits of the int32 form (and
+    of the L2 form), including an event too large for the LDS image (reads the int32 table) and empty events."""
+    from deepmetv2_amd import _native
+    sizes = [300, 1, 0, 77, 5200, 4500]
+    x, batch, ptr = _ragged(sizes, 32, seed=11 + k)
+    xd, ptrd = x.to(dev), ptr.to(dev)
+    nbr, _, loc = _native.knn_local(xd, ptrd, k)
+    _check_local_table(nbr, loc, ptrd)
+    g = torch.Generator().manual_seed(3)
+    P = torch.randn(x.shape[0], 32, generator=g).to(dev)
+    Q = torch.randn(x.shape[0], 32, generator=g).to(dev)
+    for want_arg in (True, False):
+        o0, a0 = _native.gather_max(P, Q, nbr, ptrd, want_arg, lds=False)
+        o1, a1 = _native.gather_max(P, Q, nbr, ptrd, want_arg, lds=True)
+        o2, a2 = _native.gather_max(P, Q, nbr, ptrd, want_arg, lds=True, nbr_local=loc)
+        assert torch.equal(o0, o1) and torch.equal(o1, o2)
+        if want_arg:
+            assert torch.equal(a0, a1) and torch.equal(a1, a2)
 
 
 def test_max_ties_and_empty_rows(dev):
