@@ -581,8 +581,9 @@ def bn_bwd(x: torch.Tensor, g_y: torch.Tensor, gamma: torch.Tensor, save_mean: t
 
 
 def edgeconv_linear_bwd(x: torch.Tensor, weight: torch.Tensor, g_out: torch.Tensor, arg: Optional[torch.Tensor],
-                        gQ: torch.Tensor, want_bias: bool = True):
-    """(gx[N,32], gW[32,64], gb[32] or None) of the fused EdgeConv dense layer (H = 32) from g_out, arg and gQ."""
+                        gQ: torch.Tensor, want_bias: bool = True, g_add: Optional[torch.Tensor] = None):
+    """(gx[N,32], gW[32,64], gb[32] or None) of the fused EdgeConv dense layer (H = 32) from g_out, arg and gQ;
+    g_add[N,32] (optional) is added to gx inside the kernel (the residual branch's gradient)."""
     dev = _require_device(x, weight, g_out, gQ)
     L = _lib.load()
     x = _f32c(x, "x"); weight = _f32c(weight, "weight"); g_out = _f32c(g_out, "g_out"); gQ = _f32c(gQ, "gQ")
@@ -596,11 +597,17 @@ def edgeconv_linear_bwd(x: torch.Tensor, weight: torch.Tensor, g_out: torch.Tens
     gb = torch.empty((H,), dtype=torch.float32, device=dev) if want_bias else None
     with torch.cuda.device(dev):
         ws = _ws(L.dmet_edgeconv_linear_bwd_workspace_bytes(N, H), dev)
-        _lib.check(L.dmet_edgeconv_linear_bwd_f32(x.data_ptr(), weight.data_ptr(), g_out.data_ptr(),
-                                                  arg.data_ptr() if arg is not None else None, gQ.data_ptr(), N, H,
-                                                  gx.data_ptr(), gW.data_ptr(), gb.data_ptr() if gb is not None else None,
-                                                  ws.data_ptr(), ws.numel(), _stream(dev)),
-                   "dmet_edgeconv_linear_bwd_f32")
+        if g_add is not None:
+            g_add = _f32c(g_add, "g_add")
+            if g_add.shape != x.shape:
+                raise ValueError("edgeconv_linear_bwd: g_add must have the shape of x")
+        _lib.check(L.dmet_edgeconv_linear_bwd_add_f32(x.data_ptr(), weight.data_ptr(), g_out.data_ptr(),
+                                                      arg.data_ptr() if arg is not None else None, gQ.data_ptr(),
+                                                      g_add.data_ptr() if g_add is not None else None, N, H,
+                                                      gx.data_ptr(), gW.data_ptr(),
+                                                      gb.data_ptr() if gb is not None else None,
+                                                      ws.data_ptr(), ws.numel(), _stream(dev)),
+                   "dmet_edgeconv_linear_bwd_add_f32")
     return gx, gW, gb
 
 

@@ -68,8 +68,9 @@ class _EdgeConvLinearMax(torch.autograd.Function):
     """out[i] = max_s (W.[x_i || x_j - x_i] + b), j = nbr[i,s], through P = x.(W1-W2)^T + b, Q = x.W2^T."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, table: NeighborTable, bf16: bool = False):
+    def forward(ctx, x, weight, bias, table: NeighborTable, bf16: bool = False, passthrough: bool = False):
         need_grad = any(ctx.needs_input_grad[:3])
+        ctx.passthrough = passthrough
         if bf16:
             # BASELINE configs[2]: dense layer on the bf16 matrix cores, bf16 Q table (half the gathered bytes);
             # max / add / backward stay fp32 (straight-through over the bf16 roundings)
@@ -89,10 +90,14 @@ class _EdgeConvLinearMax(torch.autograd.Function):
             ctx.save_for_backward(x, weight, arg)
             ctx.table = table
             ctx.has_bias = bias is not None
+        if passthrough:
+            # second output: x itself, for the block's residual branch.  Its gradient then arrives HERE together with
+            # g_out and is added to gx inside the backward kernel instead of by a separate autograd add
+            return out, x.view_as(x)
         return out
 
     @staticmethod
-    def backward(ctx, g_out):
+    def backward(ctx, g_out, g_pass=None):
         x, weight, arg = ctx.saved_tensors
         table: NeighborTable = ctx.table
         H = x.shape[1]
@@ -106,9 +111,9 @@ class _EdgeConvLinearMax(torch.autograd.Function):
         if H == 32 and tuple(weight.shape) == (32, 64) and g_out.dtype == torch.float32:
             # one pass over the rows: gx, gW and gb on the fp32 matrix cores (csrc/edgeconv_bwd.hip)
             gx, gW, gb = _native.edgeconv_linear_bwd(x, weight.detach(), g_out, None if table.dense else arg, gQ,
-                                                     want_bias=ctx.has_bias)
+                                                     want_bias=ctx.has_bias, g_add=g_pass)
             return (gx if ctx.needs_input_grad[0] else None, gW if ctx.needs_input_grad[1] else None,
-                    gb if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None, None)
+                    gb if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None, None, None)
         # nodes without any neighbour produced 0 (R3): no gradient reaches P there
         gP = g_out if table.dense else g_out * (arg != 255).to(g_out.dtype)
         Wd = weight[:, :H] - weight[:, H:]
@@ -116,13 +121,15 @@ class _EdgeConvLinearMax(torch.autograd.Function):
         gx = gW = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.addmm(gP @ Wd, gQ, W2)
+            if g_pass is not None:
+                gx = gx + g_pass
         if ctx.needs_input_grad[1]:
             gWd = _native.xty(gP.contiguous(), x)
             gW2 = _native.xty(gQ, x)
             gW = torch.cat([gWd, gW2 - gWd], dim=1)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = gP.sum(0)
-        return gx, gW, gb, None, None
+        return gx, gW, gb, None, None, None
 
 
 class _EdgeFeatures(torch.autograd.Function):
@@ -179,11 +186,12 @@ class EdgeConv(torch.nn.Module):
         return self.nn(torch.cat([x_i, x_j - x_i], dim=-1))
 
     # -- the two execution paths ---------------------------------------------------------------------------
-    def _forward_table(self, x: torch.Tensor, table: NeighborTable) -> torch.Tensor:
+    def _forward_table(self, x: torch.Tensor, table: NeighborTable, passthrough: bool = False):
         lin = _as_fusable_linear(self.nn) if self.aggr == "max" else None
         if lin is not None and x.shape[1] * 2 == lin.in_features and table.k <= 255:  # arg slot is uint8
-            return _EdgeConvLinearMax.apply(x, lin.weight, lin.bias, table, self._use_bf16(lin, table))
-        return self._forward_edges(x, table.edge_list())
+            return _EdgeConvLinearMax.apply(x, lin.weight, lin.bias, table, self._use_bf16(lin, table), passthrough)
+        out = self._forward_edges(x, table.edge_list())
+        return (out, x) if passthrough else out
 
     def _use_bf16(self, lin: torch.nn.Linear, table: NeighborTable) -> bool:
         dt = self.compute_dtype
@@ -254,6 +262,15 @@ class DynamicEdgeConv(EdgeConv):
             raise TypeError(f"x must be float32, got {x.dtype}")
         table = knn_table(x, self.k, batch, loop=True)
         return self._forward_table(x, table)
+
+    def forward_with_residual_input(self, x: torch.Tensor, batch: Optional[torch.Tensor] = None):
+        """(conv(x), x'): x' is x routed through this operator's autograd node, for blocks of the form
+        `x + f(conv(x))` (graph_met_network.py:66).  Using x' for the residual branch makes both gradients of x meet
+        in this operator's backward kernel, which adds them while storing gx (no separate elementwise add)."""
+        if x.dim() != 2 or x.dtype != torch.float32:
+            return self.forward(x, batch), x
+        table = knn_table(x, self.k, batch, loop=True)
+        return self._forward_table(x, table, passthrough=True)
 
     def __repr__(self) -> str:
         return f"{self.__class__.__name__}(nn={self.nn}, k={self.k})"

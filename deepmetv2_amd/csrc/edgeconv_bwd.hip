@@ -24,6 +24,8 @@ constexpr int kChunk = 32;                 // nodes per MFMA row tile
 constexpr int kPad = 36;                   // LDS row stride in floats (16-byte aligned rows, banks spread)
 constexpr int kWavesPerBlock = 4;
 constexpr int kPartial = 2 * 1024 + kH;    // per wavefront: gP^T x, gQ^T x, column sums of gP
+constexpr int kFinGroups = 33;             // finalize: 32 groups of 32 weight-tile elements + the bias
+constexpr int kFinChunks = 8;              // ... each summed over 8 contiguous ranges of wavefronts by separate workgroups
 
 __device__ __forceinline__ void ecb_wave_sync()
 {
@@ -35,13 +37,15 @@ __device__ __forceinline__ void ecb_wave_sync()
 __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd_kernel(
     const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ g_out,
     const uint8_t *__restrict__ arg, const float *__restrict__ gQ, int64_t N, int64_t nodes_per_wave,
-    float *__restrict__ gx, float *__restrict__ partial)
+    const float *__restrict__ g_add, float *__restrict__ gx, float *__restrict__ partial,
+    int *__restrict__ fin_counters)
 {
     __shared__ float sP[kWavesPerBlock][kChunk * kPad];
     __shared__ float sQ[kWavesPerBlock][kChunk * kPad];
     __shared__ float sX[kWavesPerBlock][kChunk * kPad];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 31, hh = lane >> 5;
+    if (blockIdx.x == 0 && threadIdx.x < kFinGroups) fin_counters[threadIdx.x] = 0;   // tickets of the finalize kernel
     float *P = sP[wv], *Q = sQ[wv], *X = sX[wv];
     const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wv;
     const int64_t lo = wave * nodes_per_wave, hi = min(N, lo + nodes_per_wave);
@@ -61,12 +65,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd
     float bsum = 0.0f;
 
     const int lr = lane >> 3, lp = lane & 7;      // loader role: row within a group of 8, float4 column
-    for (int64_t base = lo; base < hi; base += kChunk) {
-        ecb_wave_sync();                           // previous chunk's tiles are consumed
+    // software pipeline: the rows of the NEXT chunk are loaded into registers while the matrix products of the
+    // current one run (two wavefronts per SIMD do not hide a global round trip per chunk by themselves)
+    float4 np[kChunk / 8], nq[kChunk / 8], nx[kChunk / 8];
+    auto fetch = [&](const int64_t base) {
 #pragma unroll
         for (int g = 0; g < kChunk / 8; ++g) {
-            const int r = g * 8 + lr;
-            const int64_t i = base + r;
+            const int64_t i = base + g * 8 + lr;
             float4 vp = make_float4(0.f, 0.f, 0.f, 0.f), vq = vp, vx = vp;
             if (i < hi) {
                 vp = reinterpret_cast<const float4 *>(g_out + i * kH)[lp];
@@ -80,11 +85,29 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd
                     if (a4.w == 255) vp.w = 0.f;
                 }
             }
-            *reinterpret_cast<float4 *>(&P[r * kPad + 4 * lp]) = vp;
-            *reinterpret_cast<float4 *>(&Q[r * kPad + 4 * lp]) = vq;
-            *reinterpret_cast<float4 *>(&X[r * kPad + 4 * lp]) = vx;
+            np[g] = vp; nq[g] = vq; nx[g] = vx;
+        }
+    };
+    if (lo < hi) fetch(lo);
+    for (int64_t base = lo; base < hi; base += kChunk) {
+        ecb_wave_sync();                           // previous chunk's tiles are consumed
+#pragma unroll
+        for (int g = 0; g < kChunk / 8; ++g) {
+            const int r = g * 8 + lr;
+            *reinterpret_cast<float4 *>(&P[r * kPad + 4 * lp]) = np[g];
+            *reinterpret_cast<float4 *>(&Q[r * kPad + 4 * lp]) = nq[g];
+            *reinterpret_cast<float4 *>(&X[r * kPad + 4 * lp]) = nx[g];
         }
         ecb_wave_sync();
+        // the residual branch's gradient of THIS chunk as row segments (loader layout), used after the products
+        float4 ga[kChunk / 8];
+#pragma unroll
+        for (int g = 0; g < kChunk / 8; ++g) {
+            const int64_t i = base + g * 8 + lr;
+            ga[g] = (g_add && i < hi) ? reinterpret_cast<const float4 *>(g_add + i * kH)[lp]
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (base + kChunk < hi) fetch(base + kChunk);
         // gx tile [32 nodes][32 features] = [gP | gQ] . Wst   (A operand: lane (node c, hh) supplies G[c][2 s + hh])
         f32x16 accx;
 #pragma unroll
@@ -108,11 +131,20 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd
             for (int n = 0; n < 16; ++n) t += P[(hh * 16 + n) * kPad + c];
             bsum += t;
         }
-        // store gx: accx[e] = row (e&3) + 8 (e>>2) + 4 hh, column c
+        // store gx (+ the residual branch's gradient): accx[e] = row (e&3) + 8 (e>>2) + 4 hh, column c, transposed
+        // through the P tile (consumed by now) so that global memory sees 16-byte row segments
+        ecb_wave_sync();
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int64_t i = base + (e & 3) + 8 * (e >> 2) + 4 * hh;
-            if (i < hi) gx[i * kH + c] = accx[e];
+        for (int e = 0; e < 16; ++e) P[((e & 3) + 8 * (e >> 2) + 4 * hh) * kPad + c] = accx[e];
+        ecb_wave_sync();
+#pragma unroll
+        for (int g = 0; g < kChunk / 8; ++g) {
+            const int r = g * 8 + lr;
+            const int64_t i = base + r;
+            const float4 t = *reinterpret_cast<const float4 *>(&P[r * kPad + 4 * lp]);
+            if (i < hi)
+                reinterpret_cast<float4 *>(gx + i * kH)[lp] =
+                    make_float4(t.x + ga[g].x, t.y + ga[g].y, t.z + ga[g].z, t.w + ga[g].w);
         }
     }
     float *out = partial + wave * (int64_t)kPartial;
@@ -127,33 +159,57 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd
 }
 
 // gW[o][0:32] = sum gP^T x,  gW[o][32:64] = sum gQ^T x - sum gP^T x,  gb[o] = sum gP.  Partials are added in a fixed
-// order: 32 thread groups each take every 32nd wavefront, then the 32 group sums are added in order.  Blocks 0..31 own
-// 32 elements of both weight tiles, block 32 the bias.
+// order: the wavefronts are cut into kFinChunks contiguous ranges; inside a range 32 thread groups each take every
+// 32nd wavefront and the 32 group sums are added in order; the workgroup that finishes LAST for an element group
+// (ticket counter) adds the kFinChunks range sums in order.  Which workgroup that is varies, the sum order does not.
+// Workgroup (cg, q): element group cg (0..31: 32 elements of both weight tiles; 32: the bias), range q.
 __global__ __launch_bounds__(1024) void edgeconv_linear_bwd_finalize_kernel(const float *__restrict__ partial,
-                                                                             int64_t nwaves, float *__restrict__ gW,
+                                                                             int64_t nwaves, float *chunk_sums,
+                                                                             int *fin_counters,
+                                                                             float *__restrict__ gW,
                                                                              float *__restrict__ gb)
 {
     __shared__ float red0[32][33], red1[32][33];
+    __shared__ int ticket;
+    const int cg = blockIdx.x / kFinChunks, q = blockIdx.x % kFinChunks;
     const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const bool bias = blockIdx.x == 32;
-    const int idx = bias ? (2048 + e) : (blockIdx.x * 32 + e);
+    const bool bias = cg == 32;
+    const int idx = bias ? (2048 + e) : (cg * 32 + e);
+    const int64_t per = (nwaves + kFinChunks - 1) / kFinChunks;
+    const int64_t w0 = q * per, w1 = min(nwaves, w0 + per);
     float s0 = 0.0f, s1 = 0.0f;
     if (bias) {
 #pragma unroll 8   // independent loads: keep eight in flight (the sum order is unchanged)
-        for (int64_t w = grp; w < nwaves; w += 32) s0 += partial[w * kPartial + idx];
+        for (int64_t w = w0 + grp; w < w1; w += 32) s0 += partial[w * kPartial + idx];
     } else {
 #pragma unroll 8
-        for (int64_t w = grp; w < nwaves; w += 32) {
+        for (int64_t w = w0 + grp; w < w1; w += 32) {
             s0 += partial[w * kPartial + idx];
             s1 += partial[w * kPartial + 1024 + idx];
         }
     }
     red0[grp][e] = s0; red1[grp][e] = s1;
     __syncthreads();
-    if (grp != 0) return;
+    if (grp == 0) {
+        s0 = 0.0f; s1 = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) { s0 += red0[g][e]; s1 += red1[g][e]; }
+        chunk_sums[q * kPartial + idx] = s0;
+        if (!bias) chunk_sums[q * kPartial + 1024 + idx] = s1;
+        __threadfence();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ticket = atomicAdd(&fin_counters[cg], 1);
+    __syncthreads();
+    if (ticket != kFinChunks - 1 || grp != 0) return;
+    __threadfence();
     s0 = 0.0f; s1 = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 32; ++q) { s0 += red0[q][e]; s1 += red1[q][e]; }
+    for (int qq = 0; qq < kFinChunks; ++qq) {
+        s0 += __hip_atomic_load(&chunk_sums[qq * kPartial + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!bias)
+            s1 += __hip_atomic_load(&chunk_sums[qq * kPartial + 1024 + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (bias) {
         if (gb) gb[e] = s0;
     } else {
@@ -270,29 +326,41 @@ extern "C" size_t dmet_edgeconv_linear_bwd_workspace_bytes(int64_t N, int H)
     if (N <= 0 || H != kH) return 0;
     int64_t nw;
     (void)ecb_nodes_per_wave(N, &nw);
-    return sizeof(float) * (size_t)nw * kPartial + 512;
+    return sizeof(float) * ((size_t)nw + kFinChunks) * kPartial + sizeof(int) * 64 + 512;
+}
+
+extern "C" int dmet_edgeconv_linear_bwd_add_f32(const float *x, const float *W, const float *g_out,
+                                                const uint8_t *arg, const float *gQ, const float *g_add, int64_t N,
+                                                int H, float *gx, float *gW, float *gb, void *ws, size_t ws_bytes,
+                                                dmet_stream_t stream)
+{
+    DMET_REQUIRE(H == kH, "dmet_edgeconv_linear_bwd_f32: H=%d (only 32 is built)", H);
+    DMET_REQUIRE(N > 0, "dmet_edgeconv_linear_bwd_f32: N=%lld", (long long)N);
+    DMET_REQUIRE(x && W && g_out && gQ && gx && gW && ws, "dmet_edgeconv_linear_bwd_f32: null pointer");
+    DMET_REQUIRE(aligned16(x) && aligned16(g_out) && aligned16(gQ) && aligned16(gx) && aligned16(g_add) &&
+                     (!arg || (reinterpret_cast<uintptr_t>(arg) & 3u) == 0),
+                 "dmet_edgeconv_linear_bwd_f32: rows must be 16-byte aligned");
+    DMET_REQUIRE(ws_bytes >= dmet_edgeconv_linear_bwd_workspace_bytes(N, H), "dmet_edgeconv_linear_bwd_f32: workspace too small");
+    int64_t nw;
+    const int64_t npw = ecb_nodes_per_wave(N, &nw);
+    float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u);
+    float *chunk_sums = partial + (size_t)nw * kPartial;
+    int *fin_counters = reinterpret_cast<int *>(chunk_sums + (size_t)kFinChunks * kPartial);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(edgeconv_linear_bwd_kernel, dim3((unsigned)(nw / kWavesPerBlock)), dim3(kWave * kWavesPerBlock), 0, st,
+                       x, W, g_out, arg, gQ, N, npw, g_add, gx, partial, fin_counters);
+    DMET_LAUNCH_CHECK("edgeconv_linear_bwd_kernel");
+    hipLaunchKernelGGL(edgeconv_linear_bwd_finalize_kernel, dim3(kFinGroups * kFinChunks), dim3(1024), 0, st, partial, nw,
+                       chunk_sums, fin_counters, gW, gb);
+    DMET_LAUNCH_CHECK("edgeconv_linear_bwd_finalize_kernel");
+    return 0;
 }
 
 extern "C" int dmet_edgeconv_linear_bwd_f32(const float *x, const float *W, const float *g_out, const uint8_t *arg,
                                             const float *gQ, int64_t N, int H, float *gx, float *gW, float *gb,
                                             void *ws, size_t ws_bytes, dmet_stream_t stream)
 {
-    DMET_REQUIRE(H == kH, "dmet_edgeconv_linear_bwd_f32: H=%d (only 32 is built)", H);
-    DMET_REQUIRE(N > 0, "dmet_edgeconv_linear_bwd_f32: N=%lld", (long long)N);
-    DMET_REQUIRE(x && W && g_out && gQ && gx && gW && ws, "dmet_edgeconv_linear_bwd_f32: null pointer");
-    DMET_REQUIRE(aligned16(x) && aligned16(g_out) && aligned16(gQ) && aligned16(gx) && (!arg || (reinterpret_cast<uintptr_t>(arg) & 3u) == 0),
-                 "dmet_edgeconv_linear_bwd_f32: rows must be 16-byte aligned");
-    DMET_REQUIRE(ws_bytes >= dmet_edgeconv_linear_bwd_workspace_bytes(N, H), "dmet_edgeconv_linear_bwd_f32: workspace too small");
-    int64_t nw;
-    const int64_t npw = ecb_nodes_per_wave(N, &nw);
-    float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u);
-    hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(edgeconv_linear_bwd_kernel, dim3((unsigned)(nw / kWavesPerBlock)), dim3(kWave * kWavesPerBlock), 0, st,
-                       x, W, g_out, arg, gQ, N, npw, gx, partial);
-    DMET_LAUNCH_CHECK("edgeconv_linear_bwd_kernel");
-    hipLaunchKernelGGL(edgeconv_linear_bwd_finalize_kernel, dim3(33), dim3(1024), 0, st, partial, nw, gW, gb);
-    DMET_LAUNCH_CHECK("edgeconv_linear_bwd_finalize_kernel");
-    return 0;
+    return dmet_edgeconv_linear_bwd_add_f32(x, W, g_out, arg, gQ, nullptr, N, H, gx, gW, gb, ws, ws_bytes, stream);
 }
 
 extern "C" int dmet_gather_max_bwd_lds16_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr,

@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256) void knn_plan_kernel(const int64_t *__restrict
     __syncthreads();
     if (tid == 0) {
         int run = 0;
-        for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        const int owners = chunk > 0 ? (B + chunk - 1) / chunk : 0;   // threads beyond this own no event
+        for (int i = 0; i < owners; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        for (int i = owners; i < 256; ++i) part[i] = run;
         const int tiles = run;
         int n_full = tiles, split = 1;
         // the tiles beyond the last full round of `simds` -- ALL tiles when the batch is small -- are cut into
@@ -585,10 +587,19 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float f)   // finite inputs
 }
 
 // Squared norms and the bf16 split of x: 8 lanes per row (one float4 each), so loads and stores are contiguous.
+// Also clears the uncertified-query counters / flags (zero_bytes bytes at `zero`, 4-byte aligned) for the launches
+// that follow, which saves a memset launch per call.
 __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__ x, int64_t N, float *__restrict__ nrm,
-                                                        unsigned short *__restrict__ xs)
+                                                        unsigned short *__restrict__ xs, uint32_t *__restrict__ zero,
+                                                        size_t zero_bytes)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    {
+        const size_t words = zero_bytes >> 2, total = (size_t)gridDim.x * blockDim.x;
+        for (size_t wd = (size_t)t; wd < words; wd += total) zero[wd] = 0u;
+        if (t == 0)
+            for (size_t bt = words << 2; bt < zero_bytes; ++bt) reinterpret_cast<uint8_t *>(zero)[bt] = 0;
+    }
     const int64_t row = t >> 3;
     const int part = (int)(t & 7);
     const bool live = row < N;
@@ -1133,18 +1144,28 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
 // the exact R1 chain (distances cached in LDS when the event fits), then k rounds of "smallest (d, j) above the
 // previous pick" (R2) with a wavefront + cross-wavefront reduction.
 constexpr int kRequeryMax = 8;
+constexpr int kRequeryTiles = 8;   // consecutive tiles per workgroup
 constexpr int kRequeryCache = 16384;   // floats
 
-__global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a, const KnnPlan *__restrict__ xplan)
+__global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a, int ntiles)
 {
     __shared__ float cache[kRequeryCache];
     __shared__ float red_d[4];
     __shared__ int red_j[4];
-    const int tile = blockIdx.x;
-    if (tile >= xplan->total_tiles) return;
-    const int nflag = a.flags[tile];
-    if (nflag == 0 || nflag > kRequeryMax) return;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    // a workgroup owns kRequeryTiles consecutive tiles and reads their counters in one round trip: almost every tile
+    // has nothing to redo, and a workgroup per tile (each holding the distance cache in LDS) spent 10 us on
+    // workgroups that exit at once.  Counters of tiles beyond the plan's total are zero (cleared per call).
+    __shared__ int tile_flags[kRequeryTiles];
+    if (tid < kRequeryTiles) {
+        const int tile = blockIdx.x * kRequeryTiles + tid;
+        tile_flags[tid] = tile < ntiles ? a.flags[tile] : 0;
+    }
+    __syncthreads();
+    for (int ti = 0; ti < kRequeryTiles; ++ti) {
+    const int tile = blockIdx.x * kRequeryTiles + ti;
+    const int nflag = tile_flags[ti];
+    if (nflag == 0 || nflag > kRequeryMax) continue;   // block-uniform
     const int pos = find_tile_event(a.xtile_ptr, a.B, tile);
     const int ev = a.order[pos];
     const int ev_lo = (int)a.ptr[ev], ev_hi = (int)a.ptr[ev + 1];
@@ -1214,6 +1235,8 @@ __global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a,
             }
             last_d = bd; last_j = bj;
         }
+    }
+    __syncthreads();   // the next tile reuses the cache and the reduction slots
     }
 }
 
@@ -1308,7 +1331,8 @@ template <int KF>
 int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, hipStream_t st)
 {
     const int slots = simds * 2;   // two filter wavefronts per SIMD
-    hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((f.N * 8 + 255) / 256)), dim3(256), 0, st, f.x, f.N, w.nrm, w.xs);
+    hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((f.N * 8 + 255) / 256)), dim3(256), 0, st, f.x, f.N, w.nrm, w.xs,
+                       reinterpret_cast<uint32_t *>(w.flags), w.zero_bytes);
     DMET_LAUNCH_CHECK("knn_prep_kernel");
     const int64_t ftiles_max = (f.N + kFQ - 1) / kFQ + f.B;
     const int64_t fblocks = (ftiles_max + slots + kWavesPerGroup - 1) / kWavesPerGroup;
@@ -1339,8 +1363,10 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     hipLaunchKernelGGL(knn_plan_kernel, dim3(use_filter ? 2 : 1), dim3(256), 0, st, ptr, B, px, pf);
     DMET_LAUNCH_CHECK("knn_plan_kernel");
     KnnArgs a{x, ptr, B, N, D, k, nbr, dist, nbr16, w.wsd, w.wsj, w.plan, w.order, w.tile_ptr, w.psd, w.psj, nullptr, 0};
-    // uncertified-query counters: zero for every call, so dmet_knn_fallback_stats is meaningful on any path
-    if (hipMemsetAsync(w.flags, 0, w.zero_bytes, st) != hipSuccess) return hip_fail(hipGetLastError(), "hipMemsetAsync");
+    // uncertified-query counters: zero for every call, so dmet_knn_fallback_stats is meaningful on any path (the
+    // matrix-core path clears them in its prep kernel)
+    if (!use_filter && hipMemsetAsync(w.flags, 0, w.zero_bytes, st) != hipSuccess)
+        return hip_fail(hipGetLastError(), "hipMemsetAsync");
 
     // matrix-core filter + exact re-rank for the hot shape (D = 32, k <= 20); the exact kernel then only recomputes
     // the tiles the re-rank could not certify
@@ -1354,7 +1380,9 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
         if (rc) return rc;
         if (filter_mode() == 2) return 0;
         const int64_t xtiles_max = (N + QT - 1) / QT + B;
-        hipLaunchKernelGGL(knn_requery_kernel, dim3((unsigned)xtiles_max), dim3(256), 0, st, f, w.plan);
+        // counters exist (and are cleared) for at least xtiles_max tiles; the kernel reads none beyond that
+        hipLaunchKernelGGL(knn_requery_kernel, dim3((unsigned)((xtiles_max + kRequeryTiles - 1) / kRequeryTiles)), dim3(256),
+                           0, st, f, (int)xtiles_max);
         DMET_LAUNCH_CHECK("knn_requery_kernel");
         a.flags = w.flags;
         a.flag_min = kRequeryMax + 1;

@@ -89,8 +89,12 @@ class GraphMETNetwork(nn.Module):
         Net does), which lets the standard head shape run as one HIP kernel each way (csrc/head.hip)."""
         emb = self.embed(x_cont, x_cat)
         for conv, norm in self.conv_continuous:
-            msg = conv(emb, batch) if self.graph == "dynamic" else conv(emb, edge_index)
-            emb = dense.batch_norm(msg, norm, residual=emb)   # emb + norm(msg) in one streaming kernel
+            if self.graph == "dynamic":
+                # res is emb routed through the conv's autograd node: both gradients of emb meet in its backward
+                msg, res = conv.forward_with_residual_input(emb, batch)
+            else:
+                msg, res = conv(emb, edge_index), emb
+            emb = dense.batch_norm(msg, norm, residual=res)   # emb + norm(msg) in one streaming kernel
         if apply_sigmoid and self._fused_head_ok(emb):
             l1, l2 = self.output[0], self.output[2]
             return dense.head(emb, l1.weight, l1.bias, l2.weight, l2.bias)

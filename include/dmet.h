@@ -239,6 +239,12 @@ size_t dmet_edgeconv_linear_bwd_workspace_bytes(int64_t N, int H);
 int dmet_edgeconv_linear_bwd_f32(const float *x, const float *W, const float *g_out, const uint8_t *arg,
                                  const float *gQ, int64_t N, int H, float *gx, float *gW, float *gb, void *ws,
                                  size_t ws_bytes, dmet_stream_t stream);
+/* Same with gx += g_add[N,H] fused into the store (g_add may be NULL): the gradient that reaches x through the
+ * residual connection of the block (graph_met_network.py:66: emb = emb + norm(conv(emb))), instead of a separate
+ * elementwise add over the node table. */
+int dmet_edgeconv_linear_bwd_add_f32(const float *x, const float *W, const float *g_out, const uint8_t *arg,
+                                     const float *gQ, const float *g_add, int64_t N, int H, float *gx, float *gW,
+                                     float *gb, void *ws, size_t ws_bytes, dmet_stream_t stream);
 
 /* ---- N3 (third piece): BatchNorm1d over the nodes, optionally fused with the residual add ---------------
  * model/graph_met_network.py:32,39,58,66: bn_all(...) and emb + bn(conv(...)).  x[N,H] row-major, H a multiple of 4

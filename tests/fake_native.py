@@ -226,11 +226,13 @@ def bn_bwd(x, g_y, gamma, mean, invstd):
     return g_x, g_w, g_b
 
 
-def edgeconv_linear_bwd(x, weight, g_out, arg, gQ, want_bias=True):
+def edgeconv_linear_bwd(x, weight, g_out, arg, gQ, want_bias=True, g_add=None):
     H = x.shape[1]
     gP = g_out if arg is None else g_out * (arg != 255).to(g_out.dtype)
     Wd, W2 = weight[:, :H] - weight[:, H:], weight[:, H:]
     gx = gP @ Wd + gQ @ W2
+    if g_add is not None:
+        gx = gx + g_add
     gWd = gP.t() @ x
     gW = torch.cat([gWd, gQ.t() @ x - gWd], dim=1)
     return gx, gW, (gP.sum(0) if want_bias else None)
