@@ -266,6 +266,16 @@ def test_dynamic_edgeconv_fused_fwd_bwd(dev, sizes, H, k):
     _close(xd.grad.cpu(), gx_ref, rtol=1e-4, atol=1e-5 * max(scale, 1.0))
     _close(lin[0].weight.grad.cpu(), gW_ref, rtol=1e-4, atol=1e-5 * float(gW_ref.abs().max()))
     _close(lin[0].bias.grad.cpu(), gb_ref, rtol=1e-4, atol=1e-5 * float(gb_ref.abs().max()))
+    # residual-input form (graph_met_network.py:66, x + f(conv(x))): x handed through the conv's autograd node, its
+    # second gradient added inside the backward kernel -- must equal the plain two-consumer graph
+    lin.zero_grad()
+    x2 = x.clone().to(dev).requires_grad_(True)   # clone: on the CPU mirror of this test .to() would alias xd
+    out2, res = conv.forward_with_residual_input(x2, batch.to(dev))
+    gres = torch.randn(x.shape, generator=torch.Generator().manual_seed(2))
+    (out2 * gup.to(dev)).sum().add((res * gres.to(dev)).sum()).backward()
+    assert torch.equal(out2.detach(), out.detach()) and torch.equal(res.detach(), x2.detach())
+    _close(x2.grad.cpu(), gx_ref + gres, rtol=1e-4, atol=1e-5 * max(scale, 1.0))
+    _close(lin[0].weight.grad.cpu(), gW_ref, rtol=1e-4, atol=1e-5 * float(gW_ref.abs().max()))
 
 
 @pytest.mark.parametrize("sizes,k", [([256], 8), ([50, 450, 800], 16), ([1, 3, 0, 17, 129], 16), ([300, 100], 32)])
