@@ -269,7 +269,7 @@ def test_dynamic_edgeconv_fused_fwd_bwd(dev, sizes, H, k):
     # residual-input form (graph_met_network.py:66, x + f(conv(x))): x handed through the conv's autograd node, its
     # second gradient added inside the backward kernel -- must equal the plain two-consumer graph
     lin.zero_grad()
-    x2 = x.clone().to(dev).requires_grad_(True)   # clone: on the CPU mirror of this test .to() would alias xd
+    x2 = x.detach().clone().to(dev).requires_grad_(True)   # fresh leaf: on the CPU mirror of this test .to() aliases xd
     out2, res = conv.forward_with_residual_input(x2, batch.to(dev))
     gres = torch.randn(x.shape, generator=torch.Generator().manual_seed(2))
     (out2 * gup.to(dev)).sum().add((res * gres.to(dev)).sum()).backward()
