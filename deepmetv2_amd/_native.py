@@ -146,7 +146,10 @@ def knn_local(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict] 
     return _knn(x, ptr, k, stats, True)
 
 
-def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int, skip_self: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int, skip_self: bool = False,
+           pad: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(nbr[N,max_nbr] int32, cnt[N] int32).  pad=False leaves the slots >= cnt[i] unwritten instead of filling them
+    with -1 (the fill is most of a 255-wide table's bytes); only for consumers that go by cnt."""
     dev = _require_device(x, ptr)
     L = _lib.load()
     x = _f32c(x.detach(), "x")
@@ -155,8 +158,9 @@ def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int, skip_self
     nbr = torch.empty((N, max_nbr), dtype=torch.int32, device=dev)
     cnt = torch.empty((N,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(L.dmet_radius_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, float(r), max_nbr, 1 if skip_self else 0,
-                                     nbr.data_ptr(), cnt.data_ptr(), _stream(dev)), "dmet_radius_f32")
+        fn = L.dmet_radius_f32 if pad else L.dmet_radius_counted_f32
+        _lib.check(fn(x.data_ptr(), ptr.data_ptr(), B, N, D, float(r), max_nbr, 1 if skip_self else 0,
+                      nbr.data_ptr(), cnt.data_ptr(), _stream(dev)), "dmet_radius_f32")
     return nbr, cnt
 
 

@@ -85,7 +85,8 @@ def radius_table(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None
     # upstream's loop=False: search max_num_neighbors + 1 and drop the node itself (done inside the kernel)
     m = max_num_neighbors if loop else max_num_neighbors + 1
     info = batch_info(batch, x.shape[0], x.device, num_events)
-    nbr, _cnt = _native.radius(x, info.ptr, r, m, skip_self=not loop)
+    # no -1 fill of the unused slots: every consumer of a table with `cnt` goes by cnt
+    nbr, _cnt = _native.radius(x, info.ptr, r, m, skip_self=not loop, pad=False)
     return NeighborTable(nbr, info.ptr, dense=False, max_nodes=info.max_nodes, cnt=_cnt)
 
 

@@ -233,6 +233,16 @@ class EdgeConv(torch.nn.Module):
             return self._forward_table(x, hit[0])
         return self._forward_edges(x, edge_list_from_edge_index(edge_index, x.shape[0], self.flow))
 
+    def forward_with_residual_input(self, x: torch.Tensor, edge_index: torch.Tensor):
+        """(conv(x), x'): x' is x routed through this operator's autograd node, for blocks of the form
+        `x + f(conv(x))` (graph_met_network.py:66).  Using x' for the residual branch makes both gradients of x meet
+        in this operator's backward kernel, which adds them while storing gx (no separate elementwise add)."""
+        if torch.is_tensor(x) and x.dim() == 2 and x.dtype == torch.float32:
+            hit = lookup_graph(edge_index)
+            if hit is not None and hit[1] == self.flow and hit[0].num_nodes == x.shape[0]:
+                return self._forward_table(x, hit[0], passthrough=True)
+        return self.forward(x, edge_index), x
+
     def __repr__(self) -> str:
         return f"{self.__class__.__name__}(nn={self.nn})"
 
@@ -264,9 +274,7 @@ class DynamicEdgeConv(EdgeConv):
         return self._forward_table(x, table)
 
     def forward_with_residual_input(self, x: torch.Tensor, batch: Optional[torch.Tensor] = None):
-        """(conv(x), x'): x' is x routed through this operator's autograd node, for blocks of the form
-        `x + f(conv(x))` (graph_met_network.py:66).  Using x' for the residual branch makes both gradients of x meet
-        in this operator's backward kernel, which adds them while storing gx (no separate elementwise add)."""
+        """EdgeConv.forward_with_residual_input for the dynamic graph: (conv(x), x')."""
         if x.dim() != 2 or x.dtype != torch.float32:
             return self.forward(x, batch), x
         table = knn_table(x, self.k, batch, loop=True)

@@ -1565,8 +1565,8 @@ extern "C" int dmet_knn_fallback_stats(const void *ws, int64_t N, int B, int D, 
     return 0;
 }
 
-extern "C" int dmet_radius_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr,
-                               int skip_self, int32_t *nbr, int32_t *cnt, dmet_stream_t stream)
+static int radius_impl(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr,
+                       int skip_self, bool fill, int32_t *nbr, int32_t *cnt, dmet_stream_t stream)
 {
     DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_radius_f32: N out of range");
     DMET_REQUIRE(D >= 1 && D <= 8, "dmet_radius_f32: D=%d not in [1,8]", D);
@@ -1576,9 +1576,12 @@ extern "C" int dmet_radius_f32(const float *x, const int64_t *ptr, int B, int64_
     const float r2 = r * r;
     const int64_t blocks = (N + 4 * kWave - 1) / (4 * kWave);
     hipStream_t st = as_stream(stream);
-    // empty slots are -1: one coalesced fill instead of per-lane tail stores
-    hipError_t me = hipMemsetAsync(nbr, 0xff, sizeof(int32_t) * (size_t)N * (size_t)max_nbr, st);
-    if (me != hipSuccess) return hip_fail(me, "hipMemsetAsync(nbr)");
+    // empty slots are -1: one coalesced fill instead of per-lane tail stores (294 MB for 288 000 x 255: the counted
+    // form leaves them unwritten, its consumers go by cnt)
+    if (fill) {
+        hipError_t me = hipMemsetAsync(nbr, 0xff, sizeof(int32_t) * (size_t)N * (size_t)max_nbr, st);
+        if (me != hipSuccess) return hip_fail(me, "hipMemsetAsync(nbr)");
+    }
     if (D <= 2)
         hipLaunchKernelGGL((radius_kernel<2>), dim3((unsigned)blocks), dim3(kWave * 4), 0, st, x, ptr, B, N, D, r2,
                            max_nbr, skip_self, nbr, cnt);
@@ -1590,4 +1593,16 @@ extern "C" int dmet_radius_f32(const float *x, const int64_t *ptr, int B, int64_
                            max_nbr, skip_self, nbr, cnt);
     DMET_LAUNCH_CHECK("radius_kernel");
     return 0;
+}
+
+extern "C" int dmet_radius_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr,
+                               int skip_self, int32_t *nbr, int32_t *cnt, dmet_stream_t stream)
+{
+    return radius_impl(x, ptr, B, N, D, r, max_nbr, skip_self, true, nbr, cnt, stream);
+}
+
+extern "C" int dmet_radius_counted_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r,
+                                       int max_nbr, int skip_self, int32_t *nbr, int32_t *cnt, dmet_stream_t stream)
+{
+    return radius_impl(x, ptr, B, N, D, r, max_nbr, skip_self, false, nbr, cnt, stream);
 }

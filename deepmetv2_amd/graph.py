@@ -155,7 +155,8 @@ def edge_list_from_edge_index(edge_index: torch.Tensor, num_nodes: int, flow: st
 # fixed-width neighbour table (what the kNN / radius kernels emit)
 # ---------------------------------------------------------------------------------------------------------------
 class NeighborTable:
-    """nbr[N,k] int32 global node ids, -1 = empty slot.  Row i lists the message SOURCES of target i."""
+    """nbr[N,k] int32 global node ids, -1 = empty slot.  Row i lists the message SOURCES of target i.
+    With `cnt` (radius tables) only the first cnt[i] slots of row i are defined; the rest may be unwritten."""
 
     def __init__(self, nbr: torch.Tensor, ptr: Optional[torch.Tensor], dense: bool, dist: Optional[torch.Tensor] = None,
                  max_nodes: Optional[int] = None, cnt: Optional[torch.Tensor] = None,
@@ -181,7 +182,8 @@ class NeighborTable:
             else:
                 # wide, shallow table: sort the valid entries only (a 255-wide radius table is ~85 % padding)
                 flat = self.nbr.view(-1)
-                pos = torch.nonzero(flat >= 0).view(-1).to(torch.int32)
+                slot = torch.arange(self.k, device=flat.device, dtype=torch.int32).view(1, -1)
+                pos = torch.nonzero((slot < self.cnt.view(-1, 1)).view(-1)).view(-1).to(torch.int32)
                 keys = flat[pos.long()].contiguous()
                 rev_ptr, rev_e = _native.reverse_index(keys, self.num_nodes)
                 self._rev = (rev_ptr, pos[rev_e[: keys.numel()].long()].contiguous())

@@ -89,11 +89,8 @@ class GraphMETNetwork(nn.Module):
         Net does), which lets the standard head shape run as one HIP kernel each way (csrc/head.hip)."""
         emb = self.embed(x_cont, x_cat)
         for conv, norm in self.conv_continuous:
-            if self.graph == "dynamic":
-                # res is emb routed through the conv's autograd node: both gradients of emb meet in its backward
-                msg, res = conv.forward_with_residual_input(emb, batch)
-            else:
-                msg, res = conv(emb, edge_index), emb
+            # res is emb routed through the conv's autograd node: both gradients of emb meet in its backward
+            msg, res = conv.forward_with_residual_input(emb, batch if self.graph == "dynamic" else edge_index)
             emb = dense.batch_norm(msg, norm, residual=res)   # emb + norm(msg) in one streaming kernel
         if apply_sigmoid and self._fused_head_ok(emb):
             l1, l2 = self.output[0], self.output[2]

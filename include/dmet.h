@@ -75,6 +75,11 @@ int dmet_knn_fallback_stats(const void *ws, int64_t N, int B, int D, int k, int6
  * towards the search limit when it is met but is not stored. */
 int dmet_radius_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr, int skip_self,
                     int32_t *nbr, int32_t *cnt, dmet_stream_t stream);
+/* Same, but slots >= cnt[i] of row i are left UNWRITTEN (no -1 fill of the max_nbr-wide table: the reference's
+ * max_num_neighbors=255 rows are ~36 deep, so the fill is most of the table's bytes).  For consumers that go by cnt:
+ * dmet_gather_max_counted_f32, dmet_table_degree / dmet_table_edges, the arg-addressed backward. */
+int dmet_radius_counted_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr,
+                            int skip_self, int32_t *nbr, int32_t *cnt, dmet_stream_t stream);
 
 /* ---- K2+K3 fused: EdgeConv with nn = Linear(2*Hin -> Hout), aggr = 'max', fixed-width table ---------
  * replaces torch_geometric.nn.EdgeConv(nn=Sequential(Linear(2H,H)), aggr='max').forward

@@ -24,7 +24,7 @@ def knn_local(x, ptr, k, stats=None):
     return nbr, dist, loc
 
 
-def radius(x, ptr, r, max_nbr, skip_self=False):
+def radius(x, ptr, r, max_nbr, skip_self=False, pad=True):
     import ctypes  # noqa: F401
     x = x.detach().float().contiguous()
     N, D = x.shape
@@ -39,6 +39,9 @@ def radius(x, ptr, r, max_nbr, skip_self=False):
         order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)
         nbr = torch.gather(torch.where(keep, nbr, torch.full_like(nbr, -1)), 1, order)
         cnt = keep.sum(1).to(torch.int32)
+    if not pad:   # the counted form leaves slots >= cnt unwritten: poison them so that a consumer reading them fails
+        slot = torch.arange(max_nbr, dtype=torch.int32).view(1, -1)
+        nbr = torch.where(slot < cnt.view(-1, 1), nbr, torch.full_like(nbr, 2 ** 30))
     return nbr, cnt
 
 
@@ -60,6 +63,9 @@ def gather_max(P, Q, nbr, ptr, want_arg, cnt=None, lds=False, nbr_local=None):
         assert torch.equal(torch.where(u == 0xFFFF, torch.full_like(u, -1), u + lo), nbr)
     N, H = P.shape
     k = nbr.shape[1]
+    if cnt is not None:   # counted tables: slots >= cnt[i] are undefined
+        slot = torch.arange(k, dtype=torch.int32).view(1, -1)
+        nbr = torch.where(slot < cnt.view(-1, 1), nbr, torch.full_like(nbr, -1))
     idx = nbr.long().clamp(min=0)
     vals = Q[idx]                                             # [N,k,H]
     vals = torch.where((nbr >= 0).unsqueeze(-1), vals, torch.full_like(vals, float("-inf")))

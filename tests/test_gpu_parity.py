@@ -381,6 +381,44 @@ def test_edgeconv_static_graph_from_radius(dev):
     _close(out.detach().cpu(), ref.detach())
 
 
+@pytest.mark.parametrize("reverse_route", [False, True])
+def test_counted_radius_table_consumers_go_by_cnt(dev, monkeypatch, reverse_route):
+    """N1: radius tables are built WITHOUT the -1 fill of their unused slots (dmet_radius_counted_f32).  Every consumer
+    must go by cnt: the same table with its undefined slots overwritten by a valid but wrong node id has to give the
+    same edge_index, the same EdgeConv output and the same gradients (both backward routes)."""
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import _native, conv as conv_mod
+    from deepmetv2_amd.graph import NeighborTable
+    if reverse_route:
+        monkeypatch.setattr(conv_mod, "GATHER_BWD_FORM", "reverse")
+    g = torch.Generator().manual_seed(8)
+    sizes = [200, 0, 300, 1]
+    N = sum(sizes)
+    etaphi = (torch.rand(N, 2, generator=g) * 3).to(dev)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.tensor(sizes).cumsum(0)]).to(dev)
+    nbr_p, cnt_p = _native.radius(etaphi, ptr, 0.4, 255, skip_self=False, pad=True)
+    nbr_u, cnt_u = _native.radius(etaphi, ptr, 0.4, 255, skip_self=False, pad=False)
+    assert torch.equal(cnt_p, cnt_u)
+    slot = torch.arange(255, device=dev, dtype=torch.int32).view(1, -1)
+    live = slot < cnt_p.view(-1, 1)
+    assert torch.equal(nbr_p[live], nbr_u[live]) and bool((nbr_p[~live] == -1).all())
+    nbr_u = torch.where(live, nbr_u, torch.zeros_like(nbr_u))           # poison: node 0 everywhere it is undefined
+    lin = torch.nn.Sequential(torch.nn.Linear(64, 32)).to(dev)
+    conv = dm.EdgeConv(nn=lin)
+    emb = torch.randn(N, 32, generator=g).to(dev)
+    gup = torch.randn(N, 32, generator=g).to(dev)
+    res = []
+    for nbr in (nbr_p, nbr_u):
+        table = NeighborTable(nbr, ptr, dense=False, max_nodes=max(sizes), cnt=cnt_p)
+        x = emb.clone().requires_grad_(True)
+        lin.zero_grad()
+        out = conv._forward_table(x, table)
+        out.backward(gup)
+        res.append((out.detach(), x.grad.clone(), lin[0].weight.grad.clone(), table.edge_index("source_to_target")))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("sizes", [[300, 1, 0, 77], [4700, 50], [9500], [19000, 3]])
 def test_gather_max_bwd_lds_matches_reverse_index_route(dev, sizes):
     """K5: the LDS fixed-point scatter (no reverse index) against the sorted reverse-index kernel (itself pinned to
