@@ -38,9 +38,11 @@ def parse_args():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 = BASELINE configs[2]: edge-MLP dense layer on the bf16 matrix cores, bf16 Q table "
                          "(kNN, max, MET and the backward stay fp32)")
-    ap.add_argument("--graph", choices=["dynamic", "static"], default="dynamic",
+    ap.add_argument("--graph", choices=["dynamic", "static", "static-table"], default="dynamic",
                     help="dynamic = kNN in the embedding before each EdgeConv (north star); static = the active reference "
-                         "flow (train.py:42-50): one radius graph dR<0.4 in (eta,phi) per batch, rebuilt every step")
+                         "flow (train.py:42-50): one radius graph dR<0.4 in (eta,phi) per batch, rebuilt every step; "
+                         "static-table = the same graph handed to the model as dm.radius_table(...) instead of "
+                         "radius_graph's [2,E] tensor (no host sync for the edge count)")
     ap.add_argument("--ragged", type=int, nargs=2, metavar=("LO", "HI"), default=None,
                     help="BASELINE configs[4]: event sizes drawn uniformly from [LO, HI] (seeded) instead of --nodes")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -176,7 +178,7 @@ def main():
     N = x.shape[0]
 
     torch.manual_seed(0)
-    model = Net(8, 3, graph=args.graph, k=k, edge_dtype=torch.bfloat16 if args.dtype == "bf16" else None).to(dev)
+    model = Net(8, 3, graph="dynamic" if args.graph == "dynamic" else "static", k=k, edge_dtype=torch.bfloat16 if args.dtype == "bf16" else None).to(dev)
     flat = FlatModule(model)
     sync = GradSync(flat)
     sync.broadcast_state(0)
@@ -187,10 +189,12 @@ def main():
         model.train()
 
         def static_graph():
-            if args.graph != "static":
+            if args.graph == "dynamic":
                 return None
             phi = torch.atan2(x[:, 1], x[:, 0])                                   # train.py:45-48
             etaphi = torch.cat([x[:, 3][:, None], phi[:, None]], dim=1)
+            if args.graph == "static-table":
+                return dm.radius_table(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255)
             return dm.radius_graph(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255)
 
         if args.hip_graph:

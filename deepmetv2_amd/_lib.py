@@ -28,6 +28,8 @@ SIGNATURES = {
     "dmet_knn_fallback_stats": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
     "dmet_radius_f32": (_i, [_vp, _vp, _i, _i64, _i, _f, _i, _i, _vp, _vp, _vp]),
     "dmet_radius_counted_f32": (_i, [_vp, _vp, _i, _i64, _i, _f, _i, _i, _vp, _vp, _vp]),
+    "dmet_radius_workspace_bytes": (_sz, [_i64]),
+    "dmet_radius_windowed_f32": (_i, [_vp, _vp, _i, _i64, _i, _f, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "dmet_edgeconv_linear_workspace_bytes": (_sz, [_i64, _i]),
     "dmet_edgeconv_linear_max_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_edgeconv_fused_lds_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -95,6 +95,7 @@ timer = KernelTimer()
 # gather+max kernel form: "auto" = LDS-resident when the caller says the events fit, else L2 gathers;
 # "lds" / "l2-only" force one form (experiments, tools/gather_micro.py)
 GATHER_MAX_FORM = os.environ.get("DMET_GATHER_MAX_FORM", "auto")
+RADIUS_FORM = os.environ.get("DMET_RADIUS", "windowed")   # "sweep": all pairs of an event (dmet_radius_f32)
 
 
 # ---- K1 ------------------------------------------------------------------------------------------------------
@@ -158,9 +159,16 @@ def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int, skip_self
     nbr = torch.empty((N, max_nbr), dtype=torch.int32, device=dev)
     cnt = torch.empty((N,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        fn = L.dmet_radius_f32 if pad else L.dmet_radius_counted_f32
-        _lib.check(fn(x.data_ptr(), ptr.data_ptr(), B, N, D, float(r), max_nbr, 1 if skip_self else 0,
-                      nbr.data_ptr(), cnt.data_ptr(), _stream(dev)), "dmet_radius_f32")
+        if RADIUS_FORM == "sweep":      # all pairs of an event (A/B and fallback)
+            fn = L.dmet_radius_f32 if pad else L.dmet_radius_counted_f32
+            _lib.check(fn(x.data_ptr(), ptr.data_ptr(), B, N, D, float(r), max_nbr, 1 if skip_self else 0,
+                          nbr.data_ptr(), cnt.data_ptr(), _stream(dev)), "dmet_radius_f32")
+        else:                            # same table, candidates windowed by the first coordinate
+            ws = _ws(L.dmet_radius_workspace_bytes(N), dev)
+            _lib.check(L.dmet_radius_windowed_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, float(r), max_nbr,
+                                                  1 if skip_self else 0, 1 if pad else 0, nbr.data_ptr(),
+                                                  cnt.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+                       "dmet_radius_windowed_f32")
     return nbr, cnt
 
 

@@ -228,6 +228,10 @@ class EdgeConv(torch.nn.Module):
             raise ValueError(f"x must be [N, F], got {tuple(x.shape)}")
         if x.dtype != torch.float32:
             raise TypeError(f"x must be float32, got {x.dtype}")
+        if isinstance(edge_index, NeighborTable):
+            # the table itself (dm.radius_table / dm.knn_table) instead of an edge_index tensor: same graph, but no
+            # [2,E] tensor is ever sized on the host (radius_graph's exact-size result costs one sync per call)
+            return self._forward_table(x, edge_index)
         hit = lookup_graph(edge_index)
         if hit is not None and hit[1] == self.flow and hit[0].num_nodes == x.shape[0]:
             return self._forward_table(x, hit[0])
@@ -238,6 +242,8 @@ class EdgeConv(torch.nn.Module):
         `x + f(conv(x))` (graph_met_network.py:66).  Using x' for the residual branch makes both gradients of x meet
         in this operator's backward kernel, which adds them while storing gx (no separate elementwise add)."""
         if torch.is_tensor(x) and x.dim() == 2 and x.dtype == torch.float32:
+            if isinstance(edge_index, NeighborTable):
+                return self._forward_table(x, edge_index, passthrough=True)
             hit = lookup_graph(edge_index)
             if hit is not None and hit[1] == self.flow and hit[0].num_nodes == x.shape[0]:
                 return self._forward_table(x, hit[0], passthrough=True)

@@ -80,6 +80,15 @@ int dmet_radius_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D,
  * dmet_gather_max_counted_f32, dmet_table_degree / dmet_table_edges, the arg-addressed backward. */
 int dmet_radius_counted_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr,
                             int skip_self, int32_t *nbr, int32_t *cnt, dmet_stream_t stream);
+/* The same table (bit-identical: same candidates in the same order, same distance arithmetic) without multiplying out
+ * all n^2 pairs of an event: queries are processed in the order of their FIRST coordinate, and a wavefront only keeps
+ * the candidates whose first coordinate lies within r of its 64 queries' range (stream compaction in index order).
+ * In (eta, phi) with r = 0.4 about 85 % of the pairs are never formed.  fill != 0: -1 fill as dmet_radius_f32,
+ * fill == 0: as dmet_radius_counted_f32.  ws: dmet_radius_workspace_bytes(N) bytes (the processing order). */
+size_t dmet_radius_workspace_bytes(int64_t N);
+int dmet_radius_windowed_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr,
+                             int skip_self, int fill, int32_t *nbr, int32_t *cnt, void *ws, size_t ws_bytes,
+                             dmet_stream_t stream);
 
 /* ---- K2+K3 fused: EdgeConv with nn = Linear(2*Hin -> Hout), aggr = 'max', fixed-width table ---------
  * replaces torch_geometric.nn.EdgeConv(nn=Sequential(Linear(2H,H)), aggr='max').forward

@@ -239,6 +239,44 @@ def test_radius_graph(dev):
         assert torch.equal(got.cpu(), ref)
 
 
+@pytest.mark.parametrize("case", ["etaphi", "dense_cluster", "one_d", "eight_d", "tiny_events", "nonfinite"])
+def test_radius_windowed_equals_sweep(dev, monkeypatch, case):
+    """N1: the radius table built with the first-coordinate window (dmet_radius_windowed_f32, the default) must be
+    identical -- ids, order, counts -- to the all-pairs sweep (dmet_radius_f32, pinned to the oracle by
+    test_radius_graph) on ragged batches, rows that overflow max_nbr, wavefronts that straddle events, 1-d / 8-d
+    coordinates and non-finite coordinates."""
+    from deepmetv2_amd import _native
+    g = torch.Generator().manual_seed(21)
+    r, mx = 0.4, 255
+    if case == "tiny_events":
+        sizes = [int(v) for v in torch.randint(0, 40, (300,), generator=g)]
+    else:
+        sizes = [700, 0, 3, 1500, 64, 65, 129]
+    N = sum(sizes)
+    x = torch.stack([(torch.rand(N, generator=g) - 0.5) * 6, (torch.rand(N, generator=g) - 0.5) * 6.28], 1)
+    if case == "dense_cluster":          # > 255 nodes within r of each other: "first max_nbr in index order" matters
+        x[100:600] = x[100] + 0.05 * torch.randn(500, 2, generator=g)
+        mx = 32
+    elif case == "one_d":
+        x = x[:, :1].contiguous()
+    elif case == "eight_d":
+        x = torch.cat([x, 0.1 * torch.randn(N, 6, generator=g)], 1).contiguous()
+        r = 0.6
+    elif case == "nonfinite":
+        x[5, 0] = float("nan"); x[17, 1] = float("nan"); x[40, 0] = float("inf"); x[41, 0] = float("-inf")
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.tensor(sizes).cumsum(0)]).to(dev)
+    xd = x.to(dev)
+    for skip_self in (False, True):
+        monkeypatch.setattr(_native, "RADIUS_FORM", "sweep")
+        n0, c0 = _native.radius(xd, ptr, r, mx, skip_self=skip_self, pad=True)
+        monkeypatch.setattr(_native, "RADIUS_FORM", "windowed")
+        n1, c1 = _native.radius(xd, ptr, r, mx, skip_self=skip_self, pad=True)
+        assert torch.equal(c0, c1), case
+        assert torch.equal(n0, n1), case
+    if case == "dense_cluster":
+        assert int(c0.max()) == mx - 1 or int(c0.max()) == mx
+
+
 def _close(a, b, rtol=FEAT_RTOL, atol=FEAT_ATOL):
     torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
 
@@ -379,6 +417,10 @@ def test_edgeconv_static_graph_from_radius(dev):
     ei = dm.radius_graph(etaphi.to(dev), 0.4, batch.to(dev), loop=True, max_num_neighbors=255)
     out = conv(emb.to(dev), ei)
     _close(out.detach().cpu(), ref.detach())
+    # the table itself instead of the [2,E] tensor (no host-side edge count): same graph, same bits
+    table = dm.radius_table(etaphi.to(dev), 0.4, batch.to(dev), loop=True, max_num_neighbors=255)
+    assert torch.equal(conv(emb.to(dev), table), out)
+    assert torch.equal(table.edge_index("source_to_target"), ei)
 
 
 @pytest.mark.parametrize("reverse_route", [False, True])
