@@ -206,9 +206,15 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
     if cnt is not None:
         _t = timer.record('gather_max', dev)
         with torch.cuda.device(dev):
-            _lib.check(L.dmet_gather_max_counted_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), cnt.data_ptr(), N, k, H,
-                                                     out.data_ptr(), arg.data_ptr() if want_arg else None,
-                                                     _stream(dev)), "dmet_gather_max_counted_f32")
+            if lds and ptr is not None and H % 8 == 0 and GATHER_MAX_FORM != "l2-only":
+                _lib.check(L.dmet_gather_max_counted_lds_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), cnt.data_ptr(),
+                                                             ptr.data_ptr(), ptr.numel() - 1, N, k, H, out.data_ptr(),
+                                                             arg.data_ptr() if want_arg else None, _stream(dev)),
+                           "dmet_gather_max_counted_lds_f32")
+            else:
+                _lib.check(L.dmet_gather_max_counted_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), cnt.data_ptr(), N, k,
+                                                         H, out.data_ptr(), arg.data_ptr() if want_arg else None,
+                                                         _stream(dev)), "dmet_gather_max_counted_f32")
         if _t is not None:
             _t.record(torch.cuda.current_stream(dev))
         return out, arg

@@ -623,6 +623,100 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     }
 }
 
+// LDS-resident form for COUNTED tables (radius graphs: kmax = 255 slots, cnt[i] ~ 36 of them used): the same
+// (event, 8-channel slice) workgroups and Q image as gather_max_lds_kernel; a lane pair walks the first cnt[i] slots
+// of its node's row eight at a time (ids -> 8 LDS rows -> compare chain, strict > keeps the lowest slot on ties).
+template <bool WITH_ARG>
+__global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_counted_kernel(
+    const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ nbr,
+    const int32_t *__restrict__ cnt, const int64_t *__restrict__ ptr, int B, int kmax, int H,
+    float *__restrict__ out, uint8_t *__restrict__ arg)
+{
+    __shared__ __attribute__((aligned(16))) float4 qs[kLdsGatherRows * 2];   // [n_b + 1][2] float4 = 8 channels/node
+    constexpr int RPI = kLdsGatherThreads / 2;
+    const int nsl = H / kSliceC;
+    const int grp = blockIdx.x / (kNumXcd * nsl), rem = blockIdx.x % (kNumXcd * nsl);
+    const int b = grp * kNumXcd + (rem % kNumXcd);
+    const int sl = rem / kNumXcd;
+    if (b >= B) return;
+    const int lo = (int)ptr[b], hi = (int)ptr[b + 1];
+    const int n = hi - lo;
+    if (n <= 0) return;
+    const int h4 = H / 4;
+    const float4 *Q4 = reinterpret_cast<const float4 *>(Q);
+    const float4 *P4 = reinterpret_cast<const float4 *>(P);
+    const int half = threadIdx.x & 1;
+    const int r0 = threadIdx.x >> 1;
+    const int col4 = sl * 2 + half;
+    const float ninf = -__builtin_inff();
+    const bool in_lds = n + 1 <= kLdsGatherRows;       // block-uniform; larger events gather from global memory (L2)
+    const int64_t table_len = ptr[B] * (int64_t)kmax;   // entries in the table
+    if (in_lds) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int nchunk = (n + 31) / 32;
+        for (int c = wave; c < nchunk; c += kLdsGatherThreads / 64) {
+            int row = 32 * c + (lane >> 1);
+            row = min(row, n - 1);
+            const float4 *src = Q4 + (int64_t)(lo + row) * h4 + sl * 2 + (lane & 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(qs + 64 * c), 16, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x < 2) qs[n * 2 + threadIdx.x] = make_float4(ninf, ninf, ninf, ninf);   // the -inf row
+        __syncthreads();
+    }
+    for (int r = r0; r < n; r += RPI) {
+        const int64_t node = lo + r;
+        const int32_t *row = nbr + node * kmax;
+        const int m = min(kmax, cnt[node]);
+        const float4 p = P4[node * h4 + col4];
+        float4 best = make_float4(ninf, ninf, ninf, ninf);
+        int a0 = 255, a1 = 255, a2 = 255, a3 = 255;
+        bool any = false;
+        for (int s0 = 0; s0 < m; s0 += 8) {
+            int32_t j[8];
+            float4 v[8];
+            // 16-byte loads (rows are only 4-byte aligned: 255-wide tables); reading up to 7 slots past m stays
+            // inside the table except for the very last rows, which take the scalar loads.  (Loading the next eight
+            // ids ahead of the compare chain was measured: no gain, the loop is bound by its VALU / LDS work and the
+            // spread of cnt inside a wavefront.)
+            if (node * kmax + s0 + 8 <= table_len) {
+                struct __attribute__((packed, aligned(4))) I4 { int32_t a, b, c, d; };
+                const I4 lo4 = *reinterpret_cast<const I4 *>(row + s0), hi4 = *reinterpret_cast<const I4 *>(row + s0 + 4);
+                j[0] = lo4.a; j[1] = lo4.b; j[2] = lo4.c; j[3] = lo4.d;
+                j[4] = hi4.a; j[5] = hi4.b; j[6] = hi4.c; j[7] = hi4.d;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) j[u] = (s0 + u < m) ? j[u] : -1;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) j[u] = (s0 + u < m) ? row[s0 + u] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (in_lds) v[u] = qs[min((unsigned)(j[u] - lo), (unsigned)n) * 2 + half];
+                else v[u] = (j[u] >= 0) ? Q4[(int64_t)j[u] * h4 + col4] : make_float4(ninf, ninf, ninf, ninf);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                any = any || (j[u] >= 0);
+                if (v[u].x > best.x) { best.x = v[u].x; a0 = s0 + u; }
+                if (v[u].y > best.y) { best.y = v[u].y; a1 = s0 + u; }
+                if (v[u].z > best.z) { best.z = v[u].z; a2 = s0 + u; }
+                if (v[u].w > best.w) { best.w = v[u].w; a3 = s0 + u; }
+            }
+        }
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (any) o = make_float4(p.x + best.x, p.y + best.y, p.z + best.z, p.w + best.w);
+        reinterpret_cast<float4 *>(out)[node * h4 + col4] = o;
+        if (WITH_ARG) {
+            uchar4 a = make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
+            if (!any) a = make_uchar4(255, 255, 255, 255);
+            reinterpret_cast<uchar4 *>(arg)[node * h4 + col4] = a;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Fully fused EdgeConv(Linear(64->32), max) over a fixed-width table: neighbour gather + edge MLP + max in ONE
 // launch, no P/Q round trip through memory.  One workgroup per (event, 8-channel slice):
@@ -1152,6 +1246,31 @@ extern "C" int dmet_gather_max_lds16_f32(const float *P, const float *Q, const i
                                          uint8_t *arg, dmet_stream_t stream)
 {
     return gather_max_lds_impl(P, Q, nbr, nbr_local, ptr, B, N, k, H, out, arg, stream);
+}
+
+extern "C" int dmet_gather_max_counted_lds_f32(const float *P, const float *Q, const int32_t *nbr, const int32_t *cnt,
+                                               const int64_t *ptr, int B, int64_t N, int k, int H, float *out,
+                                               uint8_t *arg, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_gather_max_counted_lds_f32: N out of range");
+    DMET_REQUIRE(k >= 1 && k <= 255, "dmet_gather_max_counted_lds_f32: k=%d not in [1,255]", k);
+    DMET_REQUIRE(H >= kSliceC && H % kSliceC == 0 && H <= DMET_MAX_H,
+                 "dmet_gather_max_counted_lds_f32: H=%d must be a multiple of %d", H, kSliceC);
+    if (N == 0 || B == 0) return 0;
+    DMET_REQUIRE(P && Q && nbr && cnt && ptr && out, "dmet_gather_max_counted_lds_f32: null pointer");
+    DMET_REQUIRE(aligned16(P) && aligned16(Q) && aligned16(out), "dmet_gather_max_counted_lds_f32: pointers must be 16-B aligned");
+    const int nsl = H / kSliceC;
+    const int64_t groups = (B + kNumXcd - 1) / kNumXcd;
+    const int64_t blocks = groups * kNumXcd * nsl;
+    hipStream_t st = as_stream(stream);
+    if (arg)
+        hipLaunchKernelGGL((gather_max_lds_counted_kernel<true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P,
+                           Q, nbr, cnt, ptr, B, k, H, out, arg);
+    else
+        hipLaunchKernelGGL((gather_max_lds_counted_kernel<false>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P,
+                           Q, nbr, cnt, ptr, B, k, H, out, arg);
+    DMET_LAUNCH_CHECK("gather_max_lds_counted_kernel");
+    return 0;
 }
 
 extern "C" int dmet_edgeconv_linear_max_fwd_f32(const float *x, const int32_t *nbr, const int64_t *ptr, int B,

@@ -459,6 +459,22 @@ def test_counted_radius_table_consumers_go_by_cnt(dev, monkeypatch, reverse_rout
         res.append((out.detach(), x.grad.clone(), lin[0].weight.grad.clone(), table.edge_index("source_to_target")))
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
+    if not reverse_route:   # LDS-resident and L2 forms of the counted gather give the same bits (+ an oversized event)
+        Pm = torch.randn(N, 32, generator=g).to(dev)
+        Qm = torch.randn(N, 32, generator=g).to(dev)
+        for want_arg in (True, False):
+            o0, a0 = _native.gather_max(Pm, Qm, nbr_u, ptr, want_arg, cnt=cnt_p, lds=False)
+            o1, a1 = _native.gather_max(Pm, Qm, nbr_u, ptr, want_arg, cnt=cnt_p, lds=True)
+            assert torch.equal(o0, o1) and (not want_arg or torch.equal(a0, a1))
+        big = [5300, 40]
+        xb = (torch.rand(sum(big), 2, generator=g) * torch.tensor([40.0, 6.0])).to(dev)
+        pb = torch.tensor([0, 5300, 5340], device=dev)
+        nb, cb = _native.radius(xb, pb, 0.4, 255, pad=False)
+        Pb = torch.randn(sum(big), 32, generator=g).to(dev)
+        Qb = torch.randn(sum(big), 32, generator=g).to(dev)
+        o0, a0 = _native.gather_max(Pb, Qb, nb, pb, True, cnt=cb, lds=False)
+        o1, a1 = _native.gather_max(Pb, Qb, nb, pb, True, cnt=cb, lds=True)
+        assert torch.equal(o0, o1) and torch.equal(a0, a1)
 
 
 @pytest.mark.parametrize("sizes", [[300, 1, 0, 77], [4700, 50], [9500], [19000, 3]])
