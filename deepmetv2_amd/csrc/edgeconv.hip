@@ -1225,6 +1225,18 @@ static int gather_max_lds_impl(const float *P, const float *Q, const int32_t *nb
         if (arg) { if (nbr16) DMET_GML_LAUNCH(true, K4_, true); else DMET_GML_LAUNCH(true, K4_, false); }      \
         else { if (nbr16) DMET_GML_LAUNCH(false, K4_, true); else DMET_GML_LAUNCH(false, K4_, false); }        \
     } while (0)
+#ifdef DMET_KNN_EXPERIMENT
+    // phase timing (tools/build_variant.sh exp -DDMET_KNN_EXPERIMENT): DMET_GML_MODE=1 skips the staging of the Q
+    // slice, =2 the LDS gather + compare chain (results are then meaningless)
+    if (const char *e = (arg && nbr16 && k == 16) ? getenv("DMET_GML_MODE") : nullptr) {
+        const int m = atoi(e);
+        if (m == 1) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 1, true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg);
+        else if (m == 2) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 2, true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg);
+        else DMET_GML(4);
+        DMET_LAUNCH_CHECK("gather_max_lds_kernel");
+        return 0;
+    }
+#endif
     if (k == 8) DMET_GML(2);
     else if (k == 16) DMET_GML(4);
     else if (k == 32) DMET_GML(8);
