@@ -1426,7 +1426,7 @@ int dispatch_k(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
 // One lane per query, four independent wavefronts per workgroup (no workgroup barrier).  Candidates are staged per
 // wavefront in LDS as [pair][feature][2] so that one broadcast read yields a feature of two candidates in adjacent
 // registers: the R1 chain then runs on v_pk_add_f32 / v_pk_fma_f32 (each half an exact IEEE op in feature order, same
-// bits as the scalar oracle).  The table is pre-filled with -1 by a memset; the kernel only writes the hits.
+// bits as the scalar oracle).  The kernel only writes the hits; unused slots are -1 from a memset (dmet_radius_f32) or left unwritten (counted forms).
 // `skip_self` reproduces upstream's loop=False: the search limit counts the node itself, the node is not stored.
 constexpr int kRadTile = 64;   // candidates per LDS tile and wavefront
 
