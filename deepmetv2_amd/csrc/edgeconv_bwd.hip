@@ -298,7 +298,11 @@ __global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const f
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         if (u >= cb && u < cb + CH && as[u] != 255) {
+#ifdef DMET_KNN_EXPERIMENT
+                            const int j = (k == 1 ? i : (loc16 ? (int)nbr16[gi * k + as[u]] : nbr[gi * k + as[u]] - (int)lo)) - j0;   // k == 1: upper bound of what skipping the id fetch would save
+#else
                             const int j = (loc16 ? (int)nbr16[gi * k + as[u]] : nbr[gi * k + as[u]] - (int)lo) - j0;
+#endif
                             if (j >= 0 && j < jn) {
                                 const long long q = __float2ll_rn(gs[u] * scale);
                                 atomicAdd(&cells[j * CH + (u - cb)], (unsigned long long)q);
