@@ -173,7 +173,10 @@ def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int, skip_self
 
 
 # ---- K2+K3 fused -----------------------------------------------------------------------------------------------
-def node_linear_split(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+def node_linear_split(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor],
+                      sliced: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(P, Q) = (x (W1-W2)^T + b, x W2^T) as [N, Hout] tensors; sliced=True: the same values stored slice-major,
+    [Hout/8][N][8], for gather_max(..., sliced=True) only (the returned tensors then have shape [Hout/8, N, 8])."""
     dev = _require_device(x, W, b)
     L = _lib.load()
     x = _f32c(x, "x"); W = _f32c(W, "W")
@@ -181,12 +184,15 @@ def node_linear_split(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor
     Hout = W.shape[0]
     if W.shape[1] != 2 * Hin:
         raise ValueError(f"W must be [Hout, 2*Hin] = [*, {2 * Hin}], got {tuple(W.shape)}")
-    PQ = torch.empty((2, N, Hout), dtype=torch.float32, device=dev)
+    if sliced and Hout % 8 != 0:
+        raise ValueError("node_linear_split: sliced tables need Hout % 8 == 0")
+    PQ = torch.empty((2, Hout // 8, N, 8) if sliced else (2, N, Hout), dtype=torch.float32, device=dev)
     bp = _f32c(b, "b").data_ptr() if b is not None else None
     _t = timer.record('node_linear_split', dev)
     with torch.cuda.device(dev):
-        _lib.check(L.dmet_node_linear_split_f32(x.data_ptr(), N, Hin, Hout, W.data_ptr(), bp, PQ[0].data_ptr(),
-                                                PQ[1].data_ptr(), _stream(dev)), "dmet_node_linear_split_f32")
+        fn = L.dmet_node_linear_split_sliced_f32 if sliced else L.dmet_node_linear_split_f32
+        _lib.check(fn(x.data_ptr(), N, Hin, Hout, W.data_ptr(), bp, PQ[0].data_ptr(), PQ[1].data_ptr(), _stream(dev)),
+                   "dmet_node_linear_split_f32")
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))
     return PQ[0], PQ[1]
@@ -194,15 +200,32 @@ def node_linear_split(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor
 
 def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optional[torch.Tensor],
                want_arg: bool, cnt: Optional[torch.Tensor] = None, lds: bool = False,
-               nbr_local: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+               nbr_local: Optional[torch.Tensor] = None, sliced: bool = False
+               ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """out = P + max over the rows of Q listed in nbr (+ uint8 arg).  lds=True: the caller knows every event fits
     the LDS image (<= 5119 nodes, k in {8,16,32}, H % 8 == 0) -> LDS-resident kernel; else gathers come from L2."""
     dev = _require_device(P, Q, nbr)
     L = _lib.load()
-    N, H = P.shape
+    if sliced:      # [H/8, N, 8] tables of node_linear_split(..., sliced=True)
+        N, H = P.shape[1], P.shape[0] * 8
+    else:
+        N, H = P.shape
     k = nbr.shape[1]
     out = torch.empty((N, H), dtype=torch.float32, device=dev)
     arg = torch.empty((N, H), dtype=torch.uint8, device=dev) if want_arg else None
+    if sliced:
+        if cnt is not None or ptr is None or k not in (8, 16, 32) or GATHER_MAX_FORM == "l2-only":
+            raise ValueError("gather_max: slice-major tables are only read by the LDS-resident kernel (k in {8,16,32})")
+        _t = timer.record('gather_max', dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.dmet_gather_max_lds_sliced_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(),
+                                                        nbr_local.data_ptr() if nbr_local is not None else None,
+                                                        ptr.data_ptr(), ptr.numel() - 1, N, k, H, out.data_ptr(),
+                                                        arg.data_ptr() if want_arg else None, _stream(dev)),
+                       "dmet_gather_max_lds_sliced_f32")
+        if _t is not None:
+            _t.record(torch.cuda.current_stream(dev))
+        return out, arg
     if cnt is not None:
         _t = timer.record('gather_max', dev)
         with torch.cuda.device(dev):

@@ -85,9 +85,12 @@ class _EdgeConvLinearMax(torch.autograd.Function):
             # gather + edge MLP + max in one launch, the event's Q slice resident in LDS
             out, arg = _native.edgeconv_fused_lds(x, weight, bias, table.nbr, table.ptr, want_arg=need_grad)
         else:
-            P, Q = _native.node_linear_split(x, weight, bias)
-            out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad,
-                                          lds=_lds_eligible(x, weight, table), nbr_local=table.nbr_local)
+            lds = _lds_eligible(x, weight, table)
+            # the LDS-resident gather reads P / Q slice by slice: have the dense layer write them slice-major
+            sliced = lds and _native.GATHER_MAX_FORM != "l2-only" and os.environ.get("DMET_PQ_SLICED", "1") != "0"
+            P, Q = _native.node_linear_split(x, weight, bias, sliced=sliced)
+            out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad, lds=lds,
+                                          nbr_local=table.nbr_local, sliced=sliced)
         if need_grad:
             ctx.save_for_backward(x, weight, arg)
             ctx.table = table

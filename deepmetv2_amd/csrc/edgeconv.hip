@@ -26,7 +26,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 // k-step s, half h  <->  input feature f = s + (HIN/2)*h, so a lane reads HIN/2 CONTIGUOUS floats of its node row.
 // ---------------------------------------------------------------------------------------------------------
-template <int HIN, int HOUT>
+// SLICED: P and Q are written slice-major, [HOUT/8][N][8] (the 8-channel slice of every node contiguous), which is how
+// gather_max_lds_kernel's (event, slice) workgroups read them: their LDS staging and P reads become contiguous
+// streams instead of 32-byte pieces of 128-byte rows.
+template <int HIN, int HOUT, bool SLICED = false>
 __global__ __launch_bounds__(256) void node_linear_split_kernel(const float *__restrict__ x, int64_t N,
                                                                  const float *__restrict__ W,
                                                                  const float *__restrict__ bias,
@@ -80,8 +83,10 @@ __global__ __launch_bounds__(256) void node_linear_split_kernel(const float *__r
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
                 const int64_t n = tile * 32 + row;
                 if (n < N) {
-                    P[n * HOUT + jt * 32 + r] = accP[e];
-                    Q[n * HOUT + jt * 32 + r] = accQ[e];
+                    const int c = jt * 32 + r;
+                    const int64_t at = SLICED ? ((int64_t)(c >> 3) * N + n) * 8 + (c & 7) : n * HOUT + c;
+                    P[at] = accP[e];
+                    Q[at] = accQ[e];
                 }
             }
         }
@@ -427,11 +432,13 @@ __device__ __forceinline__ void load_ids16_pair(unsigned (&w)[K4], const uint16_
 // K4 = number of int4 id loads per node (k == 4*K4).  LDS image: rows 0..n-1 = the event's Q slice, row n = -inf
 // (ids < 0 and anything outside the event map to it, so the gather needs no per-neighbour branch).  Per node all
 // 4*K4 LDS reads are issued before the compare chain; the next node's ids and P slice are prefetched meanwhile.
-template <bool WITH_ARG, int K4, int GML_MODE = 0, bool IDS16 = false>
+// SLICED: P and Q are the slice-major tables of dmet_node_linear_split_sliced_f32 ([H/8][N][8]); out / arg stay
+// row-major.
+template <bool WITH_ARG, int K4, int GML_MODE = 0, bool IDS16 = false, bool SLICED = false>
 __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ nbr,
     const uint16_t *__restrict__ nbr16, const int64_t *__restrict__ ptr, int B, int k, int H,
-    float *__restrict__ out, uint8_t *__restrict__ arg)
+    float *__restrict__ out, uint8_t *__restrict__ arg, int64_t N)
 {
     static_assert(!IDS16 || K4 % 2 == 0, "uint16 tables: k must be a multiple of 8");
     __shared__ __attribute__((aligned(16))) float4 qs[kLdsGatherRows * 2];   // [n_b + 1][2] float4 = 8 channels/node
@@ -452,6 +459,8 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     const int r0 = threadIdx.x >> 1;
     const int col4 = sl * 2 + half;             // float4 column of this lane inside a full row
     const float ninf = -__builtin_inff();
+    // float4 index of this lane's 4 channels of node `i` in P / Q (row-major, or slice-major [H/8][N][8])
+    auto pq_at = [&](const int64_t i) -> int64_t { return SLICED ? ((int64_t)sl * N + i) * 2 + half : i * h4 + col4; };
 
     if (n + 1 > kLdsGatherRows) {
         // event too large for the LDS image: same arithmetic, rows gathered from global memory (L2)
@@ -462,7 +471,7 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
             for (int s = 0; s < k; ++s) {
                 const int j = nbr[node * k + s];
                 if (j < 0) continue;
-                const float4 v = Q4[(int64_t)j * h4 + col4];
+                const float4 v = Q4[pq_at(j)];
                 if (v.x > best.x) { best.x = v.x; a0 = s; }
                 if (v.y > best.y) { best.y = v.y; a1 = s; }
                 if (v.z > best.z) { best.z = v.z; a2 = s; }
@@ -470,7 +479,7 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
             }
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a0 != 255) {
-                const float4 p = P4[node * h4 + col4];
+                const float4 p = P4[pq_at(node)];
                 o = make_float4(p.x + best.x, p.y + best.y, p.z + best.z, p.w + best.w);
             }
             reinterpret_cast<float4 *>(out)[node * h4 + col4] = o;
@@ -489,7 +498,8 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
         for (int c = wave; c < nchunk; c += kLdsGatherThreads / 64) {
             int row = 32 * c + (lane >> 1);
             row = min(row, n - 1);   // tail lanes re-read the last row into rows >= n (row n is rewritten below)
-            const float4 *src = Q4 + (int64_t)(lo + row) * h4 + sl * 2 + (lane & 1);
+            const float4 *src = SLICED ? Q4 + ((int64_t)sl * N + lo + row) * 2 + (lane & 1)
+                                       : Q4 + (int64_t)(lo + row) * h4 + sl * 2 + (lane & 1);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(qs + 64 * c), 16, 0, 0);
         }
@@ -505,7 +515,7 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
             const int4 *row4 = reinterpret_cast<const int4 *>(nbr + (int64_t)(lo + r0) * k);
             load_ids_pair<K4>(ids, row4, half);
         }
-        pv = P4[(int64_t)(lo + r0) * h4 + col4];
+        pv = P4[pq_at(lo + r0)];
     }
     __builtin_amdgcn_s_waitcnt(0);   // LDS-DMA is counted by vmcnt and is not covered by the barrier itself
     __syncthreads();
@@ -543,7 +553,7 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
                 const int4 *row4 = reinterpret_cast<const int4 *>(nbr + (node + RPI) * k);
                 load_ids_pair<K4>(ids, row4, half);
             }
-            pv = P4[(node + RPI) * h4 + col4];
+            pv = P4[pq_at(node + RPI)];
         }
         float bx = ninf, by = ninf, bz = ninf, bw = ninf;
         int a0 = 255, a1 = 255, a2 = 255, a3 = 255;
@@ -1014,7 +1024,7 @@ __global__ __launch_bounds__(256) void edge_features_bwd_kernel(const float *__r
     gx[gid] = s;
 }
 
-template <int HIN, int HOUT>
+template <int HIN, int HOUT, bool SLICED = false>
 int launch_node_linear(const float *x, int64_t N, const float *W, const float *b, float *P, float *Q,
                        hipStream_t st)
 {
@@ -1022,8 +1032,8 @@ int launch_node_linear(const float *x, int64_t N, const float *W, const float *b
     int64_t blocks = (ntiles + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((node_linear_split_kernel<HIN, HOUT>), dim3((unsigned)blocks), dim3(256), 0, st, x, N, W, b,
-                       P, Q);
+    hipLaunchKernelGGL((node_linear_split_kernel<HIN, HOUT, SLICED>), dim3((unsigned)blocks), dim3(256), 0, st, x, N, W,
+                       b, P, Q);
     DMET_LAUNCH_CHECK("node_linear_split_kernel");
     return 0;
 }
@@ -1052,6 +1062,22 @@ extern "C" int dmet_node_linear_split_f32(const float *x, int64_t N, int Hin, in
     if (Hin == 64 && Hout == 32) return launch_node_linear<64, 32>(x, N, W, b, P, Q, st);
     if (Hin == 32 && Hout == 64) return launch_node_linear<32, 64>(x, N, W, b, P, Q, st);
     set_error("dmet_node_linear_split_f32: unsupported (Hin,Hout)=(%d,%d); supported: 32/64", Hin, Hout);
+    return -22;
+}
+
+extern "C" int dmet_node_linear_split_sliced_f32(const float *x, int64_t N, int Hin, int Hout, const float *W,
+                                                 const float *b, float *P, float *Q, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0, "dmet_node_linear_split_sliced_f32: N<0");
+    if (N == 0) return 0;
+    DMET_REQUIRE(x && W && P && Q, "dmet_node_linear_split_sliced_f32: null pointer");
+    DMET_REQUIRE(aligned16(x) && aligned16(P) && aligned16(Q), "dmet_node_linear_split_sliced_f32: pointers must be 16-B aligned");
+    hipStream_t st = as_stream(stream);
+    if (Hin == 32 && Hout == 32) return launch_node_linear<32, 32, true>(x, N, W, b, P, Q, st);
+    if (Hin == 64 && Hout == 64) return launch_node_linear<64, 64, true>(x, N, W, b, P, Q, st);
+    if (Hin == 64 && Hout == 32) return launch_node_linear<64, 32, true>(x, N, W, b, P, Q, st);
+    if (Hin == 32 && Hout == 64) return launch_node_linear<32, 64, true>(x, N, W, b, P, Q, st);
+    set_error("dmet_node_linear_split_sliced_f32: unsupported (Hin,Hout)=(%d,%d); supported: 32/64", Hin, Hout);
     return -22;
 }
 
@@ -1203,7 +1229,7 @@ extern "C" int dmet_gather_max_bf16q(const float *P, const uint16_t *Qh, const i
 
 static int gather_max_lds_impl(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr16,
                                const int64_t *ptr, int B, int64_t N, int k, int H, float *out, uint8_t *arg,
-                               dmet_stream_t stream)
+                               bool sliced, dmet_stream_t stream)
 {
     DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_gather_max_lds_f32: N out of range");
     DMET_REQUIRE(k >= 1 && k <= 255, "dmet_gather_max_lds_f32: k=%d not in [1,255]", k);
@@ -1218,8 +1244,14 @@ static int gather_max_lds_impl(const float *P, const float *Q, const int32_t *nb
     const int64_t blocks = groups * kNumXcd * nsl;
     hipStream_t st = as_stream(stream);
 #define DMET_GML_LAUNCH(ARG_, K4_, I16_)                                                                          \
-    hipLaunchKernelGGL((gather_max_lds_kernel<ARG_, K4_, 0, I16_>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), \
-                       0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg)
+    do {                                                                                                          \
+        if (sliced)                                                                                               \
+            hipLaunchKernelGGL((gather_max_lds_kernel<ARG_, K4_, 0, I16_, true>), dim3((unsigned)blocks),         \
+                               dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N);      \
+        else                                                                                                      \
+            hipLaunchKernelGGL((gather_max_lds_kernel<ARG_, K4_, 0, I16_, false>), dim3((unsigned)blocks),        \
+                               dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N);      \
+    } while (0)
 #define DMET_GML(K4_)                                                                                          \
     do {                                                                                                       \
         if (arg) { if (nbr16) DMET_GML_LAUNCH(true, K4_, true); else DMET_GML_LAUNCH(true, K4_, false); }      \
@@ -1230,8 +1262,8 @@ static int gather_max_lds_impl(const float *P, const float *Q, const int32_t *nb
     // slice, =2 the LDS gather + compare chain (results are then meaningless)
     if (const char *e = (arg && nbr16 && k == 16) ? getenv("DMET_GML_MODE") : nullptr) {
         const int m = atoi(e);
-        if (m == 1) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 1, true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg);
-        else if (m == 2) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 2, true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg);
+        if (m == 1) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 1, true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N);
+        else if (m == 2) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 2, true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N);
         else DMET_GML(4);
         DMET_LAUNCH_CHECK("gather_max_lds_kernel");
         return 0;
@@ -1240,7 +1272,10 @@ static int gather_max_lds_impl(const float *P, const float *Q, const int32_t *nb
     if (k == 8) DMET_GML(2);
     else if (k == 16) DMET_GML(4);
     else if (k == 32) DMET_GML(8);
-    else return dmet_gather_max_f32(P, Q, nbr, ptr, B, N, k, H, out, arg, stream);  // other widths: L2 form
+    else {
+        DMET_REQUIRE(!sliced, "dmet_gather_max_lds_sliced_f32: k=%d (slice-major tables need k in {8,16,32})", k);
+        return dmet_gather_max_f32(P, Q, nbr, ptr, B, N, k, H, out, arg, stream);  // other widths: L2 form
+    }
 #undef DMET_GML
 #undef DMET_GML_LAUNCH
     DMET_LAUNCH_CHECK("gather_max_lds_kernel");
@@ -1250,14 +1285,21 @@ static int gather_max_lds_impl(const float *P, const float *Q, const int32_t *nb
 extern "C" int dmet_gather_max_lds_f32(const float *P, const float *Q, const int32_t *nbr, const int64_t *ptr, int B,
                                        int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream)
 {
-    return gather_max_lds_impl(P, Q, nbr, nullptr, ptr, B, N, k, H, out, arg, stream);
+    return gather_max_lds_impl(P, Q, nbr, nullptr, ptr, B, N, k, H, out, arg, false, stream);
 }
 
 extern "C" int dmet_gather_max_lds16_f32(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr_local,
                                          const int64_t *ptr, int B, int64_t N, int k, int H, float *out,
                                          uint8_t *arg, dmet_stream_t stream)
 {
-    return gather_max_lds_impl(P, Q, nbr, nbr_local, ptr, B, N, k, H, out, arg, stream);
+    return gather_max_lds_impl(P, Q, nbr, nbr_local, ptr, B, N, k, H, out, arg, false, stream);
+}
+
+extern "C" int dmet_gather_max_lds_sliced_f32(const float *P, const float *Q, const int32_t *nbr,
+                                              const uint16_t *nbr_local, const int64_t *ptr, int B, int64_t N, int k,
+                                              int H, float *out, uint8_t *arg, dmet_stream_t stream)
+{
+    return gather_max_lds_impl(P, Q, nbr, nbr_local, ptr, B, N, k, H, out, arg, true, stream);
 }
 
 extern "C" int dmet_gather_max_counted_lds_f32(const float *P, const float *Q, const int32_t *nbr, const int32_t *cnt,

@@ -116,6 +116,15 @@ int dmet_node_linear_split_f32(const float *x, int64_t N, int Hin, int Hout, con
                                const float *b, float *P, float *Q, dmet_stream_t stream);
 int dmet_gather_max_f32(const float *P, const float *Q, const int32_t *nbr, const int64_t *ptr, int B,
                         int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream);
+/* Slice-major pair: step 1 writes P and Q as [Hout/8][N][8] (the 8-channel slice of every node contiguous) and the
+ * LDS-resident gather reads them that way -- its (event, slice) workgroups then stage Q and stream P as contiguous
+ * bytes instead of 32-byte pieces of 128-byte rows.  out / arg stay row-major; nbr_local may be NULL; k in {8,16,32},
+ * H % 8 == 0.  Same results as dmet_node_linear_split_f32 + dmet_gather_max_lds_f32. */
+int dmet_node_linear_split_sliced_f32(const float *x, int64_t N, int Hin, int Hout, const float *W,
+                                      const float *b, float *P, float *Q, dmet_stream_t stream);
+int dmet_gather_max_lds_sliced_f32(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr_local,
+                                   const int64_t *ptr, int B, int64_t N, int k, int H, float *out, uint8_t *arg,
+                                   dmet_stream_t stream);
 /* Same contract with a per-node slot count: only the first cnt[i] slots of row i are examined (radius tables are
  * max_num_neighbors wide but a few dozen deep).  cnt may be NULL (= k for every node). */
 int dmet_gather_max_counted_f32(const float *P, const float *Q, const int32_t *nbr, const int32_t *cnt, int64_t N,

@@ -45,7 +45,7 @@ def radius(x, ptr, r, max_nbr, skip_self=False, pad=True):
     return nbr, cnt
 
 
-def node_linear_split(x, W, b):
+def node_linear_split(x, W, b, sliced=False):   # the stand-in keeps row-major tables either way
     H = x.shape[1]
     Wd = W[:, :H] - W[:, H:]
     P = x @ Wd.t()
@@ -54,7 +54,7 @@ def node_linear_split(x, W, b):
     return P.detach(), (x @ W[:, H:].t()).detach()
 
 
-def gather_max(P, Q, nbr, ptr, want_arg, cnt=None, lds=False, nbr_local=None):
+def gather_max(P, Q, nbr, ptr, want_arg, cnt=None, lds=False, nbr_local=None, sliced=False):
     if nbr_local is not None:
         # the local table must describe the same graph (this is what the uint16 kernel would gather)
         counts = (ptr[1:] - ptr[:-1]).long()

@@ -532,6 +532,19 @@ def test_gather_max_local_ids_kernel_matches(dev, k):
         assert torch.equal(o0, o1) and torch.equal(o1, o2)
         if want_arg:
             assert torch.equal(a0, a1) and torch.equal(a1, a2)
+    # slice-major P / Q ([H/8][N][8], dmet_node_linear_split_sliced_f32 -> dmet_gather_max_lds_sliced_f32): same bits as
+    # the row-major pair, with and without the uint16 table, oversized event included
+    W = (torch.randn(32, 64, generator=g) * 0.2).to(dev)
+    b = torch.randn(32, generator=g).to(dev)
+    Pr, Qr = _native.node_linear_split(xd, W, b)
+    Ps, Qs = _native.node_linear_split(xd, W, b, sliced=True)
+    assert Ps.shape == (4, x.shape[0], 8)
+    assert torch.equal(Ps.permute(1, 0, 2).reshape(-1, 32), Pr) and torch.equal(Qs.permute(1, 0, 2).reshape(-1, 32), Qr)
+    for want_arg in (True, False):
+        o0, a0 = _native.gather_max(Pr, Qr, nbr, ptrd, want_arg, lds=True, nbr_local=loc)
+        for nl in (loc, None):
+            o1, a1 = _native.gather_max(Ps, Qs, nbr, ptrd, want_arg, lds=True, nbr_local=nl, sliced=True)
+            assert torch.equal(o0, o1) and (not want_arg or torch.equal(a0, a1))
 
 
 def test_max_ties_and_empty_rows(dev):
