@@ -37,6 +37,8 @@ __global__ __launch_bounds__(256) void node_linear_split_kernel(const float *__r
 {
     constexpr int KS = HIN / 2;     // k-steps
     constexpr int JT = HOUT / 32;   // output column tiles
+    constexpr int TP = 36;          // LDS row stride of the transposition tiles (SLICED only)
+    __shared__ __attribute__((aligned(16))) float tpose[SLICED ? 4 : 1][SLICED ? 2 : 1][SLICED ? 32 * TP : 1];
     const int lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -78,15 +80,41 @@ __global__ __launch_bounds__(256) void node_linear_split_kernel(const float *__r
                 accP = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wd[jt][s], accP, 0, 0, 0);
                 accQ = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w2[jt][s], accQ, 0, 0, 0);
             }
+            if constexpr (SLICED) {
+                // slice-major rows are 32 bytes: go through LDS so that a lane stores 16 bytes and the 16 lanes of a
+                // slice cover 8 consecutive nodes (256 contiguous bytes) instead of 32-byte pieces per store
+                float *tP = tpose[threadIdx.x >> 6][0], *tQ = tpose[threadIdx.x >> 6][1];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int64_t n = tile * 32 + row;
-                if (n < N) {
-                    const int c = jt * 32 + r;
-                    const int64_t at = SLICED ? ((int64_t)(c >> 3) * N + n) * 8 + (c & 7) : n * HOUT + c;
-                    P[at] = accP[e];
-                    Q[at] = accQ[e];
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    tP[row * TP + r] = accP[e];
+                    tQ[row * TP + r] = accQ[e];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int sl = lane >> 4, idx = lane & 15;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int row = p * 8 + (idx >> 1);
+                    const int64_t n = tile * 32 + row;
+                    if (n < N) {
+                        const int64_t at = ((int64_t)(jt * 4 + sl) * N + n) * 8 + (idx & 1) * 4;
+                        *reinterpret_cast<float4 *>(P + at) = *reinterpret_cast<const float4 *>(&tP[row * TP + sl * 8 + (idx & 1) * 4]);
+                        *reinterpret_cast<float4 *>(Q + at) = *reinterpret_cast<const float4 *>(&tQ[row * TP + sl * 8 + (idx & 1) * 4]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const int64_t n = tile * 32 + row;
+                    if (n < N) {
+                        P[n * HOUT + jt * 32 + r] = accP[e];
+                        Q[n * HOUT + jt * 32 + r] = accQ[e];
+                    }
                 }
             }
         }
