@@ -262,10 +262,25 @@ __global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const f
     const bool loc16 = nbr16 != nullptr && n <= 65535;   // event-local uint16 table (half the row bytes) when given
 
     // scale: 2^(30 - e) with 2^e > max |g| over the slice (exactly representable, so the final rescale is exact)
+    // the slice of g_out is needed twice (its maximum, then the terms): events of up to kBwdKeep * 1024 nodes keep it
+    // in registers in between instead of reading the 16-byte pieces of the rows a second time
+    constexpr int kBwdKeep = 5;
+    const bool keep = n <= kBwdKeep * kBwdThreads;    // block-uniform
+    float4 gk[kBwdKeep];
     float m = 0.0f;
-    for (int i = tid; i < n; i += kBwdThreads) {
-        const float4 g = reinterpret_cast<const float4 *>(g_out + (lo + i) * kH + c0)[0];
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
+    if (keep) {
+#pragma unroll
+        for (int u = 0; u < kBwdKeep; ++u) {
+            const int i = tid + u * kBwdThreads;
+            gk[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n) gk[u] = reinterpret_cast<const float4 *>(g_out + (lo + i) * kH + c0)[0];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(gk[u].x), fabsf(gk[u].y)), fmaxf(fabsf(gk[u].z), fabsf(gk[u].w))));
+        }
+    } else {
+        for (int i = tid; i < n; i += kBwdThreads) {
+            const float4 g = reinterpret_cast<const float4 *>(g_out + (lo + i) * kH + c0)[0];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w))));
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
@@ -289,10 +304,18 @@ __global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const f
             for (int t = tid; t < jn * CH; t += kBwdThreads) cells[t] = 0ull;
             __syncthreads();
             if (m > 0.0f) {
-                for (int i = tid; i < n; i += kBwdThreads) {
+                int u_keep = 0;
+                for (int i = tid; i < n; i += kBwdThreads, ++u_keep) {
                     const int64_t gi = lo + i;
                     const uchar4 a4 = reinterpret_cast<const uchar4 *>(arg + gi * kH + c0)[0];
-                    const float4 g4 = reinterpret_cast<const float4 *>(g_out + gi * kH + c0)[0];
+                    float4 g4;
+                    if (keep) {   // static register indices: select, do not index
+                        g4 = gk[0];
+#pragma unroll
+                        for (int u = 1; u < kBwdKeep; ++u) if (u_keep == u) g4 = gk[u];
+                    } else {
+                        g4 = reinterpret_cast<const float4 *>(g_out + gi * kH + c0)[0];
+                    }
                     const uint8_t as[4] = {a4.x, a4.y, a4.z, a4.w};
                     const float gs[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
@@ -312,9 +335,18 @@ __global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const f
                 }
             }
             __syncthreads();
-            for (int t = tid; t < jn * CH; t += kBwdThreads) {
-                const int j = t / CH, u = t - j * CH;
-                gQ[(lo + j0 + j) * kH + c0 + cb + u] = (float)(long long)cells[t] * inv_scale;
+            if (CH == 4) {   // one node per thread: 16-byte stores
+                for (int j = tid; j < jn; j += kBwdThreads) {
+                    const unsigned long long *cj = cells + 4 * j;
+                    const float4 o = make_float4((float)(long long)cj[0] * inv_scale, (float)(long long)cj[1] * inv_scale,
+                                                 (float)(long long)cj[2] * inv_scale, (float)(long long)cj[3] * inv_scale);
+                    *reinterpret_cast<float4 *>(gQ + (lo + j0 + j) * kH + c0) = o;
+                }
+            } else {
+                for (int t = tid; t < jn * CH; t += kBwdThreads) {
+                    const int j = t / CH, u = t - j * CH;
+                    gQ[(lo + j0 + j) * kH + c0 + cb + u] = (float)(long long)cells[t] * inv_scale;
+                }
             }
         }
     }
