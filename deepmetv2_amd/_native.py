@@ -213,9 +213,9 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
     k = nbr.shape[1]
     out = torch.empty((N, H), dtype=torch.float32, device=dev)
     arg = torch.empty((N, H), dtype=torch.uint8, device=dev) if want_arg else None
-    if sliced:
-        if cnt is not None or ptr is None or k not in (8, 16, 32) or GATHER_MAX_FORM == "l2-only":
-            raise ValueError("gather_max: slice-major tables are only read by the LDS-resident kernel (k in {8,16,32})")
+    if sliced and cnt is None:
+        if ptr is None or k not in (8, 16, 32) or GATHER_MAX_FORM == "l2-only":
+            raise ValueError("gather_max: slice-major tables are only read by the LDS-resident kernels")
         _t = timer.record('gather_max', dev)
         with torch.cuda.device(dev):
             _lib.check(L.dmet_gather_max_lds_sliced_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(),
@@ -231,9 +231,12 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
         with torch.cuda.device(dev):
             if lds and ptr is not None and H % 8 == 0 and GATHER_MAX_FORM != "l2-only":
                 _lib.check(L.dmet_gather_max_counted_lds_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), cnt.data_ptr(),
-                                                             ptr.data_ptr(), ptr.numel() - 1, N, k, H, out.data_ptr(),
+                                                             ptr.data_ptr(), ptr.numel() - 1, N, k, H,
+                                                             1 if sliced else 0, out.data_ptr(),
                                                              arg.data_ptr() if want_arg else None, _stream(dev)),
                            "dmet_gather_max_counted_lds_f32")
+            elif sliced:
+                raise ValueError("gather_max: slice-major tables are only read by the LDS-resident kernels")
             else:
                 _lib.check(L.dmet_gather_max_counted_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), cnt.data_ptr(), N, k,
                                                          H, out.data_ptr(), arg.data_ptr() if want_arg else None,

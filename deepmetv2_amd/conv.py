@@ -77,10 +77,12 @@ class _EdgeConvLinearMax(torch.autograd.Function):
             P, Qh = _native.node_linear_split_bf16(x, weight, bias)
             out, arg = _native.gather_max_bf16q(P, Qh, table.nbr, want_arg=need_grad)
         elif table.cnt is not None:
-            P, Q = _native.node_linear_split(x, weight, bias)
             lds = (x.shape[1] == 32 and weight.shape[0] == 32 and table.ptr is not None
                    and table.max_nodes is not None and table.max_nodes <= _LDS_MAX_EVENT_NODES)
-            out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad, cnt=table.cnt, lds=lds)
+            sliced = lds and _native.GATHER_MAX_FORM != "l2-only" and os.environ.get("DMET_PQ_SLICED", "1") != "0"
+            P, Q = _native.node_linear_split(x, weight, bias, sliced=sliced)
+            out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad, cnt=table.cnt, lds=lds,
+                                          sliced=sliced)
         elif EDGECONV_FORM == "fused" and _lds_eligible(x, weight, table):
             # gather + edge MLP + max in one launch, the event's Q slice resident in LDS
             out, arg = _native.edgeconv_fused_lds(x, weight, bias, table.nbr, table.ptr, want_arg=need_grad)

@@ -664,11 +664,11 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
 // LDS-resident form for COUNTED tables (radius graphs: kmax = 255 slots, cnt[i] ~ 36 of them used): the same
 // (event, 8-channel slice) workgroups and Q image as gather_max_lds_kernel; a lane pair walks the first cnt[i] slots
 // of its node's row eight at a time (ids -> 8 LDS rows -> compare chain, strict > keeps the lowest slot on ties).
-template <bool WITH_ARG>
+template <bool WITH_ARG, bool SLICED>
 __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_counted_kernel(
     const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ nbr,
     const int32_t *__restrict__ cnt, const int64_t *__restrict__ ptr, int B, int kmax, int H,
-    float *__restrict__ out, uint8_t *__restrict__ arg)
+    float *__restrict__ out, uint8_t *__restrict__ arg, int64_t N)
 {
     __shared__ __attribute__((aligned(16))) float4 qs[kLdsGatherRows * 2];   // [n_b + 1][2] float4 = 8 channels/node
     constexpr int RPI = kLdsGatherThreads / 2;
@@ -688,14 +688,17 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_counted_kern
     const int col4 = sl * 2 + half;
     const float ninf = -__builtin_inff();
     const bool in_lds = n + 1 <= kLdsGatherRows;       // block-uniform; larger events gather from global memory (L2)
-    const int64_t table_len = ptr[B] * (int64_t)kmax;   // entries in the table
+    const int64_t table_len = N * (int64_t)kmax;        // entries in the table
+    // float4 index of this lane's 4 channels of node `i` in P / Q (row-major, or slice-major [H/8][N][8])
+    auto pq_at = [&](const int64_t i) -> int64_t { return SLICED ? ((int64_t)sl * N + i) * 2 + half : i * h4 + col4; };
     if (in_lds) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int nchunk = (n + 31) / 32;
         for (int c = wave; c < nchunk; c += kLdsGatherThreads / 64) {
             int row = 32 * c + (lane >> 1);
             row = min(row, n - 1);
-            const float4 *src = Q4 + (int64_t)(lo + row) * h4 + sl * 2 + (lane & 1);
+            const float4 *src = SLICED ? Q4 + ((int64_t)sl * N + lo + row) * 2 + (lane & 1)
+                                       : Q4 + (int64_t)(lo + row) * h4 + sl * 2 + (lane & 1);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(qs + 64 * c), 16, 0, 0);
         }
@@ -708,7 +711,7 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_counted_kern
         const int64_t node = lo + r;
         const int32_t *row = nbr + node * kmax;
         const int m = min(kmax, cnt[node]);
-        const float4 p = P4[node * h4 + col4];
+        const float4 p = P4[pq_at(node)];
         float4 best = make_float4(ninf, ninf, ninf, ninf);
         int a0 = 255, a1 = 255, a2 = 255, a3 = 255;
         bool any = false;
@@ -733,7 +736,7 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_counted_kern
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 if (in_lds) v[u] = qs[min((unsigned)(j[u] - lo), (unsigned)n) * 2 + half];
-                else v[u] = (j[u] >= 0) ? Q4[(int64_t)j[u] * h4 + col4] : make_float4(ninf, ninf, ninf, ninf);
+                else v[u] = (j[u] >= 0) ? Q4[pq_at(j[u])] : make_float4(ninf, ninf, ninf, ninf);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -1331,8 +1334,8 @@ extern "C" int dmet_gather_max_lds_sliced_f32(const float *P, const float *Q, co
 }
 
 extern "C" int dmet_gather_max_counted_lds_f32(const float *P, const float *Q, const int32_t *nbr, const int32_t *cnt,
-                                               const int64_t *ptr, int B, int64_t N, int k, int H, float *out,
-                                               uint8_t *arg, dmet_stream_t stream)
+                                               const int64_t *ptr, int B, int64_t N, int k, int H, int pq_sliced,
+                                               float *out, uint8_t *arg, dmet_stream_t stream)
 {
     DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_gather_max_counted_lds_f32: N out of range");
     DMET_REQUIRE(k >= 1 && k <= 255, "dmet_gather_max_counted_lds_f32: k=%d not in [1,255]", k);
@@ -1345,12 +1348,12 @@ extern "C" int dmet_gather_max_counted_lds_f32(const float *P, const float *Q, c
     const int64_t groups = (B + kNumXcd - 1) / kNumXcd;
     const int64_t blocks = groups * kNumXcd * nsl;
     hipStream_t st = as_stream(stream);
-    if (arg)
-        hipLaunchKernelGGL((gather_max_lds_counted_kernel<true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P,
-                           Q, nbr, cnt, ptr, B, k, H, out, arg);
-    else
-        hipLaunchKernelGGL((gather_max_lds_counted_kernel<false>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P,
-                           Q, nbr, cnt, ptr, B, k, H, out, arg);
+#define DMET_GCL(ARG_, SL_)                                                                                     \
+    hipLaunchKernelGGL((gather_max_lds_counted_kernel<ARG_, SL_>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, \
+                       st, P, Q, nbr, cnt, ptr, B, k, H, out, arg, N)
+    if (arg) { if (pq_sliced) DMET_GCL(true, true); else DMET_GCL(true, false); }
+    else { if (pq_sliced) DMET_GCL(false, true); else DMET_GCL(false, false); }
+#undef DMET_GCL
     DMET_LAUNCH_CHECK("gather_max_lds_counted_kernel");
     return 0;
 }

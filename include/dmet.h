@@ -138,8 +138,9 @@ int dmet_gather_max_lds_f32(const float *P, const float *Q, const int32_t *nbr, 
  * (event, 8-channel slice) workgroups and LDS image of dmet_gather_max_lds_f32; events that do not fit gather from
  * global memory inside the same kernel.  Identical results. */
 int dmet_gather_max_counted_lds_f32(const float *P, const float *Q, const int32_t *nbr, const int32_t *cnt,
-                                    const int64_t *ptr, int B, int64_t N, int k, int H, float *out, uint8_t *arg,
-                                    dmet_stream_t stream);
+                                    const int64_t *ptr, int B, int64_t N, int k, int H, int pq_sliced, float *out,
+                                    uint8_t *arg, dmet_stream_t stream);   /* pq_sliced != 0: P / Q are the slice-major
+                                    tables of dmet_node_linear_split_sliced_f32 */
 /* Same again with the table ALSO given as event-local uint16 ids (nbr_local from dmet_knn_local_f32; k in {8,16,32},
  * 16-byte aligned): events that fit the LDS image read their ids from it -- half the id bytes, and every one of the
  * H/8 slice workgroups of an event re-reads the ids, so this is a third of the kernel's L2 requests.  Larger events

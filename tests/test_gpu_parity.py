@@ -475,6 +475,13 @@ def test_counted_radius_table_consumers_go_by_cnt(dev, monkeypatch, reverse_rout
         o0, a0 = _native.gather_max(Pb, Qb, nb, pb, True, cnt=cb, lds=False)
         o1, a1 = _native.gather_max(Pb, Qb, nb, pb, True, cnt=cb, lds=True)
         assert torch.equal(o0, o1) and torch.equal(a0, a1)
+        # slice-major P / Q through the counted LDS kernel (small events, then the oversized one)
+        for Pr, Qr, tb, pp, cc in ((Pm, Qm, nbr_u, ptr, cnt_p), (Pb, Qb, nb, pb, cb)):
+            Ps = Pr.view(-1, 4, 8).permute(1, 0, 2).contiguous()
+            Qs = Qr.view(-1, 4, 8).permute(1, 0, 2).contiguous()
+            o0, a0 = _native.gather_max(Pr, Qr, tb, pp, True, cnt=cc, lds=True)
+            o1, a1 = _native.gather_max(Ps, Qs, tb, pp, True, cnt=cc, lds=True, sliced=True)
+            assert torch.equal(o0, o1) and torch.equal(a0, a1)
 
 
 @pytest.mark.parametrize("sizes", [[300, 1, 0, 77], [4700, 50], [9500], [19000, 3]])
