@@ -55,7 +55,10 @@ def _as_fusable_linear(nn_module) -> Optional[torch.nn.Linear]:
 # the one BASELINE.md's roofline definition describes.
 GATHER_BWD_FORM = os.environ.get("DMET_GATHER_BWD", "lds")   # "reverse": radix-sorted reverse index route
 EDGECONV_FORM = os.environ.get("DMET_EDGECONV_FORM", "split")
-_LDS_MAX_EVENT_NODES = 5119                                      # 160 KB LDS / 32 B per node, minus the -inf row
+# 160 KB LDS / 32 B per node, minus the -inf row.  Batch-level decision: the LDS kernels do handle larger events (from
+# global memory), but a batch that has them is faster through the L2-form kernel as a whole (measured on the ragged
+# 500-8000 configuration: 35 us against 213 us), so the override is for experiments only.
+_LDS_MAX_EVENT_NODES = int(os.environ.get("DMET_LDS_MAX_NODES", "5119"))
 
 
 def _lds_eligible(x, weight, table: NeighborTable) -> bool:
