@@ -740,6 +740,12 @@ __device__ __forceinline__ void filter_select(FilterLane<M> &L, const f32x16 &ac
                                               FilterQueue<filter_queue_len(M)> &Q, int lane)
 {
     constexpr int QF = filter_queue_len(M);
+#if defined(DMET_FILTER_ABL) && (DMET_FILTER_ABL == 1 || DMET_FILTER_ABL == 2)
+    // cycle-budget experiment (tools/knn_budget.sh): keys computed (and swapped), never looked at
+#pragma unroll
+    for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[e]));
+    return;
+#endif
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         if (__any(L.cnt > QF - 8)) filter_drain<M>(L, Q, lane);
@@ -747,10 +753,21 @@ __device__ __forceinline__ void filter_select(FilterLane<M> &L, const f32x16 &ac
         for (int u = 0; u < 8; ++u) {
             const int e = half * 8 + u;
             const float key = acc[e];
+#if defined(DMET_FILTER_ABL) && DMET_FILTER_ABL == 3
+            // experiment: the push's VALU work (compare, count, two slot addresses, id) without the LDS stores
+            const unsigned ak = (unsigned)L.cnt * (kWave * 4u) + (unsigned)lane * 4u;
+            const unsigned ai = (unsigned)L.cnt * (kWave * 2u) + (unsigned)lane * 2u;
+            const unsigned idv = (unsigned)(jrel + (e & 3) + 8 * (e >> 2));
+            asm volatile("" ::"v"(ak), "v"(ai), "v"(idv), "v"(key));
+#else
             Q.key[L.cnt][lane] = __float_as_uint(key);
             Q.id[L.cnt][lane] = (unsigned short)(jrel + (e & 3) + 8 * (e >> 2));
+#endif
             L.cnt += (key < L.tau) ? 1 : 0;
         }
+#if defined(DMET_FILTER_ABL) && (DMET_FILTER_ABL == 3 || DMET_FILTER_ABL == 4)
+        asm volatile("v_mov_b32 %0, 0" : "=v"(L.cnt) : "v"(L.cnt));   // experiment: queue never fills, no drains
+#endif
     }
 }
 
@@ -843,6 +860,7 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
             f32x16 acc1 = filter_block(av, bq[1], ci);
             // lanes 32..63 of block 0 <-> lanes 0..31 of block 1: afterwards acc0 = rows {0-3, 8-11, ..} and
             // acc1 = rows {4-7, 12-15, ..} of THIS lane's query
+#if !(defined(DMET_FILTER_ABL) && DMET_FILTER_ABL == 2)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[e]), __float_as_uint(acc1[e]),
@@ -850,6 +868,7 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
                 acc0[e] = __uint_as_float(r[0]);
                 acc1[e] = __uint_as_float(r[1]);
             }
+#endif
             filter_select<M>(L, acc0, c0 - ev_lo, Q, lane);
             filter_select<M>(L, acc1, c0 - ev_lo + 4, Q, lane);
             if (more) {
@@ -860,6 +879,9 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
         }
     }
     filter_drain<M>(L, Q, lane);
+#if defined(DMET_FILTER_ABL) && DMET_FILTER_ABL == 5
+    return;   // experiment: selection only, no exact re-rank / certificate
+#endif
     if (nsub == 1) {
         // ---- whole-sweep items: exact re-rank right here, while the kept candidates still sit in LDS ----------------
         // Every lane owns one query and <= QF-8 kept candidates (all keys <= tau, ties included, so every dropped
