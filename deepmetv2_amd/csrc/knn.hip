@@ -564,7 +564,8 @@ struct KnnFilterArgs {
     int64_t N;
     int k;
     float *nrm;                 // [N] squared norms
-    unsigned short *xs;         // [N][64] bf16 split of x: 32 high terms, then 32 middle terms
+    uint8_t *rec;               // candidate tile records (kRecBytes each): the bf16 split of 32 rows in MFMA operand
+                                // order + their squared norms; event b starts at record (ptr[b] >> 5) + b
     const KnnPlan *plan;        // filter plan (kFQ-query tiles)
     const int32_t *order;
     const int32_t *pos_of;
@@ -578,6 +579,7 @@ struct KnnFilterArgs {
     uint8_t *qflag;             // [N] 1 = uncertified query
     const int32_t *xtile_ptr;   // tile prefix of the exact kernel's plan (same event order)
     int xtile_queries;
+    int form2;                  // 1: events of kF2MinNodes..kF2MaxNodes nodes are swept by knn_filter2_kernel
 };
 
 __device__ __forceinline__ unsigned bf16_rne_bits(float f)   // finite inputs
@@ -586,12 +588,26 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float f)   // finite inputs
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
 
-// Squared norms and the bf16 split of x: 8 lanes per row (one float4 each), so loads and stores are contiguous.
-// Also clears the uncertified-query counters / flags (zero_bytes bytes at `zero`, 4-byte aligned) for the launches
-// that follow, which saves a memset launch per call.
-__global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__ x, int64_t N, float *__restrict__ nrm,
-                                                        unsigned short *__restrict__ xs, uint32_t *__restrict__ zero,
-                                                        size_t zero_bytes)
+// ---- candidate tile records ---------------------------------------------------------------------------------------
+// The filter sweeps an event's candidates in tiles of 32 rows.  A tile's A operands are stored the way a wavefront
+// consumes them: frag[m][lane] = the 8 bf16 values lane (col = lane & 31, hh = lane >> 5) feeds to MFMA operand m
+// (m = 0,1: high terms of features 0-15 / 16-31; m = 2,3: middle terms), i.e. features 16 (m & 1) + 8 hh + 0..7 of row
+// col -- so one load instruction of a wavefront is 1 KB of contiguous memory (8 full cache lines) instead of 32-byte
+// pieces of 32 different rows -- followed by the 32 squared norms.  Rows past the end of an event are zero with
+// norm = +inf (key = +inf: never admitted), so the sweep needs no range checks.  Event b owns the records
+// [(ptr[b] >> 5) + b, ... + ceil(n_b / 32)): monotone and disjoint without a prefix sum over the events.
+constexpr int kRecFragBytes = 4 * kWave * 16;           // 4096
+constexpr int kRecBytes = kRecFragBytes + 32 * 4;       // + norms = 4224 (33 cache lines)
+
+__device__ __forceinline__ int64_t rec_base_tile(const int64_t *__restrict__ ptr, int b) { return (ptr[b] >> 5) + b; }
+
+// One wavefront per record: lane (col, hh) converts the 16 features of row col it will later feed to the MFMAs.
+// Also writes the flat norm array (certificates) and clears the uncertified-query counters / flags (zero_bytes bytes
+// at `zero`, 4-byte aligned) for the launches that follow, which saves a memset launch per call.
+__global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__ x, const int64_t *__restrict__ ptr,
+                                                        int B, int64_t N, float *__restrict__ nrm,
+                                                        uint8_t *__restrict__ rec, int64_t nrec,
+                                                        uint32_t *__restrict__ zero, size_t zero_bytes)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     {
@@ -600,26 +616,50 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__
         if (t == 0)
             for (size_t bt = words << 2; bt < zero_bytes; ++bt) reinterpret_cast<uint8_t *>(zero)[bt] = 0;
     }
-    const int64_t row = t >> 3;
-    const int part = (int)(t & 7);
-    const bool live = row < N;
-    const int64_t r = live ? row : N - 1;
-    const float4 v = reinterpret_cast<const float4 *>(x + r * 32)[part];
-    float s = v.x * v.x;
-    s = __builtin_fmaf(v.y, v.y, s); s = __builtin_fmaf(v.z, v.z, s); s = __builtin_fmaf(v.w, v.w, s);
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);   // fixed order: deterministic
-    const float f[4] = {v.x, v.y, v.z, v.w};
-    unsigned h[4], m[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        h[u] = bf16_rne_bits(f[u]);
-        m[u] = bf16_rne_bits(f[u] - __uint_as_float(h[u] << 16));   // the subtraction is exact
+    const int64_t tile = t >> 6;            // wave-uniform
+    if (tile >= nrec) return;
+    const int lane = (int)(t & 63), col = lane & 31, hh = lane >> 5;
+    // event that owns the record: the last b with (ptr[b] >> 5) + b <= tile
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rec_base_tile(ptr, mid) <= tile) lo = mid; else hi = mid;
     }
-    if (live) {
-        uint2 *dst = reinterpret_cast<uint2 *>(xs + r * 64);
-        dst[part] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-        dst[8 + part] = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-        if (part == 0) nrm[r] = s;
+    const int64_t ev_lo = ptr[lo], n = ptr[lo + 1] - ev_lo;
+    const int64_t li0 = (tile - rec_base_tile(ptr, lo)) * 32;
+    if (li0 >= n) return;                   // a slot between two events: never read
+    const bool live = li0 + col < n;
+    const int64_t r = ev_lo + (live ? li0 + col : 0);
+    float f[16];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const float4 *g = reinterpret_cast<const float4 *>(x + r * 32 + 16 * kb + 8 * hh);
+        const float4 v0 = g[0], v1 = g[1];
+        f[8 * kb + 0] = v0.x; f[8 * kb + 1] = v0.y; f[8 * kb + 2] = v0.z; f[8 * kb + 3] = v0.w;
+        f[8 * kb + 4] = v1.x; f[8 * kb + 5] = v1.y; f[8 * kb + 6] = v1.z; f[8 * kb + 7] = v1.w;
+    }
+    float s = 0.0f;
+    unsigned h[16], m[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const float v = live ? f[u] : 0.0f;
+        s = __builtin_fmaf(v, v, s);
+        h[u] = bf16_rne_bits(v);
+        m[u] = bf16_rne_bits(v - __uint_as_float(h[u] << 16));   // the subtraction is exact
+    }
+    s += __shfl_xor(s, 32, 64);             // the row's other 16 features: fixed order, deterministic
+    if (!live) s = __builtin_inff();
+    uint4 *dst = reinterpret_cast<uint4 *>(rec + tile * kRecBytes);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        dst[kb * 64 + lane] = make_uint4(h[8 * kb] | (h[8 * kb + 1] << 16), h[8 * kb + 2] | (h[8 * kb + 3] << 16),
+                                         h[8 * kb + 4] | (h[8 * kb + 5] << 16), h[8 * kb + 6] | (h[8 * kb + 7] << 16));
+        dst[(2 + kb) * 64 + lane] = make_uint4(m[8 * kb] | (m[8 * kb + 1] << 16), m[8 * kb + 2] | (m[8 * kb + 3] << 16),
+                                               m[8 * kb + 4] | (m[8 * kb + 5] << 16), m[8 * kb + 6] | (m[8 * kb + 7] << 16));
+    }
+    if (hh == 0) {
+        reinterpret_cast<float *>(rec + tile * kRecBytes + kRecFragBytes)[col] = s;
+        if (live) nrm[r] = s;
     }
 }
 
@@ -637,24 +677,20 @@ __device__ __forceinline__ f32x16 filter_block(const bf16x8 (&av)[4], const bf16
     return acc;
 }
 
-// candidate tile [c0, c0+32): A operand = the lane's 8-feature slices of candidate c0 + (lane & 31); the accumulator
-// is seeded with |x_j|^2 of the 16 candidate rows this lane receives results for
-__device__ __forceinline__ void filter_load(bf16x8 (&av)[4], f32x16 &cinit, const unsigned short *__restrict__ xs,
-                                            const float *__restrict__ nrm, int c0, int chi, int col, int hh)
+// one candidate tile record: the lane's four A operands and the squared norms of the 16 candidate rows it receives
+// results for (accumulator seed; rows (e & 3) + 8 (e >> 2) + 4 hh)
+__device__ __forceinline__ void filter_load(bf16x8 (&av)[4], f32x16 &cinit, const uint8_t *__restrict__ rec, int64_t tidx,
+                                            int lane, int hh)
 {
-    const int row = min(c0 + col, chi - 1);
-    const bf16x8 *g = reinterpret_cast<const bf16x8 *>(xs + (int64_t)row * 64 + 8 * hh);
-    av[0] = g[0]; av[1] = g[2]; av[2] = g[4]; av[3] = g[6];
-    const float inf = __builtin_inff();
-    if (c0 + 32 <= chi) {
+    const uint8_t *base = rec + tidx * kRecBytes;
+    const bf16x8 *g = reinterpret_cast<const bf16x8 *>(base);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) cinit[e] = nrm[c0 + (e & 3) + 8 * (e >> 2) + 4 * hh];
-    } else {
+    for (int m = 0; m < 4; ++m) av[m] = g[m * 64 + lane];
+    const float4 *nr = reinterpret_cast<const float4 *>(base + kRecFragBytes);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int r = c0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-            cinit[e] = (r < chi) ? nrm[r] : inf;   // rows past the range: key = +inf, never admitted
-        }
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = nr[2 * q + hh];
+        cinit[4 * q] = v.x; cinit[4 * q + 1] = v.y; cinit[4 * q + 2] = v.z; cinit[4 * q + 3] = v.w;
     }
 }
 
@@ -787,6 +823,11 @@ __device__ __forceinline__ float chain_dist32(const float *__restrict__ xj, cons
     return acc;
 }
 
+// events of the second form (knn_filter2_kernel below)
+constexpr int kF2MinNodes = 2048;   // smaller events: first form (tau of the second form needs M tiles to exist at all)
+constexpr int kF2MaxNodes = 65536;  // tile number must fit 11 bits
+__device__ __forceinline__ bool f2_in_domain(int n) { return n >= kF2MinNodes && n <= kF2MaxNodes; }
+
 template <int KP>
 __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(const KnnFilterArgs a)
 {
@@ -797,7 +838,7 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = lane & 31, hh = lane >> 5;
     const int item = blockIdx.x * kWavesPerGroup + wv;
-    const unsigned short *__restrict__ xs = a.xs;
+    const uint8_t *__restrict__ rec = a.rec;
     const int64_t *__restrict__ ptr = a.ptr;
     FilterQueue<QF> &Q = queue_all[wv];
 
@@ -813,6 +854,7 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
     const int pos = find_tile_event(a.tile_ptr, a.B, tile);
     const int ev = a.order[pos];
     const int ev_lo = (int)ptr[ev], ev_hi = (int)ptr[ev + 1];
+    if (a.form2 && f2_in_domain(ev_hi - ev_lo)) return;   // swept by knn_filter2_kernel
     const int q_first = ev_lo + (tile - a.tile_ptr[pos]) * kFQ;
     int clo = ev_lo, chi = ev_hi;
     if (nsub > 1) {
@@ -822,16 +864,19 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
     }
     const bool fits = (ev_hi - ev_lo) <= 65535;   // 16-bit candidate ids
 
-    // B operands of both 32-query blocks: -2 * the query's bf16 terms (exact: sign flip and exponent + 1)
+    // record of the event's first 32 candidates; the (32-aligned, event-relative) tile at c0 is rbase + (c0 - ev_lo) / 32
+    const int64_t rbase = (ptr[ev] >> 5) + ev;
+    const int64_t rlast = rbase + (ev_hi - ev_lo - 1) / 32;
+    // B operands of both 32-query blocks: -2 * the query's bf16 terms (exact: sign flip and exponent + 1); the query
+    // tiles are records too (a block past the end of the event reads the event's last record: idle lanes)
     bf16x8 bq[2][4];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int q = q_first + b * 32 + col;
-        const int64_t qq = (q < ev_hi) ? q : ev_lo;
-        const bf16x8 *g = reinterpret_cast<const bf16x8 *>(xs + qq * 64 + 8 * hh);
+        const int64_t qrec = min(rbase + (q_first - ev_lo) / 32 + b, rlast);
+        const bf16x8 *g = reinterpret_cast<const bf16x8 *>(rec + qrec * kRecBytes);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const bf16x8 v = g[2 * m];
+            const bf16x8 v = g[m * 64 + lane];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float f = -2.0f * __uint_as_float(((unsigned)(unsigned short)v[u]) << 16);
@@ -852,10 +897,11 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
     if (clo < chi && fits) {
         bf16x8 av[4], an[4];
         f32x16 ci, cn;
-        filter_load(av, ci, xs, a.nrm, clo, chi, col, hh);
+        int64_t tidx = rbase + (clo - ev_lo) / 32;
+        filter_load(av, ci, rec, tidx, lane, hh);
         for (int c0 = clo; c0 < chi; c0 += 32) {
             const bool more = c0 + 32 < chi;
-            if (more) filter_load(an, cn, xs, a.nrm, c0 + 32, chi, col, hh);
+            if (more) filter_load(an, cn, rec, ++tidx, lane, hh);
             f32x16 acc0 = filter_block(av, bq[0], ci);
             f32x16 acc1 = filter_block(av, bq[1], ci);
             // lanes 32..63 of block 0 <-> lanes 0..31 of block 1: afterwards acc0 = rows {0-3, 8-11, ..} and
@@ -1034,6 +1080,404 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
 }
 
 
+// ---- filter, second form ("tile masks"): events of kF2MinNodes .. 65536 nodes ------------------------------------------
+// Budget of the first form at 64 x 4500 x 32 (tools/knn_budget.sh, ablation builds): once the operands arrive as
+// contiguous records the kernel is bound by the per-key push -- two LDS stores per key on a 64 B/clk store path plus
+// ~5 VALU ops -- and by the drains that re-read the queue.  This form keeps the per-key work to a compare and a carry
+// add (a 32-bit hit mask per lane and tile) and touches LDS once per TILE:
+//   * tau of a query = the M-th smallest TILE MINIMUM seen so far (a v_min3 tree over the lane's 32 keys, then the
+//     v_med3 insertion chain once per tile): every one of those M tiles holds a key <= tau, so at least M >= k
+//     candidates lie at or below it, and it is refreshed every tile instead of every drain;
+//   * mask bit r = key of candidate row r < tau (the value before this tile's update); a tile with a non-zero mask
+//     appends ONE 8-byte entry {mask, tile minimum | tile number};
+//   * entries whose tile minimum exceeds the current tau are dropped when a lane runs out of slots and once at the
+//     end: what survives are the ~M tiles that hold the list's keys.  Every dropped candidate -- an unset bit, a tile
+//     that was never appended, a dropped entry -- had key >= the tau of its time >= the final tau: the same
+//     certificate as the first form with T = tk[M-1];
+//   * the first kF2Defer tiles only feed tau; they are swept again at the end against the final tau (their masks
+//     would otherwise be nearly full: tau is still the sentinel there);
+//   * the exact re-rank walks the set bits of the surviving entries.
+constexpr int kF2Defer = 32;        // tiles that only feed tau in the main sweep
+constexpr int kF2Slots = 30;        // entries per lane
+constexpr int kF2RowF = 16;         // features staged per re-rank half round
+constexpr unsigned kF2TileBits = 11u, kF2TileMask = (1u << kF2TileBits) - 1u;
+
+struct F2Wave {
+    uint2 ent[kF2Slots][kWave];              // 15 360 B
+    float rows[kWave][kF2RowF + 4];          //  5 120 B: half rows of the re-rank (16-byte aligned, conflict-free b128)
+};
+static_assert(sizeof(F2Wave) == 20480, "two workgroups of four wavefronts fill the CU's 160 KB exactly");
+
+template <int M>
+struct F2Lane {
+    float tk[M];     // the M smallest tile minima, sorted
+    float tau;       // admission threshold (= tk[M-1]; -inf for idle lanes / after an overflow)
+    int cnt;         // entries in the lane's queue
+    bool overflow;
+};
+
+// drop the entries whose tile minimum is above tau (compare with a 2^-10 relative allowance: the stored minimum carries
+// the tile number in its low mantissa bits)
+template <int M>
+__device__ __forceinline__ void f2_compact(F2Lane<M> &L, F2Wave &S, int lane)
+{
+    const float tauS = L.tau + __builtin_fabsf(L.tau) * 9.765625e-4f + 1e-30f;
+    int maxcnt = L.cnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, off, 64));
+    int out = 0;
+    for (int s = 0; s < maxcnt; ++s) {
+        if (s < L.cnt) {
+            const uint2 e = S.ent[s][lane];
+            if (!(__uint_as_float(e.y) > tauS)) { S.ent[out][lane] = e; ++out; }
+        }
+    }
+    L.cnt = out;
+    if (out > kF2Slots - 4) {   // more than ~26 tiles tied at tau: leave the query to the exact path
+        L.overflow = true;
+        L.cnt = 0;
+        L.tau = -__builtin_inff();
+    }
+}
+
+// One pass over the tiles [t_lo, t_hi) of the event whose first record is rbase.  UPD: the tile minima feed tk / tau;
+// REC: hit masks are recorded.
+template <int M, bool UPD, bool REC>
+__device__ __forceinline__ void f2_sweep(F2Lane<M> &L, F2Wave &S, const uint8_t *__restrict__ rec, int64_t rbase,
+                                         int t_lo, int t_hi, const bf16x8 (&bq)[2][4], int lane, int hh, bool alive)
+{
+    if (t_lo >= t_hi) return;
+    bf16x8 av[4], an[4];
+    f32x16 ci, cn;
+    filter_load(av, ci, rec, rbase + t_lo, lane, hh);
+    for (int t = t_lo; t < t_hi; ++t) {
+        const bool more = t + 1 < t_hi;
+        if (more) filter_load(an, cn, rec, rbase + t + 1, lane, hh);
+        f32x16 acc0 = filter_block(av, bq[0], ci);
+        f32x16 acc1 = filter_block(av, bq[1], ci);
+        // lanes 32..63 of block 0 <-> lanes 0..31 of block 1: afterwards acc0 = rows {0-3, 8-11, ..} and
+        // acc1 = rows {4-7, 12-15, ..} of THIS lane's query
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[e]), __float_as_uint(acc1[e]), false,
+                                                            false);
+            acc0[e] = __uint_as_float(r[0]);
+            acc1[e] = __uint_as_float(r[1]);
+        }
+        unsigned mask = 0u;
+        if (REC) {
+            if (__any(L.cnt >= kF2Slots - 1)) f2_compact<M>(L, S, lane);
+            // candidate row r = 8 (r >> 3) + 4 a + (r & 3) sits in acc{a}[(r & 3) + 4 (r >> 3)]; rows in ascending order,
+            // so row r ends up in bit 31 - r.  v_cmp + v_addc (mask = 2 mask + carry): two VALU ops per key.
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                const int e = (r & 3) + 4 * (r >> 3);
+                const float key = ((r >> 2) & 1) ? acc1[e] : acc0[e];
+                asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                    : "+v"(mask)
+                    : "v"(key), "v"(L.tau)
+                    : "vcc");
+            }
+        }
+        float tmin = -__builtin_inff();   // deferred tiles: "never drop" (their tau is already final)
+        if (UPD) {
+            tmin = kKnnSentinel;          // also keeps a NaN key out of the v_med3 chain
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                tmin = __builtin_fminf(tmin, __builtin_fminf(acc0[e], acc0[e + 1]));
+                tmin = __builtin_fminf(tmin, __builtin_fminf(acc1[e], acc1[e + 1]));
+            }
+        }
+        if (REC) {
+            // one 8-byte entry per tile and lane, kept only when the mask is non-zero (branch-free append)
+            const unsigned packed = (__float_as_uint(tmin) & ~kF2TileMask) | (unsigned)t;
+            S.ent[L.cnt][lane] = make_uint2(mask, packed);
+            L.cnt += (mask != 0u) ? 1 : 0;
+        }
+        if (UPD) {
+#pragma unroll
+            for (int p = M - 1; p >= 1; --p) L.tk[p] = __builtin_amdgcn_fmed3f(L.tk[p - 1], tmin, L.tk[p]);
+            L.tk[0] = __builtin_fminf(L.tk[0], tmin);
+            if (alive && !L.overflow) L.tau = L.tk[M - 1];
+        }
+        if (more) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) av[m] = an[m];
+            ci = cn;
+        }
+    }
+}
+
+template <int KP>
+__global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter2_kernel(const KnnFilterArgs a)
+{
+    constexpr int M = filter_list_len(KP);
+    constexpr int MS = (M + 1 + 3) & ~3;
+    __shared__ F2Wave sh_all[kWavesPerGroup];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int col = lane & 31, hh = lane >> 5;
+    const int item = blockIdx.x * kWavesPerGroup + wv;
+    const uint8_t *__restrict__ rec = a.rec;
+    const int64_t *__restrict__ ptr = a.ptr;
+    F2Wave &S = sh_all[wv];
+
+    const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
+    int tile = item, sub = 0, nsub = 1;
+    if (item >= n_full) {
+        const int r = item - n_full;
+        tile = n_full + r / split;
+        sub = r % split;
+        nsub = split;
+    }
+    if (tile >= total) return;
+    const int pos = find_tile_event(a.tile_ptr, a.B, tile);
+    const int ev = a.order[pos];
+    const int ev_lo = (int)ptr[ev], ev_hi = (int)ptr[ev + 1];
+    if (!f2_in_domain(ev_hi - ev_lo)) return;      // the first form's events
+    const int q_first = ev_lo + (tile - a.tile_ptr[pos]) * kFQ;
+    int clo = ev_lo, chi = ev_hi;
+    if (nsub > 1) {
+        const int chunk = (((chi - clo) + nsub - 1) / nsub + 31) & ~31;
+        clo = min(chi, clo + sub * chunk);
+        chi = min(chi, clo + chunk);
+    }
+    const int64_t rbase = (ptr[ev] >> 5) + ev;
+    const int64_t rlast = rbase + (ev_hi - ev_lo - 1) / 32;
+    const int t_lo = (clo - ev_lo) / 32, t_hi = (chi - ev_lo + 31) / 32;
+
+    bf16x8 bq[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int64_t qrec = min(rbase + (q_first - ev_lo) / 32 + b, rlast);
+        const bf16x8 *g = reinterpret_cast<const bf16x8 *>(rec + qrec * kRecBytes);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const bf16x8 v = g[m * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float f = -2.0f * __uint_as_float(((unsigned)(unsigned short)v[u]) << 16);
+                bq[b][m][u] = (short)(__float_as_uint(f) >> 16);
+            }
+        }
+    }
+    const int myq = q_first + hh * 32 + col;
+    const bool valid = myq < ev_hi;
+    F2Lane<M> L;
+#pragma unroll
+    for (int p = 0; p < M; ++p) L.tk[p] = kKnnSentinel;
+    L.tau = -__builtin_inff();     // nothing is recorded before tk is full
+    L.cnt = 0;
+    L.overflow = false;
+
+    const int t_def = min(t_hi, t_lo + kF2Defer);
+    f2_sweep<M, true, false>(L, S, rec, rbase, t_lo, t_def, bq, lane, hh, valid);     // tau only
+    f2_sweep<M, true, true>(L, S, rec, rbase, t_def, t_hi, bq, lane, hh, valid);
+    f2_sweep<M, false, true>(L, S, rec, rbase, t_lo, t_def, bq, lane, hh, valid);     // against the final tau
+    f2_compact<M>(L, S, lane);
+
+    // ---- exact re-rank of the set bits (R1 chain, top-k by (d, j)), candidates fetched cooperatively ----------------
+    const int64_t qrow_id = valid ? myq : ev_lo;
+    float qrow[32];
+    {
+        const float4 *g = reinterpret_cast<const float4 *>(a.x + qrow_id * 32);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 v = g[c];
+            qrow[4 * c] = v.x; qrow[4 * c + 1] = v.y; qrow[4 * c + 2] = v.z; qrow[4 * c + 3] = v.w;
+        }
+    }
+    float kd[KP];
+    int32_t kj[KP];
+#pragma unroll
+    for (int p = 0; p < KP; ++p) { kd[p] = kKnnSentinel; kj[p] = -1; }
+    const int nent = (valid && !L.overflow) ? L.cnt : 0;
+    int slot = 0;
+    unsigned cmask = 0u;
+    int ctile = 0;
+    // next candidate of this lane (ascending tiles as appended, ascending rows inside a tile), -1 when exhausted
+    auto pop = [&]() -> int32_t {
+        if (cmask == 0u && slot < nent) {
+            const uint2 e = S.ent[slot][lane];
+            cmask = e.x;
+            ctile = (int)(e.y & kF2TileMask);
+            ++slot;
+        }
+        if (cmask == 0u) return -1;
+        const int r = __builtin_clz(cmask);
+        cmask &= ~(0x80000000u >> r);
+        const int32_t j = ev_lo + ctile * 32 + r;
+        return j < ev_hi ? j : -1;      // rows past the event's end have key = +inf and are never set; belt and braces
+    };
+    // rows are fetched half a row at a time (16 features = 64 bytes): load instruction h*4 + r brings half h of rows
+    // 16 r + (lane >> 2), 16 bytes per lane; the chain continues over the two halves in feature order
+    auto fetch = [&](int32_t j, float4 (&pv)[8]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int32_t jr = __shfl(j, 16 * r + (lane >> 2), 64);
+                pv[4 * h + r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (jr >= 0) pv[4 * h + r] = reinterpret_cast<const float4 *>(a.x + (int64_t)jr * 32)[4 * h + (lane & 3)];
+            }
+    };
+    auto round = [&](const float4 (&pv)[8], int32_t j) {
+        float dc = 0.0f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<float4 *>(&S.rows[16 * r + (lane >> 2)][4 * (lane & 3)]) = pv[4 * h + r];
+            wave_sync();
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const float4 v = *reinterpret_cast<const float4 *>(&S.rows[lane][4 * c4]);
+                const int f0 = 16 * h + 4 * c4;
+                float df;
+                df = v.x - qrow[f0 + 0]; dc = __builtin_fmaf(df, df, dc);
+                df = v.y - qrow[f0 + 1]; dc = __builtin_fmaf(df, df, dc);
+                df = v.z - qrow[f0 + 2]; dc = __builtin_fmaf(df, df, dc);
+                df = v.w - qrow[f0 + 3]; dc = __builtin_fmaf(df, df, dc);
+            }
+        }
+        if (j >= 0) {
+            // sorted insert by (d, j) (R2)
+#pragma unroll
+            for (int p = KP - 1; p >= 1; --p) {
+                const bool gq = kd[p - 1] > dc || (kd[p - 1] == dc && kj[p - 1] > j);
+                const bool gp = kd[p] > dc || (kd[p] == dc && kj[p] > j);
+                const float dn = gq ? kd[p - 1] : (gp ? dc : kd[p]);
+                const int32_t jn = gq ? kj[p - 1] : (gp ? j : kj[p]);
+                kd[p] = dn; kj[p] = jn;
+            }
+            if (kd[0] > dc || (kd[0] == dc && kj[0] > j)) { kd[0] = dc; kj[0] = j; }
+        }
+    };
+    {
+        float4 pa[8], pb[8];
+        int32_t ja = pop(), jb;
+        fetch(ja, pa);
+        while (__any(ja >= 0)) {
+            jb = pop();
+            fetch(jb, pb);
+            round(pa, ja);
+            if (!__any(jb >= 0)) break;
+            ja = pop();
+            fetch(ja, pa);
+            round(pb, jb);
+        }
+    }
+    if (!valid) return;
+    const int k = a.k;
+    const float tau = L.tk[M - 1];
+    if (nsub == 1) {
+        float kth = -1.0f;
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+            if (p < k) {
+                a.nbr[(int64_t)myq * k + p] = kj[p];
+                a.dist[(int64_t)myq * k + p] = kd[p];
+            }
+            if (p == k - 1 && kj[p] >= 0) kth = kd[p];
+        }
+        if (a.nbr16) {
+            uint16_t *r16 = a.nbr16 + (int64_t)myq * k;
+            if ((k & 1) == 0) {   // two ids per dword store
+#pragma unroll
+                for (int p = 0; p + 1 < KP; p += 2)
+                    if (p < k)
+                        reinterpret_cast<unsigned *>(r16)[p >> 1] =
+                            (unsigned)local_id16(kj[p], ev_lo) | ((unsigned)local_id16(kj[p + 1], ev_lo) << 16);
+            } else {
+#pragma unroll
+                for (int p = 0; p < KP; ++p)
+                    if (p < k) r16[p] = local_id16(kj[p], ev_lo);
+            }
+        }
+        // certificate: every dropped candidate had key >= tau (see the header of this form)
+        const float nx = a.nrm[myq];
+        const float an = __builtin_sqrtf(nx) * 1.000001f;
+        const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
+        const float slack = 2.0f * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1e-30f;
+        const bool full = tau < kKnnSentinel;
+        if (L.overflow || (full && !(tau + nx - slack > kth))) {
+            const int xt = a.xtile_ptr[pos] + (myq - ev_lo) / a.xtile_queries;
+            a.qflag[myq] = 1;
+            atomicAdd(a.flags + xt, 1);   // a count: order-independent
+        }
+        return;
+    }
+    // ---- split (tail) items: the exact top-KP of this candidate range + its threshold, merged by knn_filter2_merge_kernel
+    const int64_t fslot = (int64_t)(tile - n_full) * kFQ + hh * 32 + col;
+    float *ld = a.psd + (fslot * nsub + sub) * MS;
+    int32_t *lj = a.psj + (fslot * nsub + sub) * MS;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) { ld[p] = kd[p]; lj[p] = kj[p]; }
+    ld[M] = tau;
+    lj[M] = L.overflow ? 1 : 0;
+}
+
+// Split (tail) tiles of the second form: merge the two exact partial lists of a query by (d, j) and certify against
+// each sub-sweep's threshold.  One lane per query.
+template <int KP>
+__global__ __launch_bounds__(256) void knn_filter2_merge_kernel(const KnnFilterArgs a)
+{
+    constexpr int M = filter_list_len(KP);
+    constexpr int MS = (M + 1 + 3) & ~3;
+    const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
+    if (split <= 1) return;
+    const int64_t fslot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ft = n_full + (int)(fslot / kFQ);
+    if (ft >= total) return;
+    const int pos = find_tile_event(a.tile_ptr, a.B, ft);
+    const int ev = a.order[pos];
+    const int64_t ev_lo = a.ptr[ev], ev_hi = a.ptr[ev + 1];
+    if (!f2_in_domain((int)(ev_hi - ev_lo))) return;
+    const int64_t q = ev_lo + (int64_t)(ft - a.tile_ptr[pos]) * kFQ + (fslot % kFQ);
+    if (q >= ev_hi) return;
+    const float *pd = a.psd + fslot * split * MS;
+    const int32_t *pj = a.psj + fslot * split * MS;
+    const int k = a.k;
+    int head[kFilterMaxSplit];
+#pragma unroll
+    for (int s = 0; s < kFilterMaxSplit; ++s) head[s] = 0;
+    float kth = -1.0f;
+    for (int p = 0; p < k; ++p) {
+        float bd = kKnnSentinel;
+        int32_t bj = -1;
+        int bs = -1;
+#pragma unroll
+        for (int s = 0; s < kFilterMaxSplit; ++s) {
+            if (s < split && head[s] < KP) {
+                const float d = pd[s * MS + head[s]];
+                const int32_t j = pj[s * MS + head[s]];
+                if (j >= 0 && (bs < 0 || d < bd || (d == bd && j < bj))) { bd = d; bj = j; bs = s; }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < kFilterMaxSplit; ++s) head[s] += (s == bs) ? 1 : 0;
+        a.dist[q * k + p] = bd;
+        a.nbr[q * k + p] = bj;
+        if (a.nbr16) a.nbr16[q * k + p] = local_id16(bj, (int)ev_lo);
+        if (p == k - 1 && bj >= 0) kth = bd;
+    }
+    const float nx = a.nrm[q];
+    const float an = __builtin_sqrtf(nx) * 1.000001f;
+    const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
+    const float slack = 2.0f * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1e-30f;
+    bool fail = false;
+    for (int s = 0; s < split; ++s) {
+        const float tau = pd[s * MS + M];
+        const bool full = tau < kKnnSentinel;
+        if (pj[s * MS + M] != 0 || (full && !(tau + nx - slack > kth))) fail = true;
+    }
+    if (fail) {
+        const int xt = a.xtile_ptr[pos] + (int)((q - ev_lo) / a.xtile_queries);
+        a.qflag[q] = 1;
+        atomicAdd(a.flags + xt, 1);
+    }
+}
+
 // Exact R1 chain for the kept candidates of one query, top-k by (d, j), certification.  M lanes per query (one kept
 // candidate each; split tiles take a second round), 64 / M queries per wavefront; workgroups of one XCD walk one
 // contiguous range of queries so the candidate rows they gather stay in that XCD's L2.
@@ -1064,6 +1508,7 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
     const int pos = find_tile_event(a.tile_ptr, a.B, ft);
     const int ev = a.order[pos];
     const int64_t ev_lo = a.ptr[ev], ev_hi = a.ptr[ev + 1];
+    if (a.form2 && f2_in_domain((int)(ev_hi - ev_lo))) return;   // merged by knn_filter2_merge_kernel
     const int qoff = part * QPB + wv * QPW + qw;         // query within the tile
     const int64_t q = ev_lo + (int64_t)(ft - a.tile_ptr[pos]) * kFQ + qoff;
     const bool active = qw < QPW && qoff < kFQ && q < ev_hi;
@@ -1294,7 +1739,8 @@ struct KnnWorkspace {
     int32_t *fpos_of;
     int32_t *ftile_ptr;
     float *nrm;
-    unsigned short *xs;
+    uint8_t *rec;         // candidate tile records
+    int64_t nrec;
     int32_t *flags;       // flags[...] and qflag[N] are one zero-filled region
     uint8_t *qflag;
     size_t zero_bytes;
@@ -1332,7 +1778,8 @@ inline KnnWorkspace carve_workspace(void *ws, int64_t N, int B, int KP)
     w.fpos_of = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
     w.ftile_ptr = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
     w.nrm = reinterpret_cast<float *>(take(sizeof(float) * (size_t)N));
-    w.xs = reinterpret_cast<unsigned short *>(take(sizeof(unsigned short) * (size_t)N * 64));
+    w.nrec = (N >> 5) + B + 1;                               // event b owns records from (ptr[b] >> 5) + b
+    w.rec = reinterpret_cast<uint8_t *>(take((size_t)w.nrec * kRecBytes));
     w.zero_bytes = sizeof(int32_t) * (size_t)exact_tiles_max(N, B) + (size_t)N;
     w.flags = reinterpret_cast<int32_t *>(take(w.zero_bytes));
     w.qflag = reinterpret_cast<uint8_t *>(w.flags + exact_tiles_max(N, B));
@@ -1348,24 +1795,39 @@ inline int filter_mode()
     return (e && strcmp(e, "exact") == 0) ? 0 : (e && strcmp(e, "filter_only") == 0) ? 2 : 1;
 }
 
+// DMET_KNN_FILTER=1: first form (per-key queue) for every event (A/B timing, tests); default: second form where it applies
+inline int filter_form2()
+{
+    const char *e = getenv("DMET_KNN_FILTER");
+    return (e && strcmp(e, "1") == 0) ? 0 : 1;
+}
+
 // prep + filter (+ in-place re-rank) + re-rank of the split tail tiles, for result capacity KF >= k
 template <int KF>
 int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, hipStream_t st)
 {
     const int slots = simds * 2;   // two filter wavefronts per SIMD
-    hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((f.N * 8 + 255) / 256)), dim3(256), 0, st, f.x, f.N, w.nrm, w.xs,
-                       reinterpret_cast<uint32_t *>(w.flags), w.zero_bytes);
+    hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((w.nrec * kWave + 255) / 256)), dim3(256), 0, st, f.x, f.ptr, f.B,
+                       f.N, w.nrm, w.rec, w.nrec, reinterpret_cast<uint32_t *>(w.flags), w.zero_bytes);
     DMET_LAUNCH_CHECK("knn_prep_kernel");
     const int64_t ftiles_max = (f.N + kFQ - 1) / kFQ + f.B;
     const int64_t fblocks = (ftiles_max + slots + kWavesPerGroup - 1) / kWavesPerGroup;
     hipLaunchKernelGGL((knn_filter_kernel<KF>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
     DMET_LAUNCH_CHECK("knn_filter_kernel");
+    if (f.form2) {
+        hipLaunchKernelGGL((knn_filter2_kernel<KF>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
+        DMET_LAUNCH_CHECK("knn_filter2_kernel");
+    }
     constexpr int kRerankQpb = 4 * (kWave / filter_list_len(KF));
     constexpr int kRerankParts = (kFQ + kRerankQpb - 1) / kRerankQpb;
     // only the split tail tiles (fewer than `slots`) need the separate re-rank: whole sweeps re-rank in place
     const int64_t tail_max = ftiles_max < slots ? ftiles_max : slots;
     hipLaunchKernelGGL((knn_rerank_kernel<KF>), dim3((unsigned)(tail_max * kRerankParts)), dim3(256), 0, st, f);
     DMET_LAUNCH_CHECK("knn_rerank_kernel");
+    if (f.form2) {
+        hipLaunchKernelGGL((knn_filter2_merge_kernel<KF>), dim3((unsigned)((tail_max * kFQ + 255) / 256)), dim3(256), 0, st, f);
+        DMET_LAUNCH_CHECK("knn_filter2_merge_kernel");
+    }
     return 0;
 }
 
@@ -1393,8 +1855,8 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     // matrix-core filter + exact re-rank for the hot shape (D = 32, k <= 20); the exact kernel then only recomputes
     // the tiles the re-rank could not certify
     if (use_filter) {
-        KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.xs, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
-                        w.psd, w.psj, nbr, dist, nbr16, w.flags, w.qflag, w.tile_ptr, QT};
+        KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.rec, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
+                        w.psd, w.psj, nbr, dist, nbr16, w.flags, w.qflag, w.tile_ptr, QT, filter_form2()};
         int rc = 0;
         if constexpr (KP == 8) rc = launch_filter<8>(f, w, simds, st);
         else if constexpr (KP == 16) rc = launch_filter<16>(f, w, simds, st);
