@@ -190,6 +190,26 @@ struct KnnPlanOut {
     KnnPlan *plan;
 };
 
+// Event order of the plans.  Ranks are by size, longest first.  Workgroups are dealt round-robin over the 8 XCDs
+// (each with its own L2), and the matrix-core filter maps each XCD's workgroups to ONE contiguous eighth of the tile
+// list so that the tiles of an event -- which all sweep the same candidate records -- run on one XCD and re-read them
+// from its L2 (the records of a batch do not fit any L2: left to round-robin every sweep comes from the Infinity
+// Cache).  For the eighths to carry equal work on ragged batches the ranks are dealt to 8 bins in snake order
+// (0..7, 7..0, ...) and the bins concatenated: every bin, hence every XCD, gets the same mix of event sizes and still
+// runs its own events longest first.  Small batches keep the plain order.
+__device__ __forceinline__ int xcd_dealt_position(int rank, int B)
+{
+    if (B < 4 * kNumXcd) return rank;
+    const int c = rank % (2 * kNumXcd), g = rank / (2 * kNumXcd);
+    const int bin = c < kNumXcd ? c : 2 * kNumXcd - 1 - c;
+    const int idx = 2 * g + (c >= kNumXcd ? 1 : 0);
+    const int rem = B % (2 * kNumXcd), full = B / (2 * kNumXcd);
+    int start = 0;
+    for (int b = 0; b < bin; ++b)      // sizes of the earlier bins
+        start += 2 * full + (b < min(rem, kNumXcd) ? 1 : 0) + ((rem > kNumXcd && b > 2 * kNumXcd - 1 - rem) ? 1 : 0);
+    return start + idx;
+}
+
 // blockIdx.x selects one of up to two plans (exact kernel: 128-query tiles; matrix-core filter: 64-query tiles)
 __global__ __launch_bounds__(256) void knn_plan_kernel(const int64_t *__restrict__ ptr, int B, KnnPlanOut o0, KnnPlanOut o1)
 {
@@ -207,8 +227,9 @@ __global__ __launch_bounds__(256) void knn_plan_kernel(const int64_t *__restrict
                 const int64_t nc = ptr[c + 1] - ptr[c];
                 rank += (nc > nb || (nc == nb && c < b)) ? 1 : 0;
             }
-            order[rank] = b;
-            pos_of[b] = rank;
+            const int p = xcd_dealt_position(rank, B);
+            order[p] = b;
+            pos_of[b] = p;
         }
     } else {
         for (int b = tid; b < B; b += 256) { order[b] = b; pos_of[b] = b; }
@@ -1157,6 +1178,7 @@ __device__ __forceinline__ void f2_sweep(F2Lane<M> &L, F2Wave &S, const uint8_t 
         f32x16 acc1 = filter_block(av, bq[1], ci);
         // lanes 32..63 of block 0 <-> lanes 0..31 of block 1: afterwards acc0 = rows {0-3, 8-11, ..} and
         // acc1 = rows {4-7, 12-15, ..} of THIS lane's query
+#if !(defined(DMET_F2_ABL) && DMET_F2_ABL >= 4)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[e]), __float_as_uint(acc1[e]), false,
@@ -1164,23 +1186,41 @@ __device__ __forceinline__ void f2_sweep(F2Lane<M> &L, F2Wave &S, const uint8_t 
             acc0[e] = __uint_as_float(r[0]);
             acc1[e] = __uint_as_float(r[1]);
         }
+#endif
         unsigned mask = 0u;
-        if (REC) {
+#if defined(DMET_F2_ABL) && DMET_F2_ABL >= 2
+        constexpr bool kRec = false;     // cycle-budget experiment (tools/knn_budget2.sh)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc0[e]), "v"(acc1[e]));
+#else
+        constexpr bool kRec = REC;
+#endif
+        if (kRec) {
             if (__any(L.cnt >= kF2Slots - 1)) f2_compact<M>(L, S, lane);
             // candidate row r = 8 (r >> 3) + 4 a + (r & 3) sits in acc{a}[(r & 3) + 4 (r >> 3)]; rows in ascending order,
             // so row r ends up in bit 31 - r.  v_cmp + v_addc (mask = 2 mask + carry): two VALU ops per key.
+            // The compares write their own SGPR pairs (independent, issued ahead); two carry chains of 16 rows each.
+            unsigned mlo = 0u, mhi = 0u;
 #pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                const int e = (r & 3) + 4 * (r >> 3);
-                const float key = ((r >> 2) & 1) ? acc1[e] : acc0[e];
-                asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                    : "+v"(mask)
-                    : "v"(key), "v"(L.tau)
-                    : "vcc");
+            for (int r = 0; r < 16; ++r) {
+                const int ra = r, rb = r + 16;
+                const float ka = ((ra >> 2) & 1) ? acc1[(ra & 3) + 4 * (ra >> 3)] : acc0[(ra & 3) + 4 * (ra >> 3)];
+                const float kb = ((rb >> 2) & 1) ? acc1[(rb & 3) + 4 * (rb >> 3)] : acc0[(rb & 3) + 4 * (rb >> 3)];
+                unsigned long long ca, cb;
+                asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(ca) : "v"(ka), "v"(L.tau));
+                asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(cb) : "v"(kb), "v"(L.tau));
+                asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(mhi) : "s"(ca) : "vcc");
+                asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(mlo) : "s"(cb) : "vcc");
             }
+            mask = (mhi << 16) | mlo;
         }
         float tmin = -__builtin_inff();   // deferred tiles: "never drop" (their tau is already final)
-        if (UPD) {
+#if defined(DMET_F2_ABL) && DMET_F2_ABL >= 3
+        constexpr bool kUpd = false;
+#else
+        constexpr bool kUpd = UPD;
+#endif
+        if (kUpd) {
             tmin = kKnnSentinel;          // also keeps a NaN key out of the v_med3 chain
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
@@ -1188,13 +1228,13 @@ __device__ __forceinline__ void f2_sweep(F2Lane<M> &L, F2Wave &S, const uint8_t 
                 tmin = __builtin_fminf(tmin, __builtin_fminf(acc1[e], acc1[e + 1]));
             }
         }
-        if (REC) {
+        if (kRec) {
             // one 8-byte entry per tile and lane, kept only when the mask is non-zero (branch-free append)
             const unsigned packed = (__float_as_uint(tmin) & ~kF2TileMask) | (unsigned)t;
             S.ent[L.cnt][lane] = make_uint2(mask, packed);
             L.cnt += (mask != 0u) ? 1 : 0;
         }
-        if (UPD) {
+        if (kUpd) {
 #pragma unroll
             for (int p = M - 1; p >= 1; --p) L.tk[p] = __builtin_amdgcn_fmed3f(L.tk[p - 1], tmin, L.tk[p]);
             L.tk[0] = __builtin_fminf(L.tk[0], tmin);
@@ -1216,12 +1256,16 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter2_kernel(
     __shared__ F2Wave sh_all[kWavesPerGroup];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int col = lane & 31, hh = lane >> 5;
-    const int item = blockIdx.x * kWavesPerGroup + wv;
     const uint8_t *__restrict__ rec = a.rec;
     const int64_t *__restrict__ ptr = a.ptr;
     F2Wave &S = sh_all[wv];
 
     const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
+    // whole-sweep tiles: the workgroups of one XCD take one contiguous eighth of the tile list (see xcd_dealt_position);
+    // the split tail tiles that follow stay interleaved over the XCDs
+    const int full_groups = n_full / kWavesPerGroup;   // n_full is a multiple of the SIMD count
+    const int group = (int)blockIdx.x < full_groups ? xcd_swizzle((int)blockIdx.x, full_groups) : (int)blockIdx.x;
+    const int item = group * kWavesPerGroup + wv;
     int tile = item, sub = 0, nsub = 1;
     if (item >= n_full) {
         const int r = item - n_full;
@@ -1274,6 +1318,9 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter2_kernel(
     f2_sweep<M, true, true>(L, S, rec, rbase, t_def, t_hi, bq, lane, hh, valid);
     f2_sweep<M, false, true>(L, S, rec, rbase, t_lo, t_def, bq, lane, hh, valid);     // against the final tau
     f2_compact<M>(L, S, lane);
+#if defined(DMET_F2_ABL) && DMET_F2_ABL >= 1
+    return;
+#endif
 
     // ---- exact re-rank of the set bits (R1 chain, top-k by (d, j)), candidates fetched cooperatively ----------------
     const int64_t qrow_id = valid ? myq : ev_lo;
@@ -1286,86 +1333,117 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter2_kernel(
             qrow[4 * c] = v.x; qrow[4 * c + 1] = v.y; qrow[4 * c + 2] = v.z; qrow[4 * c + 3] = v.w;
         }
     }
-    float kd[KP];
-    int32_t kj[KP];
+    // sorted top-KP as 64-bit words (distance bits << 32 | j): distances are >= +0, so the unsigned order IS the (d, j)
+    // order of R2, one v_cmp_gt_u64 per slot and no branches.  Empty slots are (sentinel, 0): a candidate at exactly
+    // the sentinel distance (or NaN / inf: larger bit patterns) is never inserted, like the oracle's strict '>'.
+    unsigned long long kk[KP];
 #pragma unroll
-    for (int p = 0; p < KP; ++p) { kd[p] = kKnnSentinel; kj[p] = -1; }
+    for (int p = 0; p < KP; ++p) kk[p] = (unsigned long long)__float_as_uint(kKnnSentinel) << 32;
     const int nent = (valid && !L.overflow) ? L.cnt : 0;
     int slot = 0;
     unsigned cmask = 0u;
     int ctile = 0;
-    // next candidate of this lane (ascending tiles as appended, ascending rows inside a tile), -1 when exhausted
-    auto pop = [&]() -> int32_t {
+    // next candidate of this lane (tiles as appended, ascending rows inside a tile), -1 when exhausted
+    auto pop = [&]() __attribute__((always_inline)) -> int32_t {
         if (cmask == 0u && slot < nent) {
             const uint2 e = S.ent[slot][lane];
             cmask = e.x;
             ctile = (int)(e.y & kF2TileMask);
             ++slot;
         }
-        if (cmask == 0u) return -1;
-        const int r = __builtin_clz(cmask);
-        cmask &= ~(0x80000000u >> r);
-        const int32_t j = ev_lo + ctile * 32 + r;
-        return j < ev_hi ? j : -1;      // rows past the event's end have key = +inf and are never set; belt and braces
-    };
-    // rows are fetched half a row at a time (16 features = 64 bytes): load instruction h*4 + r brings half h of rows
-    // 16 r + (lane >> 2), 16 bytes per lane; the chain continues over the two halves in feature order
-    auto fetch = [&](int32_t j, float4 (&pv)[8]) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int32_t jr = __shfl(j, 16 * r + (lane >> 2), 64);
-                pv[4 * h + r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (jr >= 0) pv[4 * h + r] = reinterpret_cast<const float4 *>(a.x + (int64_t)jr * 32)[4 * h + (lane & 3)];
-            }
-    };
-    auto round = [&](const float4 (&pv)[8], int32_t j) {
-        float dc = 0.0f;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            wave_sync();
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                *reinterpret_cast<float4 *>(&S.rows[16 * r + (lane >> 2)][4 * (lane & 3)]) = pv[4 * h + r];
-            wave_sync();
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const float4 v = *reinterpret_cast<const float4 *>(&S.rows[lane][4 * c4]);
-                const int f0 = 16 * h + 4 * c4;
-                float df;
-                df = v.x - qrow[f0 + 0]; dc = __builtin_fmaf(df, df, dc);
-                df = v.y - qrow[f0 + 1]; dc = __builtin_fmaf(df, df, dc);
-                df = v.z - qrow[f0 + 2]; dc = __builtin_fmaf(df, df, dc);
-                df = v.w - qrow[f0 + 3]; dc = __builtin_fmaf(df, df, dc);
-            }
+        int32_t j = -1;
+        if (cmask != 0u) {
+            const int r = __builtin_clz(cmask);
+            cmask &= ~(0x80000000u >> r);
+            j = ev_lo + ctile * 32 + r;   // < ev_hi: rows past the event's end have key = +inf and are never set
         }
-        if (j >= 0) {
-            // sorted insert by (d, j) (R2)
-#pragma unroll
-            for (int p = KP - 1; p >= 1; --p) {
-                const bool gq = kd[p - 1] > dc || (kd[p - 1] == dc && kj[p - 1] > j);
-                const bool gp = kd[p] > dc || (kd[p] == dc && kj[p] > j);
-                const float dn = gq ? kd[p - 1] : (gp ? dc : kd[p]);
-                const int32_t jn = gq ? kj[p - 1] : (gp ? j : kj[p]);
-                kd[p] = dn; kj[p] = jn;
-            }
-            if (kd[0] > dc || (kd[0] == dc && kj[0] > j)) { kd[0] = dc; kj[0] = j; }
-        }
+        return j;
     };
-    {
-        float4 pa[8], pb[8];
-        int32_t ja = pop(), jb;
-        fetch(ja, pa);
-        while (__any(ja >= 0)) {
-            jb = pop();
-            fetch(jb, pb);
+    // rows are fetched half a row at a time (16 features = 64 bytes): load instruction 4 h + r brings half h of rows
+    // 16 r + (lane >> 2), 16 bytes per lane; exhausted lanes re-read the event's first row (no branches, result unused)
+    const float4 *x4 = reinterpret_cast<const float4 *>(a.x);
+    struct HalfRows { float4 v0, v1, v2, v3, v4, v5, v6, v7; };   // named members: stays in registers
+    auto fetch = [&](int32_t j) __attribute__((always_inline)) -> HalfRows {
+        const int32_t jc = j >= 0 ? j : ev_lo;
+        const int64_t o = 4 * 0 + (lane & 3);
+        const int64_t r0 = (int64_t)__shfl(jc, 0 + (lane >> 2), 64) * 8 + o;
+        const int64_t r1 = (int64_t)__shfl(jc, 16 + (lane >> 2), 64) * 8 + o;
+        const int64_t r2 = (int64_t)__shfl(jc, 32 + (lane >> 2), 64) * 8 + o;
+        const int64_t r3 = (int64_t)__shfl(jc, 48 + (lane >> 2), 64) * 8 + o;
+        HalfRows R;
+        R.v0 = x4[r0]; R.v1 = x4[r1]; R.v2 = x4[r2]; R.v3 = x4[r3];
+        R.v4 = x4[r0 + 4]; R.v5 = x4[r1 + 4]; R.v6 = x4[r2 + 4]; R.v7 = x4[r3 + 4];
+        return R;
+    };
+    auto chain16 = [&](float dc, int h) __attribute__((always_inline)) -> float {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const float4 v = *reinterpret_cast<const float4 *>(&S.rows[lane][4 * c4]);
+            const int f0 = 16 * h + 4 * c4;
+            float df;
+            df = v.x - qrow[f0 + 0]; dc = __builtin_fmaf(df, df, dc);
+            df = v.y - qrow[f0 + 1]; dc = __builtin_fmaf(df, df, dc);
+            df = v.z - qrow[f0 + 2]; dc = __builtin_fmaf(df, df, dc);
+            df = v.w - qrow[f0 + 3]; dc = __builtin_fmaf(df, df, dc);
+        }
+        return dc;
+    };
+    auto round = [&](const HalfRows &R, int32_t j) __attribute__((always_inline)) {
+        float4 *dst = reinterpret_cast<float4 *>(&S.rows[lane >> 2][4 * (lane & 3)]);   // + 16 r rows per register
+        constexpr int kStride = 16 * (kF2RowF + 4) / 4;                                    // float4s per 16 rows
+        wave_sync();
+        dst[0] = R.v0; dst[kStride] = R.v1; dst[2 * kStride] = R.v2; dst[3 * kStride] = R.v3;
+        wave_sync();
+        float dc = chain16(0.0f, 0);
+        wave_sync();
+        dst[0] = R.v4; dst[kStride] = R.v5; dst[2 * kStride] = R.v6; dst[3 * kStride] = R.v7;
+        wave_sync();
+        dc = chain16(dc, 1);
+        const unsigned long long nk =
+            j >= 0 ? (((unsigned long long)__float_as_uint(dc) << 32) | (unsigned)j) : ~0ull;
+        bool g[KP];
+#pragma unroll
+        for (int p = 0; p < KP; ++p) g[p] = kk[p] > nk;
+#pragma unroll
+        for (int p = KP - 1; p >= 1; --p) kk[p] = g[p - 1] ? kk[p - 1] : (g[p] ? nk : kk[p]);
+        kk[0] = g[0] ? nk : kk[0];
+    };
+    if constexpr (KP <= 16) {
+        // three rounds of rows in flight: the loop is bound by the gathers' latency
+        int32_t ja = pop(), jb, jc;
+        HalfRows pa = fetch(ja), pb, pc;
+        jb = pop();
+        pb = fetch(jb);
+        for (;;) {
+            if (!__any(ja >= 0)) break;
+            jc = pop(); pc = fetch(jc);
             round(pa, ja);
             if (!__any(jb >= 0)) break;
-            ja = pop();
-            fetch(ja, pa);
+            ja = pop(); pa = fetch(ja);
+            round(pb, jb);
+            if (!__any(jc >= 0)) break;
+            jb = pop(); pb = fetch(jb);
+            round(pc, jc);
+        }
+    } else {
+        // the 20-wide list leaves registers for two rounds in flight
+        int32_t ja = pop(), jb;
+        HalfRows pa = fetch(ja), pb;
+        for (;;) {
+            if (!__any(ja >= 0)) break;
+            jb = pop(); pb = fetch(jb);
+            round(pa, ja);
+            if (!__any(jb >= 0)) break;
+            ja = pop(); pa = fetch(ja);
             round(pb, jb);
         }
+    }
+    float kd[KP];
+    int32_t kj[KP];
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        kd[p] = __uint_as_float((unsigned)(kk[p] >> 32));
+        kj[p] = kd[p] == kKnnSentinel ? -1 : (int32_t)(unsigned)kk[p];
     }
     if (!valid) return;
     const int k = a.k;
