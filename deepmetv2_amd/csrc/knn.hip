@@ -211,9 +211,8 @@ __device__ __forceinline__ int xcd_dealt_position(int rank, int B)
 }
 
 // blockIdx.x selects one of up to two plans (exact kernel: 128-query tiles; matrix-core filter: 64-query tiles)
-__global__ __launch_bounds__(256) void knn_plan_kernel(const int64_t *__restrict__ ptr, int B, KnnPlanOut o0, KnnPlanOut o1)
+__device__ __forceinline__ void knn_plan_body(const int64_t *__restrict__ ptr, int B, const KnnPlanOut &o)
 {
-    const KnnPlanOut o = blockIdx.x == 0 ? o0 : o1;
     const int tile_queries = o.tile_queries, simds = o.simds, max_split = o.max_split;
     int32_t *__restrict__ order = o.order, *__restrict__ pos_of = o.pos_of, *__restrict__ tile_ptr = o.tile_ptr;
     KnnPlan *__restrict__ plan = o.plan;
@@ -271,6 +270,11 @@ __global__ __launch_bounds__(256) void knn_plan_kernel(const int64_t *__restrict
         tile_ptr[p] = run;
         run += (int)((ptr[b + 1] - ptr[b] + tile_queries - 1) / tile_queries);
     }
+}
+
+__global__ __launch_bounds__(256) void knn_plan_kernel(const int64_t *__restrict__ ptr, int B, KnnPlanOut o0, KnnPlanOut o1)
+{
+    knn_plan_body(ptr, B, blockIdx.x == 0 ? o0 : o1);
 }
 
 // Position (in the longest-first order) that owns tile t: the p with tile_ptr[p] <= t < tile_ptr[p+1].
@@ -628,7 +632,8 @@ __device__ __forceinline__ int64_t rec_base_tile(const int64_t *__restrict__ ptr
 __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__ x, const int64_t *__restrict__ ptr,
                                                         int B, int64_t N, float *__restrict__ nrm,
                                                         uint8_t *__restrict__ rec, int64_t nrec,
-                                                        uint32_t *__restrict__ zero, size_t zero_bytes)
+                                                        uint32_t *__restrict__ zero, size_t zero_bytes, KnnPlanOut o0,
+                                                        KnnPlanOut o1)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     {
@@ -636,6 +641,11 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__
         for (size_t wd = (size_t)t; wd < words; wd += total) zero[wd] = 0u;
         if (t == 0)
             for (size_t bt = words << 2; bt < zero_bytes; ++bt) reinterpret_cast<uint8_t *>(zero)[bt] = 0;
+    }
+    // the last two workgroups compute the two launch plans (one launch less on the critical path of the build)
+    if (blockIdx.x + 2 >= gridDim.x) {
+        knn_plan_body(ptr, B, blockIdx.x + 2 == gridDim.x ? o0 : o1);
+        return;
     }
     const int64_t tile = t >> 6;            // wave-uniform
     if (tile >= nrec) return;
@@ -1161,89 +1171,121 @@ __device__ __forceinline__ void f2_compact(F2Lane<M> &L, F2Wave &S, int lane)
     }
 }
 
-// One pass over the tiles [t_lo, t_hi) of the event whose first record is rbase.  UPD: the tile minima feed tk / tau;
-// REC: hit masks are recorded.
+// Operands of one candidate tile (A fragments + accumulator seed).
+struct F2Ops {
+    bf16x8 a[4];
+    f32x16 c;
+};
+
+// One tile of a sweep, software-pipelined inside the wavefront: the 12 MFMAs of tile t + 1 (operands `use`) are
+// issued between the vector instructions that select from tile t's keys (c0, c1, computed one call earlier), and the
+// operands of tile t + 2 are loaded into `ld`.  On gfx950 independent VALU work of the same wavefront hides under an
+// MFMA (tools/mfma_overlap_micro.hip: 12 v_add per 32x32x16 MFMA interleaved cost 62 cycles per slot against 85 when
+// the two run in phases), but only if it is in program order between the MFMAs: the scheduler is told to emit
+// 1 MFMA + 11 VALU groups.  UPD: the tile minima feed tk / tau;  REC: hit masks are recorded.
+template <int M, bool UPD, bool REC>
+__device__ __forceinline__ void f2_tile(F2Lane<M> &L, F2Wave &S, const uint8_t *__restrict__ rec, int64_t rbase, int t,
+                                        int t_hi, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1, const F2Ops &use,
+                                        F2Ops &ld, const bf16x8 (&bq)[2][4], int lane, int hh, bool alive)
+{
+#if defined(DMET_F2_ABL) && DMET_F2_ABL >= 2
+    constexpr bool kRec = false;     // cycle-budget experiment (tools/knn_budget2.sh)
+#else
+    constexpr bool kRec = REC;
+#endif
+#if defined(DMET_F2_ABL) && DMET_F2_ABL >= 3
+    constexpr bool kUpd = false;
+#else
+    constexpr bool kUpd = UPD;
+#endif
+    if (kRec) {
+        if (__any(L.cnt >= kF2Slots - 1)) f2_compact<M>(L, S, lane);
+    }
+#if defined(DMET_F2_SAMEREC)
+    filter_load(ld.a, ld.c, rec, rbase + (t & 1), lane, hh);   // experiment: operands always cache-resident
+#else
+    filter_load(ld.a, ld.c, rec, rbase + min(t + 2, t_hi - 1), lane, hh);   // clamped: the last two calls re-read the last tile
+#endif
+    n0 = filter_block(use.a, bq[0], use.c);
+    n1 = filter_block(use.a, bq[1], use.c);
+    // lanes 32..63 of block 0 <-> lanes 0..31 of block 1: afterwards c0 = rows {0-3, 8-11, ..} and c1 = rows
+    // {4-7, 12-15, ..} of THIS lane's query
+#if !(defined(DMET_F2_ABL) && DMET_F2_ABL >= 4)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c0[e]), __float_as_uint(c1[e]), false, false);
+        c0[e] = __uint_as_float(r[0]);
+        c1[e] = __uint_as_float(r[1]);
+    }
+#endif
+#if defined(DMET_F2_ABL) && DMET_F2_ABL >= 2
+#pragma unroll
+    for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(c0[e]), "v"(c1[e]));
+#endif
+    unsigned mask = 0u;
+    if (kRec) {
+        // candidate row r = 8 (r >> 3) + 4 a + (r & 3) sits in c{a}[(r & 3) + 4 (r >> 3)]; rows in ascending order, so
+        // row r ends up in bit 31 - r.  Two VALU ops per key: key - tau, then v_alignbit shifts its sign bit into the
+        // mask (a NaN key may set a bit: its exact distance is NaN and never enters the result).
+        unsigned mlo = 0u, mhi = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ra = r, rb = r + 16;
+            const float ka = ((ra >> 2) & 1) ? c1[(ra & 3) + 4 * (ra >> 3)] : c0[(ra & 3) + 4 * (ra >> 3)];
+            const float kb = ((rb >> 2) & 1) ? c1[(rb & 3) + 4 * (rb >> 3)] : c0[(rb & 3) + 4 * (rb >> 3)];
+            mhi = __builtin_amdgcn_alignbit(mhi, __float_as_uint(ka - L.tau), 31);
+            mlo = __builtin_amdgcn_alignbit(mlo, __float_as_uint(kb - L.tau), 31);
+        }
+        mask = (mhi << 16) | mlo;
+    }
+    float tmin = -__builtin_inff();   // deferred tiles: "never drop" (their tau is already final)
+    if (kUpd) {
+        tmin = kKnnSentinel;          // also keeps a NaN key out of the v_med3 chain
+        // v_min3_f32 by hand: fminf() makes hipcc canonicalise every MFMA output with a v_max first (twice the ops)
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(tmin) : "v"(c0[e]), "v"(c0[e + 1]));
+            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(tmin) : "v"(c1[e]), "v"(c1[e + 1]));
+        }
+    }
+    if (kRec) {
+        // one 8-byte entry per tile and lane, kept only when the mask is non-zero (branch-free append)
+        const unsigned packed = (__float_as_uint(tmin) & ~kF2TileMask) | (unsigned)t;
+        S.ent[L.cnt][lane] = make_uint2(mask, packed);
+        L.cnt += (mask != 0u) ? 1 : 0;
+    }
+    if (kUpd) {
+#pragma unroll
+        for (int p = M - 1; p >= 1; --p) L.tk[p] = __builtin_amdgcn_fmed3f(L.tk[p - 1], tmin, L.tk[p]);
+        L.tk[0] = __builtin_fminf(L.tk[0], tmin);
+        if (alive && !L.overflow) L.tau = L.tk[M - 1];
+    }
+#ifdef DMET_F2_SCHED
+    // experiment: force 1 MFMA + 11 VALU groups (measured 4 % SLOWER than hipcc's own order at two wavefronts per SIMD)
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, (kRec ? 11 : (kUpd ? 5 : 2)), 0);
+    }
+#endif
+}
+
+// One pass over the tiles [t_lo, t_hi) of the event whose first record is rbase.
 template <int M, bool UPD, bool REC>
 __device__ __forceinline__ void f2_sweep(F2Lane<M> &L, F2Wave &S, const uint8_t *__restrict__ rec, int64_t rbase,
                                          int t_lo, int t_hi, const bf16x8 (&bq)[2][4], int lane, int hh, bool alive)
 {
     if (t_lo >= t_hi) return;
-    bf16x8 av[4], an[4];
-    f32x16 ci, cn;
-    filter_load(av, ci, rec, rbase + t_lo, lane, hh);
-    for (int t = t_lo; t < t_hi; ++t) {
-        const bool more = t + 1 < t_hi;
-        if (more) filter_load(an, cn, rec, rbase + t + 1, lane, hh);
-        f32x16 acc0 = filter_block(av, bq[0], ci);
-        f32x16 acc1 = filter_block(av, bq[1], ci);
-        // lanes 32..63 of block 0 <-> lanes 0..31 of block 1: afterwards acc0 = rows {0-3, 8-11, ..} and
-        // acc1 = rows {4-7, 12-15, ..} of THIS lane's query
-#if !(defined(DMET_F2_ABL) && DMET_F2_ABL >= 4)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[e]), __float_as_uint(acc1[e]), false,
-                                                            false);
-            acc0[e] = __uint_as_float(r[0]);
-            acc1[e] = __uint_as_float(r[1]);
-        }
-#endif
-        unsigned mask = 0u;
-#if defined(DMET_F2_ABL) && DMET_F2_ABL >= 2
-        constexpr bool kRec = false;     // cycle-budget experiment (tools/knn_budget2.sh)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc0[e]), "v"(acc1[e]));
-#else
-        constexpr bool kRec = REC;
-#endif
-        if (kRec) {
-            if (__any(L.cnt >= kF2Slots - 1)) f2_compact<M>(L, S, lane);
-            // candidate row r = 8 (r >> 3) + 4 a + (r & 3) sits in acc{a}[(r & 3) + 4 (r >> 3)]; rows in ascending order,
-            // so row r ends up in bit 31 - r.  v_cmp + v_addc (mask = 2 mask + carry): two VALU ops per key.
-            // The compares write their own SGPR pairs (independent, issued ahead); two carry chains of 16 rows each.
-            unsigned mlo = 0u, mhi = 0u;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ra = r, rb = r + 16;
-                const float ka = ((ra >> 2) & 1) ? acc1[(ra & 3) + 4 * (ra >> 3)] : acc0[(ra & 3) + 4 * (ra >> 3)];
-                const float kb = ((rb >> 2) & 1) ? acc1[(rb & 3) + 4 * (rb >> 3)] : acc0[(rb & 3) + 4 * (rb >> 3)];
-                unsigned long long ca, cb;
-                asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(ca) : "v"(ka), "v"(L.tau));
-                asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(cb) : "v"(kb), "v"(L.tau));
-                asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(mhi) : "s"(ca) : "vcc");
-                asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(mlo) : "s"(cb) : "vcc");
-            }
-            mask = (mhi << 16) | mlo;
-        }
-        float tmin = -__builtin_inff();   // deferred tiles: "never drop" (their tau is already final)
-#if defined(DMET_F2_ABL) && DMET_F2_ABL >= 3
-        constexpr bool kUpd = false;
-#else
-        constexpr bool kUpd = UPD;
-#endif
-        if (kUpd) {
-            tmin = kKnnSentinel;          // also keeps a NaN key out of the v_med3 chain
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                tmin = __builtin_fminf(tmin, __builtin_fminf(acc0[e], acc0[e + 1]));
-                tmin = __builtin_fminf(tmin, __builtin_fminf(acc1[e], acc1[e + 1]));
-            }
-        }
-        if (kRec) {
-            // one 8-byte entry per tile and lane, kept only when the mask is non-zero (branch-free append)
-            const unsigned packed = (__float_as_uint(tmin) & ~kF2TileMask) | (unsigned)t;
-            S.ent[L.cnt][lane] = make_uint2(mask, packed);
-            L.cnt += (mask != 0u) ? 1 : 0;
-        }
-        if (kUpd) {
-#pragma unroll
-            for (int p = M - 1; p >= 1; --p) L.tk[p] = __builtin_amdgcn_fmed3f(L.tk[p - 1], tmin, L.tk[p]);
-            L.tk[0] = __builtin_fminf(L.tk[0], tmin);
-            if (alive && !L.overflow) L.tau = L.tk[M - 1];
-        }
-        if (more) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) av[m] = an[m];
-            ci = cn;
+    F2Ops A, B;
+    filter_load(A.a, A.c, rec, rbase + t_lo, lane, hh);
+    f32x16 c0 = filter_block(A.a, bq[0], A.c);      // prologue: the first tile's keys
+    f32x16 c1 = filter_block(A.a, bq[1], A.c);
+    f32x16 n0, n1;
+    filter_load(A.a, A.c, rec, rbase + min(t_lo + 1, t_hi - 1), lane, hh);
+    for (int t = t_lo; t < t_hi; t += 2) {
+        f2_tile<M, UPD, REC>(L, S, rec, rbase, t, t_hi, c0, c1, n0, n1, A, B, bq, lane, hh, alive);
+        if (t + 1 < t_hi) {
+            f2_tile<M, UPD, REC>(L, S, rec, rbase, t + 1, t_hi, n0, n1, c0, c1, B, A, bq, lane, hh, alive);
         }
     }
 }
@@ -1254,7 +1296,9 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter2_kernel(
     constexpr int M = filter_list_len(KP);
     constexpr int MS = (M + 1 + 3) & ~3;
     __shared__ F2Wave sh_all[kWavesPerGroup];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wavefront number is wave-uniform, but only readfirstlane tells the compiler: without it the tile, the event,
+    // the loop counters and every record address are computed per lane on the vector ALU
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int col = lane & 31, hh = lane >> 5;
     const uint8_t *__restrict__ rec = a.rec;
     const int64_t *__restrict__ ptr = a.ptr;
@@ -1516,39 +1560,47 @@ __global__ __launch_bounds__(256) void knn_filter2_merge_kernel(const KnnFilterA
     const float *pd = a.psd + fslot * split * MS;
     const int32_t *pj = a.psj + fslot * split * MS;
     const int k = a.k;
-    int head[kFilterMaxSplit];
+    // both sorted lists into registers with every load issued up front (a head-pointer merge is a chain of dependent
+    // global round trips), then rank-based merge: element i of one list lands at i + (elements of the other list that
+    // precede it in (d, j) order); (d, j) pairs are distinct, empty slots are (sentinel, -1) and sort last
+    static_assert(kFilterMaxSplit == 2, "two sub-sweeps");
+    float da[KP], db[KP];
+    int32_t ja[KP], jb[KP];
 #pragma unroll
-    for (int s = 0; s < kFilterMaxSplit; ++s) head[s] = 0;
-    float kth = -1.0f;
-    for (int p = 0; p < k; ++p) {
-        float bd = kKnnSentinel;
-        int32_t bj = -1;
-        int bs = -1;
-#pragma unroll
-        for (int s = 0; s < kFilterMaxSplit; ++s) {
-            if (s < split && head[s] < KP) {
-                const float d = pd[s * MS + head[s]];
-                const int32_t j = pj[s * MS + head[s]];
-                if (j >= 0 && (bs < 0 || d < bd || (d == bd && j < bj))) { bd = d; bj = j; bs = s; }
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < kFilterMaxSplit; ++s) head[s] += (s == bs) ? 1 : 0;
-        a.dist[q * k + p] = bd;
-        a.nbr[q * k + p] = bj;
-        if (a.nbr16) a.nbr16[q * k + p] = local_id16(bj, (int)ev_lo);
-        if (p == k - 1 && bj >= 0) kth = bd;
+    for (int p = 0; p < KP; ++p) {
+        da[p] = pd[p]; ja[p] = pj[p];
+        db[p] = pd[MS + p]; jb[p] = pj[MS + p];
     }
     const float nx = a.nrm[q];
+    const float tau0 = pd[M], tau1 = pd[MS + M];
+    const int32_t of0 = pj[M], of1 = pj[MS + M];
+    float kth = -1.0f;
+    for (int p = 0; p < k; ++p) { a.dist[q * k + p] = kKnnSentinel; a.nbr[q * k + p] = -1; if (a.nbr16) a.nbr16[q * k + p] = 0xFFFFu; }
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        int ra = i, rb = i;
+#pragma unroll
+        for (int o = 0; o < KP; ++o) {
+            ra += (jb[o] >= 0 && (db[o] < da[i] || (db[o] == da[i] && jb[o] < ja[i]))) ? 1 : 0;
+            rb += (ja[o] >= 0 && (da[o] < db[i] || (da[o] == db[i] && ja[o] < jb[i]))) ? 1 : 0;
+        }
+        if (ja[i] >= 0 && ra < k) {
+            a.dist[q * k + ra] = da[i]; a.nbr[q * k + ra] = ja[i];
+            if (a.nbr16) a.nbr16[q * k + ra] = local_id16(ja[i], (int)ev_lo);
+            if (ra == k - 1) kth = da[i];
+        }
+        if (jb[i] >= 0 && rb < k) {
+            a.dist[q * k + rb] = db[i]; a.nbr[q * k + rb] = jb[i];
+            if (a.nbr16) a.nbr16[q * k + rb] = local_id16(jb[i], (int)ev_lo);
+            if (rb == k - 1) kth = db[i];
+        }
+    }
     const float an = __builtin_sqrtf(nx) * 1.000001f;
     const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
     const float slack = 2.0f * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1e-30f;
-    bool fail = false;
-    for (int s = 0; s < split; ++s) {
-        const float tau = pd[s * MS + M];
-        const bool full = tau < kKnnSentinel;
-        if (pj[s * MS + M] != 0 || (full && !(tau + nx - slack > kth))) fail = true;
-    }
+    bool fail = of0 != 0 || of1 != 0;
+    if (tau0 < kKnnSentinel && !(tau0 + nx - slack > kth)) fail = true;
+    if (tau1 < kKnnSentinel && !(tau1 + nx - slack > kth)) fail = true;
     if (fail) {
         const int xt = a.xtile_ptr[pos] + (int)((q - ev_lo) / a.xtile_queries);
         a.qflag[q] = 1;
@@ -1882,11 +1934,12 @@ inline int filter_form2()
 
 // prep + filter (+ in-place re-rank) + re-rank of the split tail tiles, for result capacity KF >= k
 template <int KF>
-int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, hipStream_t st)
+int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, const KnnPlanOut &px, const KnnPlanOut &pf,
+                  hipStream_t st)
 {
     const int slots = simds * 2;   // two filter wavefronts per SIMD
-    hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((w.nrec * kWave + 255) / 256)), dim3(256), 0, st, f.x, f.ptr, f.B,
-                       f.N, w.nrm, w.rec, w.nrec, reinterpret_cast<uint32_t *>(w.flags), w.zero_bytes);
+    hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((w.nrec * kWave + 255) / 256 + 2)), dim3(256), 0, st, f.x, f.ptr,
+                       f.B, f.N, w.nrm, w.rec, w.nrec, reinterpret_cast<uint32_t *>(w.flags), w.zero_bytes, px, pf);
     DMET_LAUNCH_CHECK("knn_prep_kernel");
     const int64_t ftiles_max = (f.N + kFQ - 1) / kFQ + f.B;
     const int64_t fblocks = (ftiles_max + slots + kWavesPerGroup - 1) / kWavesPerGroup;
@@ -1922,8 +1975,10 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     const int slots = simds * 2;   // two filter wavefronts per SIMD
     const KnnPlanOut px{QT, simds, kMaxSplit, w.order, w.pos_of, w.tile_ptr, w.plan};
     const KnnPlanOut pf{kFQ, slots, kFilterMaxSplit, w.forder, w.fpos_of, w.ftile_ptr, w.fplan};
-    hipLaunchKernelGGL(knn_plan_kernel, dim3(use_filter ? 2 : 1), dim3(256), 0, st, ptr, B, px, pf);
-    DMET_LAUNCH_CHECK("knn_plan_kernel");
+    if (!use_filter) {   // the filter path computes both plans inside its prep launch
+        hipLaunchKernelGGL(knn_plan_kernel, dim3(1), dim3(256), 0, st, ptr, B, px, pf);
+        DMET_LAUNCH_CHECK("knn_plan_kernel");
+    }
     KnnArgs a{x, ptr, B, N, D, k, nbr, dist, nbr16, w.wsd, w.wsj, w.plan, w.order, w.tile_ptr, w.psd, w.psj, nullptr, 0};
     // uncertified-query counters: zero for every call, so dmet_knn_fallback_stats is meaningful on any path (the
     // matrix-core path clears them in its prep kernel)
@@ -1936,9 +1991,9 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
         KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.rec, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
                         w.psd, w.psj, nbr, dist, nbr16, w.flags, w.qflag, w.tile_ptr, QT, filter_form2()};
         int rc = 0;
-        if constexpr (KP == 8) rc = launch_filter<8>(f, w, simds, st);
-        else if constexpr (KP == 16) rc = launch_filter<16>(f, w, simds, st);
-        else if constexpr (KP == 32) rc = launch_filter<20>(f, w, simds, st);   // 16 < k <= 20 (checked above)
+        if constexpr (KP == 8) rc = launch_filter<8>(f, w, simds, px, pf, st);
+        else if constexpr (KP == 16) rc = launch_filter<16>(f, w, simds, px, pf, st);
+        else if constexpr (KP == 32) rc = launch_filter<20>(f, w, simds, px, pf, st);   // 16 < k <= 20 (checked above)
         if (rc) return rc;
         if (filter_mode() == 2) return 0;
         const int64_t xtiles_max = (N + QT - 1) / QT + B;
