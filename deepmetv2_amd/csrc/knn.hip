@@ -1797,7 +1797,8 @@ __global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a,
                 const int jj = ev_lo + j;
                 const bool after = d > last_d || (d == last_d && jj > last_j);
                 const bool better = d < bd || (d == bd && jj < bj);
-                if (after && better) { bd = d; bj = jj; }
+                // a candidate at d >= 1e10 is never a neighbour (upstream's initial best distance, dmet_oracle.c:62)
+                if (after && better && d < kKnnSentinel) { bd = d; bj = jj; }
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {

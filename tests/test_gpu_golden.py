@@ -92,7 +92,18 @@ def test_g4_reference_model_run(dev, golden_dir, mode):
     # graph first and fall back to the fixture's graph if (and only if) it differs in a handful of edges
     ref_ei = G["edge_index"].long()
     if ei.shape != ref_ei.shape or not torch.equal(ei.cpu(), ref_ei):
-        assert abs(ei.shape[1] - ref_ei.shape[1]) <= 4
+        # every edge present in only one of the two graphs must be borderline: |dR^2 - r^2| within a few ulp of the
+        # coordinates' rounding (phi from atan2), never a genuinely different neighbour
+        N = x.shape[0]
+        a = set((ei[0].cpu() * N + ei[1].cpu()).tolist())
+        b = set((ref_ei[0] * N + ref_ei[1]).tolist())
+        odd = sorted(a ^ b)
+        assert 0 < len(odd) <= 4, len(odd)
+        ep = etaphi.double().cpu()
+        for key in odd:
+            j, i = key // N, key % N
+            d2 = float(((ep[j] - ep[i]) ** 2).sum())
+            assert abs(d2 - 0.16) < 1e-5, (j, i, d2)
         ei = ref_ei.to(dev)
     w = model(*split_features(x), ei, batch)
     loss = loss_fn(w, x, y, batch)
