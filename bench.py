@@ -70,6 +70,19 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+def sample_sizes(args, n_ev: int):
+    """Event sizes of a bounded CPU sample of the benchmarked workload (same distribution: fixed --nodes, or the first
+    n_ev sizes of the seeded --ragged draw)."""
+    if args.ragged is None:
+        return [args.nodes] * n_ev
+    from deepmetv2_amd import synth
+    return synth.ragged_sizes(max(n_ev, 1), args.ragged[0], args.ragged[1], seed=1234)[:n_ev]
+
+
+def size_label(args, sizes):
+    return str(args.nodes) if args.ragged is None else f"U[{args.ragged[0]},{args.ragged[1]}] ({min(sizes)}..{max(sizes)})"
+
+
 def cpu_baseline(args, seed: int):
     """The same training step on the host cores through the CPU oracle (PyG-shaped, un-fused restatement of the
     reference's operators; kind 'port' -- PyG itself is not installable here), on a bounded sample of events."""
@@ -82,7 +95,8 @@ def cpu_baseline(args, seed: int):
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     n_ev = args.cpu_sample_events or max(2, min(16, cores))
-    x, y, batch, ptr = synth.make_events([args.nodes] * n_ev, seed=seed)
+    sizes = sample_sizes(args, n_ev)
+    x, y, batch, ptr = synth.make_events(sizes, seed=seed)
     torch.manual_seed(0)
     model = ref_model.RefNet(8, 3, graph="dynamic", k=args.k).train()
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
@@ -103,7 +117,7 @@ def cpu_baseline(args, seed: int):
         reps += 1
     dt = (time.perf_counter() - t0) / reps
     return {"value": n_ev / dt, "unit": "events/s", "cores": cores, "kind": "port",
-            "sample": f"{n_ev} events x {args.nodes} nodes, k={args.k}, 2 layers, {args.mode} step, {reps} reps "
+            "sample": f"{n_ev} events x {size_label(args, sizes)} nodes, k={args.k}, 2 layers, {args.mode} step, {reps} reps "
                       f"({dt:.2f} s/step); oracle/ref_model.py + C kNN (OpenMP over events) on {cores} threads"}
 
 
@@ -119,7 +133,8 @@ def parity_sample(args, model, dev, seed: int):
     from oracle import ref_model, ref_ops
 
     n_ev = 4
-    x, y, batch, ptr = synth.make_events([args.nodes] * n_ev, seed=seed)
+    sizes = sample_sizes(args, n_ev)
+    x, y, batch, ptr = synth.make_events(sizes, seed=seed)
     ref = ref_model.RefNet(8, 3, graph="dynamic", k=args.k)
     ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
     ref.train()
@@ -139,10 +154,138 @@ def parity_sample(args, model, dev, seed: int):
     model.train(was_training)
     d = met.double() - met_ref.double()
     scale = float((w_ref.double().abs() * x[:, :2].double().abs().sum(1)).sum() / n_ev)
-    return {"sample": f"{n_ev} events x {args.nodes} nodes, k={args.k}, full 2-layer forward, same weights",
+    return {"sample": f"{n_ev} events x {size_label(args, sizes)} nodes, k={args.k}, full 2-layer forward, same weights",
             "met_mse_vs_ref": float((d * d).sum(1).mean() / 2.0),
             "met_max_abs_diff": float(d.abs().max()), "met_sum_abs_wp_per_event": scale,
             "knn_index_mismatches": int((nbr.cpu() != nbr_ref).sum())}
+
+
+def workload_label(args, B, n, k) -> str:
+    which = "configs[1]"
+    if args.ragged is not None:
+        which = "configs[4] (ragged events)"
+    elif args.dtype == "bf16":
+        which = "configs[2] (bf16 edge-MLP on MFMA)"
+    nodes = f"{n}" if args.ragged is None else f"U[{args.ragged[0]},{args.ragged[1]}]"
+    if args.graph == "dynamic":
+        graph = "2 DynamicEdgeConv layers (kNN rebuilt per layer in the 32-d embedding)"
+    else:
+        graph = ("2 EdgeConv layers over one radius graph dR<0.4 in (eta,phi) rebuilt every step (the reference's active "
+                 "flow, train.py:48)" + (", table handed to the model" if args.graph == "static-table" else ""))
+        which = "reference's active flow at the " + which + " sizes"
+    return (f"BASELINE {which}: {B} events/GPU x {nodes} PF candidates x 11 features, k={k}, {graph}, "
+            f"{'fp32' if args.dtype == 'f32' else 'bf16 dense layer, fp32 elsewhere'}, {args.mode} step")
+
+
+def knn_floor(sizes):
+    """Stated bound for the matrix-core kNN build (D = 32): per 64-query x 32-candidate tile a wavefront issues 12
+    v_mfma_f32_32x32x16_bf16 (32 cycles of its SIMD's matrix pipe each) and ~130 vector instructions for the selection
+    (half-wave swap, hit mask, tile minimum, threshold list; 2 cycles each at two wavefronts per SIMD, issue-bound);
+    the first 32 tiles of a sweep are visited twice.  Floors at 1024 SIMDs x 2.4 GHz if either pipe were the only
+    limit; the two do not overlap across wavefronts of a SIMD on gfx950 (tools/mfma_overlap_micro.hip), so the sum is
+    the realistic floor of this design."""
+    tiles = 0
+    for nn_ in sizes:
+        ct = (nn_ + 31) // 32
+        tiles += ((nn_ + 63) // 64) * (ct + min(ct, 32))
+    clk, simds = 2.4e9, 1024
+    return {"tiles": tiles, "mfma_floor_us": round(tiles * 12 * 32 / simds / clk * 1e6, 1),
+            "valu_floor_us": round(tiles * 130 * 2 / simds / clk * 1e6, 1)}
+
+
+def gather_roofline(args, ksum, ev_overhead_ms, model, x, batch, ptr, sizes, static_graph, dev):
+    """`roofline` block of the north-star kernel (fused gather + max): algorithmic bytes / mean launch time inside the
+    timed region, the name of the kernel form that really ran, and two untimed legs that bracket the cache state --
+    the same launch standalone back to back (operands L2 / Infinity-Cache warm) and with 512 MB written between
+    launches (cold: everything comes from HBM).  Inside the training step the kernel sits in between: P and Q were
+    written by the launch just before, the ids and the rest are cold."""
+    import torch
+
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import _native
+    from deepmetv2_amd.model import split_features
+
+    gname = "edgeconv_fused" if "edgeconv_fused" in ksum else ("gather_max" if "gather_max" in ksum else None)
+    if gname is None:
+        return None
+    H, k, N = 32, args.k, x.shape[0]
+    ms = ksum[gname][1]
+    g = model.graphnet
+    conv = g.conv_continuous[0][0]
+    lin = conv.nn[0]
+    # algorithmic bytes per launch (SURVEY 8d / BASELINE.md 2): own row H*4 + neighbour ids + output row H*4
+    # [+ arg: one byte per channel when training].  ids: k*4 per node for the fixed-k kNN table (int32, the API's
+    # internal width; the LDS kernel reads a uint16 copy, not credited), cnt_i*4 for a counted radius table.
+    with torch.no_grad():
+        emb = g.embed(*split_features(x)).contiguous()
+        if args.graph == "dynamic":
+            table = dm.knn_table(emb, k, batch, loop=True)
+            id_bytes = float(N) * k * 4
+            id_note = f"{k} int32 ids per node"
+        else:
+            table = static_graph() if args.graph == "static-table" else None
+            if table is None:
+                phi = torch.atan2(x[:, 1], x[:, 0])
+                table = dm.radius_table(torch.stack([x[:, 3], phi], 1), r=0.4, batch=batch, loop=True, max_num_neighbors=255)
+            mean_cnt = float(table.cnt.double().mean())
+            id_bytes = float(table.cnt.double().sum()) * 4
+            id_note = f"counted radius table, mean {mean_cnt:.1f} int32 ids per node"
+    arg_bytes = H if args.mode == "train" else 0
+    alg_bytes = N * (H * 4 + H * 4 + arg_bytes) + id_bytes
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    roof = {"kernel": _native.last_gather_kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": int(alg_bytes), "algorithmic_bytes_note": f"per node {H * 4} (P row) + {H * 4} (out row)"
+            + (f" + {arg_bytes} (arg, uint8)" if arg_bytes else "") + f" + ids ({id_note})",
+            "avg_launch_us": round(ms * 1e3, 2), "event_bracket_overhead_us": round(ev_overhead_ms * 1e3, 2),
+            "launches": ksum[gname][0],
+            "cache_state": "inside the training step: P/Q written by the preceding launch (L2 / Infinity-Cache resident), "
+                           "ids and outputs cold; FETCH_SIZE counts Infinity-Cache hits, so `frac` is not a pure DRAM figure"}
+    # HBM-side traffic from PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, profiles/README.md)
+    # cannot be collected from inside this process: quoted from the committed summary of this round, if present
+    tpath = os.path.join(ROOT, "profiles", "r02_pmc_gather_max.json")
+    if args.dtype == "f32" and args.graph == "dynamic" and args.ragged is None and os.path.exists(tpath):
+        try:
+            roof["traffic"] = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            roof["traffic_source"] = "profiles/r02_pmc_gather_max.json (rocprofv3 PMC run of this bench command)"
+        except Exception:
+            pass
+    # untimed legs: the same kernel form standalone, warm and cold
+    if gname == "gather_max" and args.dtype == "f32" and not args.hip_graph:
+        try:
+            with torch.no_grad():
+                from deepmetv2_amd import conv as conv_mod
+                lds = conv_mod._lds_eligible(emb, lin.weight, table) if table.cnt is None else (table.max_nodes or 1 << 30) <= conv_mod._LDS_MAX_EVENT_NODES
+                P, Q = _native.node_linear_split(emb, lin.weight, lin.bias, sliced=lds)
+                want_arg = args.mode == "train"
+
+                def launch():
+                    return _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=want_arg, cnt=table.cnt, lds=lds,
+                                              nbr_local=table.nbr_local, sliced=lds)
+
+                def timed(flush):
+                    ts = []
+                    junk = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device=dev) if flush else None
+                    for _ in range(12):
+                        if flush:
+                            junk.fill_(1.0)
+                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a.record(); launch(); b.record()
+                        torch.cuda.synchronize(dev)
+                        ts.append(a.elapsed_time(b))
+                    ts.sort()
+                    return ts[len(ts) // 2]
+
+                launch(); torch.cuda.synchronize(dev)
+                warm_ms, cold_ms = timed(False), timed(True)
+                roof["standalone_warm"] = {"us": round(warm_ms * 1e3, 2), "frac": round(alg_bytes / (warm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                roof["cold_us"] = round(cold_ms * 1e3, 2)
+                roof["cold_frac"] = round(alg_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                roof["cold_note"] = "median of 12 launches, each after a 512 MB fill (L2 and Infinity Cache flushed); HIP events, bracket cost not removed"
+        except Exception as e:  # the legs are diagnostics: never lose the bench line over them
+            roof["cold_frac"] = None
+            roof["cold_note"] = f"not measured: {type(e).__name__}: {e}"
+    return roof
 
 
 def main():
@@ -159,7 +302,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU path in the product)"
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    if world > 1:
+    # one process per GPU.  Under torch.distributed.run the group is created for ANY world size, also 1, so that the
+    # N = 1 point of a scaling run executes the same RCCL calls (broadcast, all_reduce, barrier) as the N = 8 point
+    use_group = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_group:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -215,7 +361,7 @@ def main():
                 return dm.met_reduce(w, x, ptr=ptr)
 
     def barrier():
-        if world > 1:
+        if use_group:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -245,63 +391,32 @@ def main():
         _native.timer.enabled = False
         for name, v in _native.timer.summary().items():
             ksum.setdefault(name, v)
-    if world > 1:
+    if use_group:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
         events = B * world * args.steps
-        # roofline of the north-star kernel: fused gather + max (algorithmic bytes per node, SURVEY 8d / BASELINE.md:
-        # own P row H*4 + neighbour ids k*4 + output row H*4 [+ arg H*1 when training; the table says H*4, we
-        # store the winning slot in one byte])
-        H = 32
-        per_node = H * 4 + k * 4 + H * 4 + (H if args.mode == "train" else 0)   # same definition for both dtypes
-        alg_bytes = per_node * N
-        roof = None
-        # the kernel that actually ran: the fully fused one (gather + edge MLP + max, LDS-resident) when eligible,
-        # else the gather+max step of the split form; same algorithmic-byte definition (own row, ids, out[, arg])
-        gname = "edgeconv_fused" if "edgeconv_fused" in ksum else ("gather_max" if "gather_max" in ksum else None)
-        if gname is not None and args.graph == "dynamic":   # the byte count below assumes the fixed-k kNN table
-            ms = ksum[gname][1]
-            ach = alg_bytes / (ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", f"pmc_{gname}.json")
-            if args.dtype == "f32" and os.path.exists(tpath):   # the counters were collected for the fp32 kernel
-                try:
-                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            kname = {"edgeconv_fused": "edgeconv_fused_lds_kernel (gather + edge-MLP + max in one launch)",
-                     "gather_max": "gather_max_lds_kernel (gather + max; per-event Q slice resident in LDS)"
-                     if args.dtype == "f32" else "gather_max_bf16q_kernel (gather + max over the bf16 Q table)"}[gname]
-            roof = {"kernel": kname, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(ms * 1e3, 2),
-                    "event_bracket_overhead_us": round(ev_overhead_ms * 1e3, 2),
-                    "launches": ksum[gname][0]}
+        roof = gather_roofline(args, ksum, ev_overhead_ms, model, x, batch, ptr, sizes, static_graph if args.mode == "train" else None, dev)
         kernels = {}
         for name, (cnt, ms) in sorted(ksum.items()):
             kernels[name] = {"launches": cnt, "avg_us": round(ms * 1e3, 2)}
         if "knn" in ksum:
-            # the whole graph build (plan + bf16-split MFMA filter + exact re-rank + fallback kernels) per call.
-            # "effective" = what an all-pairs fp32 difference-form sweep would need (sub, mul, add per (query,
-            # candidate, feature), D = 32) divided by the time: comparable with the exact VALU kernel's 52 TFLOP/s
-            # and its measured ~78 TFLOP/s instruction-mix ceiling; the filter does not execute those flops.
+            # the whole graph build (prep + plans, matrix-core filter with in-place exact re-rank, tail merge, fallback
+            # kernels) per call, against the stated floor of its design
             pairs = float(sum(sz * sz for sz in sizes))
-            tf = 3.0 * pairs * 32 / (ksum["knn"][1] * 1e-3) / 1e12
+            fl = knn_floor(sizes)
             kernels["knn"].update({"path": os.environ.get("DMET_KNN_PATH", "mfma_filter+exact_rerank"),
-                                   "pairs_per_s": round(pairs / (ksum["knn"][1] * 1e-3), 1),
-                                   "effective_fp32_tflops": round(tf, 2),
-                                   "exact_valu_kernel_ceiling_tflops": 78.0})
+                                   "pairs_per_s": round(pairs / (ksum["knn"][1] * 1e-3), 1), **fl,
+                                   "frac_of_floor_sum": round((fl["mfma_floor_us"] + fl["valu_floor_us"]) / (ksum["knn"][1] * 1e3), 3)})
         out = {
             "metric": "events/sec (4.5k PF cands, k=16)", "value": round(events / elapsed, 1), "unit": "events/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {B} events/GPU x {n} PF candidates x 11 features, k={k}, "
-                                   f"2 DynamicEdgeConv layers (kNN rebuilt per layer in the 32-d embedding), {'fp32' if args.dtype == 'f32' else 'bf16 edge-MLP on MFMA (configs[2])'}, "
-                                   f"{args.mode} step", "events_per_gpu": B, "nodes_per_event": n if args.ragged is None else f"U[{args.ragged[0]},{args.ragged[1]}]", "k": k,
+            "config": {"workload": workload_label(args, B, n, k), "events_per_gpu": B,
+                       "nodes_per_event": n if args.ragged is None else f"U[{args.ragged[0]},{args.ragged[1]}]", "k": k,
                        "global_batch": B * world, "mode": args.mode, "graph": args.graph, "parallelism": f"dp{world}",
                        "hip_graph": bool(args.hip_graph)},
             "roofline": roof, "kernels": kernels,
@@ -311,7 +426,7 @@ def main():
             if args.graph == "dynamic" and args.dtype == "f32":
                 out["parity"] = parity_sample(args, model, dev, seed=4321)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_group:
         dist.destroy_process_group()
 
 

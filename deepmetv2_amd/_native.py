@@ -92,10 +92,18 @@ class KernelTimer:
 
 timer = KernelTimer()
 
+# which gather + max kernel the last gather_max* call launched (bench.py labels its roofline block with it)
+last_gather_kernel = None
+
 # gather+max kernel form: "auto" = LDS-resident when the caller says the events fit, else L2 gathers;
 # "lds" / "l2-only" force one form (experiments, tools/gather_micro.py)
 GATHER_MAX_FORM = os.environ.get("DMET_GATHER_MAX_FORM", "auto")
 RADIUS_FORM = os.environ.get("DMET_RADIUS", "windowed")   # "sweep": all pairs of an event (dmet_radius_f32)
+
+
+def _note_gather(name: str) -> None:
+    global last_gather_kernel
+    last_gather_kernel = name
 
 
 # ---- K1 ------------------------------------------------------------------------------------------------------
@@ -217,6 +225,8 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
         if ptr is None or k not in (8, 16, 32) or GATHER_MAX_FORM == "l2-only":
             raise ValueError("gather_max: slice-major tables are only read by the LDS-resident kernels")
         _t = timer.record('gather_max', dev)
+        _note_gather("gather_max_lds_kernel (per-event Q slice resident in LDS; slice-major P/Q, "
+                     + ("uint16 event-local ids)" if nbr_local is not None else "int32 ids)"))
         with torch.cuda.device(dev):
             _lib.check(L.dmet_gather_max_lds_sliced_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(),
                                                         nbr_local.data_ptr() if nbr_local is not None else None,
@@ -230,6 +240,8 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
         _t = timer.record('gather_max', dev)
         with torch.cuda.device(dev):
             if lds and ptr is not None and H % 8 == 0 and GATHER_MAX_FORM != "l2-only":
+                _note_gather("gather_max_lds_kernel, counted rows (radius table; Q slice resident in LDS"
+                             + (", slice-major P/Q)" if sliced else ")"))
                 _lib.check(L.dmet_gather_max_counted_lds_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), cnt.data_ptr(),
                                                              ptr.data_ptr(), ptr.numel() - 1, N, k, H,
                                                              1 if sliced else 0, out.data_ptr(),
@@ -238,6 +250,7 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
             elif sliced:
                 raise ValueError("gather_max: slice-major tables are only read by the LDS-resident kernels")
             else:
+                _note_gather("gather_max_kernel, counted rows (radius table; gathers from L2)")
                 _lib.check(L.dmet_gather_max_counted_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), cnt.data_ptr(), N, k,
                                                          H, out.data_ptr(), arg.data_ptr() if want_arg else None,
                                                          _stream(dev)), "dmet_gather_max_counted_f32")
@@ -250,12 +263,15 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
         if use_lds and nbr_local is not None and k in (8, 16, 32):
             if nbr_local.shape != nbr.shape or nbr_local.dtype != torch.int16 or not nbr_local.is_contiguous():
                 raise ValueError("nbr_local must be the contiguous int16 [N, k] table of knn_local()")
+            _note_gather("gather_max_lds_kernel (per-event Q slice resident in LDS; row-major P/Q, uint16 ids)")
             _lib.check(L.dmet_gather_max_lds16_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), nbr_local.data_ptr(),
                                                    ptr.data_ptr(), ptr.numel() - 1, N, k, H, out.data_ptr(),
                                                    arg.data_ptr() if want_arg else None, _stream(dev)),
                        "dmet_gather_max_lds16_f32")
         else:
             fn = L.dmet_gather_max_lds_f32 if use_lds else L.dmet_gather_max_f32
+            _note_gather("gather_max_lds_kernel (per-event Q slice resident in LDS; row-major P/Q, int32 ids)" if use_lds
+                         else "gather_max_mlp_kernel (row gathers from L2; events too large for the LDS image)")
             _lib.check(fn(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), ptr.data_ptr() if ptr is not None else None,
                           (ptr.numel() - 1) if ptr is not None else 0, N, k, H, out.data_ptr(),
                           arg.data_ptr() if want_arg else None, _stream(dev)), "dmet_gather_max_f32")
@@ -277,6 +293,7 @@ def edgeconv_fused_lds(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tenso
     arg = torch.empty((N, Hout), dtype=torch.uint8, device=dev) if want_arg else None
     bp = _f32c(b, "b").data_ptr() if b is not None else None
     _t = timer.record('edgeconv_fused', dev)
+    _note_gather("edgeconv_fused_lds_kernel (gather + edge-MLP + max in one launch)")
     with torch.cuda.device(dev):
         _lib.check(L.dmet_edgeconv_fused_lds_f32(x.data_ptr(), nbr.data_ptr(), ptr.data_ptr(), ptr.numel() - 1, N, k,
                                                  Hin, Hout, W.data_ptr(), bp, out.data_ptr(),
@@ -314,6 +331,7 @@ def gather_max_bf16q(P: torch.Tensor, Qh: torch.Tensor, nbr: torch.Tensor, want_
     out = torch.empty((N, H), dtype=torch.float32, device=dev)
     arg = torch.empty((N, H), dtype=torch.uint8, device=dev) if want_arg else None
     _t = timer.record('gather_max', dev)
+    _note_gather("gather_max_bf16q_kernel (gather + max over the bf16 Q table, gathers from L2)")
     with torch.cuda.device(dev):
         _lib.check(L.dmet_gather_max_bf16q(P.data_ptr(), Qh.data_ptr(), nbr.data_ptr(), N, k, H, out.data_ptr(),
                                            arg.data_ptr() if want_arg else None, _stream(dev)), "dmet_gather_max_bf16q")

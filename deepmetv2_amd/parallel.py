@@ -91,10 +91,13 @@ class GradSync:
     def __init__(self, flat: FlatModule, group: Optional[dist.ProcessGroup] = None):
         self.flat = flat
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # a process group of ONE rank still runs its collectives (so that `torchrun --nproc-per-node 1` exercises the
+        # same RCCL calls as N ranks do); without any group the step has no collective at all
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
 
     def broadcast_state(self, src: int = 0) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         dist.broadcast(self.flat.flat_param.data, src=src, group=self.group)
         for b in self.flat.buffers():
@@ -102,11 +105,12 @@ class GradSync:
 
     def average_gradients(self) -> None:
         """Loss is a mean over the rank's events; with equal events per rank the mean of rank-gradients is the
-        gradient of the global mean (model/net.py:60)."""
-        if self.world == 1:
+        gradient of the global mean (model/net.py:60).  One all-reduce of the flat fp32 gradient (26.6 KB)."""
+        if not self.active:
             return
         dist.all_reduce(self.flat.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.flat_grad.div_(self.world)
+        if self.world > 1:
+            self.flat.flat_grad.div_(self.world)
 
 
 def train_step(model: torch.nn.Module, flat: FlatModule, sync: GradSync, optimizer: torch.optim.Optimizer,
