@@ -208,12 +208,33 @@ def node_linear_split(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor
 
 def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optional[torch.Tensor],
                want_arg: bool, cnt: Optional[torch.Tensor] = None, lds: bool = False,
-               nbr_local: Optional[torch.Tensor] = None, sliced: bool = False
+               nbr_local: Optional[torch.Tensor] = None, sliced: bool = False, mixed: bool = False
                ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """out = P + max over the rows of Q listed in nbr (+ uint8 arg).  lds=True: the caller knows every event fits
-    the LDS image (<= 5119 nodes, k in {8,16,32}, H % 8 == 0) -> LDS-resident kernel; else gathers come from L2."""
+    the LDS image (<= 5119 nodes, k in {8,16,32}, H % 8 == 0) -> LDS-resident kernel; mixed=True: some events do not,
+    the form is chosen per event inside the call (row-major P / Q); else gathers come from L2."""
     dev = _require_device(P, Q, nbr)
     L = _lib.load()
+    if mixed and cnt is None and not sliced and ptr is not None and GATHER_MAX_FORM == "auto":
+        N, H = P.shape
+        k = nbr.shape[1]
+        out = torch.empty((N, H), dtype=torch.float32, device=dev)
+        arg = torch.empty((N, H), dtype=torch.uint8, device=dev) if want_arg else None
+        if nbr_local is not None and (nbr_local.shape != nbr.shape or nbr_local.dtype != torch.int16
+                                      or not nbr_local.is_contiguous()):
+            raise ValueError("nbr_local must be the contiguous int16 [N, k] table of knn_local()")
+        _t = timer.record('gather_max', dev)
+        _note_gather("gather_max_lds_kernel (events <= 5119 nodes: Q slice resident in LDS) + gather_max_mlp_kernel "
+                     "(larger events: row gathers from L2), chosen per event in one call; row-major P/Q")
+        with torch.cuda.device(dev):
+            _lib.check(L.dmet_gather_max_mixed_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(),
+                                                   nbr_local.data_ptr() if nbr_local is not None else None,
+                                                   ptr.data_ptr(), ptr.numel() - 1, N, k, H, out.data_ptr(),
+                                                   arg.data_ptr() if want_arg else None, _stream(dev)),
+                       "dmet_gather_max_mixed_f32")
+        if _t is not None:
+            _t.record(torch.cuda.current_stream(dev))
+        return out, arg
     if sliced:      # [H/8, N, 8] tables of node_linear_split(..., sliced=True)
         N, H = P.shape[1], P.shape[0] * 8
     else:

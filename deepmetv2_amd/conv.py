@@ -55,16 +55,15 @@ def _as_fusable_linear(nn_module) -> Optional[torch.nn.Linear]:
 # the one BASELINE.md's roofline definition describes.
 GATHER_BWD_FORM = os.environ.get("DMET_GATHER_BWD", "lds")   # "reverse": radix-sorted reverse index route
 EDGECONV_FORM = os.environ.get("DMET_EDGECONV_FORM", "split")
-# 160 KB LDS / 32 B per node, minus the -inf row.  Batch-level decision: the LDS kernels do handle larger events (from
-# global memory), but a batch that has them is faster through the L2-form kernel as a whole (measured on the ragged
-# 500-8000 configuration: 35 us against 213 us), so the override is for experiments only.
+# 160 KB LDS / 32 B per node, minus the -inf row: events up to this size gather from the LDS image.  A batch that also
+# holds larger events gathers from L2 as a whole (faster than the per-event mix, see _EdgeConvLinearMax.forward).
 _LDS_MAX_EVENT_NODES = int(os.environ.get("DMET_LDS_MAX_NODES", "5119"))
 
 
-def _lds_eligible(x, weight, table: NeighborTable) -> bool:
+def _lds_eligible(x, weight, table: NeighborTable, any_size: bool = False) -> bool:
     return (x.shape[1] == 32 and weight.shape[0] == 32 and table.k in (8, 16, 32)
-            and table.ptr is not None and table.max_nodes is not None and table.max_nodes <= _LDS_MAX_EVENT_NODES
-            and table.nbr.data_ptr() % 16 == 0)
+            and table.ptr is not None and table.max_nodes is not None
+            and (any_size or table.max_nodes <= _LDS_MAX_EVENT_NODES) and table.nbr.data_ptr() % 16 == 0)
 
 
 class _EdgeConvLinearMax(torch.autograd.Function):
@@ -91,11 +90,17 @@ class _EdgeConvLinearMax(torch.autograd.Function):
             out, arg = _native.edgeconv_fused_lds(x, weight, bias, table.nbr, table.ptr, want_arg=need_grad)
         else:
             lds = _lds_eligible(x, weight, table)
+            # ragged batch with SOME events beyond the LDS image: dmet_gather_max_mixed_f32 chooses the form per event
+            # inside one call.  Opt-in (DMET_GATHER_MIXED=1): measured on 64 events of 500..8000 nodes
+            # (tools/gather_sweep.py) it takes 70-75 us against 35-46 us for L2 gathers on the whole batch -- the LDS
+            # kernel runs one (event, slice) workgroup per CU, so ragged sizes leave CUs idle behind the largest event
+            mixed = (not lds and _lds_eligible(x, weight, table, any_size=True) and table.max_nodes is not None
+                     and os.environ.get("DMET_GATHER_MIXED", "0") == "1")
             # the LDS-resident gather reads P / Q slice by slice: have the dense layer write them slice-major
             sliced = lds and _native.GATHER_MAX_FORM != "l2-only" and os.environ.get("DMET_PQ_SLICED", "1") != "0"
             P, Q = _native.node_linear_split(x, weight, bias, sliced=sliced)
             out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad, lds=lds,
-                                          nbr_local=table.nbr_local, sliced=sliced)
+                                          nbr_local=table.nbr_local, sliced=sliced, mixed=mixed)
         if need_grad:
             ctx.save_for_backward(x, weight, arg)
             ctx.table = table

@@ -333,11 +333,15 @@ __global__ __launch_bounds__(256) void gather_max_kernel(const float *__restrict
 // Deep-MLP variant for k == 4*K4 (the kNN tables: k = 8/16/32): the kernel above is latency bound (ids -> 4 gathers
 // -> compare, 4 rows in flight per lane); here a lane loads all of its node's ids as int4 and has up to 16 row
 // gathers in flight before the compare chain starts.  Same results (same compare order).
-template <int H, bool WITH_ARG, int K4>
+// ONLY_BIG (dmet_gather_max_mixed_f32): only the nodes of events too large for the LDS image are computed here -- the
+// LDS-resident kernel takes the others in the same call (per-event, not per-batch, eligibility on ragged batches).
+template <int H, bool WITH_ARG, int K4, bool ONLY_BIG = false>
 __global__ __launch_bounds__(256) void gather_max_mlp_kernel(const float *__restrict__ P,
                                                               const float *__restrict__ Q,
                                                               const int32_t *__restrict__ nbr, int64_t N,
-                                                              float *__restrict__ out, uint8_t *__restrict__ arg)
+                                                              float *__restrict__ out, uint8_t *__restrict__ arg,
+                                                              const int64_t *__restrict__ ptr = nullptr, int B = 0,
+                                                              int lds_rows = 0)
 {
     constexpr int LPN = H / 4;               // lanes per node
     constexpr int NPB = 256 / LPN;           // nodes per block
@@ -346,6 +350,14 @@ __global__ __launch_bounds__(256) void gather_max_mlp_kernel(const float *__rest
     const int64_t node = (int64_t)bid * NPB + threadIdx.x / LPN;
     const int c4 = threadIdx.x % LPN;
     if (node >= N) return;
+    if (ONLY_BIG) {
+        // a block covers NPB consecutive nodes: almost always one event (block-uniform answer from its first / last node)
+        const int64_t first = (int64_t)bid * NPB, last = min(N, first + NPB) - 1;
+        const int eb0 = find_event(ptr, B, first), eb1 = find_event(ptr, B, last);
+        int eb = eb0;
+        if (eb0 != eb1) eb = find_event(ptr, B, node);
+        if (ptr[eb + 1] - ptr[eb] + 1 <= lds_rows) return;
+    }
     const int4 *row4 = reinterpret_cast<const int4 *>(nbr + node * (4 * K4));
     const float4 *Q4 = reinterpret_cast<const float4 *>(Q);
     int4 idv[K4];
@@ -466,7 +478,7 @@ template <bool WITH_ARG, int K4, int GML_MODE = 0, bool IDS16 = false, bool SLIC
 __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ nbr,
     const uint16_t *__restrict__ nbr16, const int64_t *__restrict__ ptr, int B, int k, int H,
-    float *__restrict__ out, uint8_t *__restrict__ arg, int64_t N)
+    float *__restrict__ out, uint8_t *__restrict__ arg, int64_t N, int skip_big)
 {
     static_assert(!IDS16 || K4 % 2 == 0, "uint16 tables: k must be a multiple of 8");
     __shared__ __attribute__((aligned(16))) float4 qs[kLdsGatherRows * 2];   // [n_b + 1][2] float4 = 8 channels/node
@@ -491,6 +503,7 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     auto pq_at = [&](const int64_t i) -> int64_t { return SLICED ? ((int64_t)sl * N + i) * 2 + half : i * h4 + col4; };
 
     if (n + 1 > kLdsGatherRows) {
+        if (skip_big) return;   // dmet_gather_max_mixed_f32: the L2-form kernel of the same call takes this event
         // event too large for the LDS image: same arithmetic, rows gathered from global memory (L2)
         for (int r = r0; r < n; r += RPI) {
             const int64_t node = lo + r;
@@ -1260,7 +1273,7 @@ extern "C" int dmet_gather_max_bf16q(const float *P, const uint16_t *Qh, const i
 
 static int gather_max_lds_impl(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr16,
                                const int64_t *ptr, int B, int64_t N, int k, int H, float *out, uint8_t *arg,
-                               bool sliced, dmet_stream_t stream)
+                               bool sliced, dmet_stream_t stream, int skip_big = 0)
 {
     DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_gather_max_lds_f32: N out of range");
     DMET_REQUIRE(k >= 1 && k <= 255, "dmet_gather_max_lds_f32: k=%d not in [1,255]", k);
@@ -1278,10 +1291,10 @@ static int gather_max_lds_impl(const float *P, const float *Q, const int32_t *nb
     do {                                                                                                          \
         if (sliced)                                                                                               \
             hipLaunchKernelGGL((gather_max_lds_kernel<ARG_, K4_, 0, I16_, true>), dim3((unsigned)blocks),         \
-                               dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N);      \
+                               dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N, skip_big);      \
         else                                                                                                      \
             hipLaunchKernelGGL((gather_max_lds_kernel<ARG_, K4_, 0, I16_, false>), dim3((unsigned)blocks),        \
-                               dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N);      \
+                               dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N, skip_big);      \
     } while (0)
 #define DMET_GML(K4_)                                                                                          \
     do {                                                                                                       \
@@ -1293,8 +1306,8 @@ static int gather_max_lds_impl(const float *P, const float *Q, const int32_t *nb
     // slice, =2 the LDS gather + compare chain (results are then meaningless)
     if (const char *e = (arg && nbr16 && k == 16) ? getenv("DMET_GML_MODE") : nullptr) {
         const int m = atoi(e);
-        if (m == 1) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 1, true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N);
-        else if (m == 2) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 2, true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N);
+        if (m == 1) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 1, true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N, skip_big);
+        else if (m == 2) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 2, true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N, skip_big);
         else DMET_GML(4);
         DMET_LAUNCH_CHECK("gather_max_lds_kernel");
         return 0;
@@ -1324,6 +1337,36 @@ extern "C" int dmet_gather_max_lds16_f32(const float *P, const float *Q, const i
                                          uint8_t *arg, dmet_stream_t stream)
 {
     return gather_max_lds_impl(P, Q, nbr, nbr_local, ptr, B, N, k, H, out, arg, false, stream);
+}
+
+extern "C" int dmet_gather_max_mixed_f32(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr_local,
+                                         const int64_t *ptr, int B, int64_t N, int k, int H, float *out,
+                                         uint8_t *arg, dmet_stream_t stream)
+{
+    // per-EVENT choice of the gather form on ragged batches: events whose Q slice fits the LDS image go through the
+    // LDS-resident kernel, the others through the L2-form kernel; both read the row-major tables, each skips the
+    // other's events
+    if (!(H == 32 && (k == 8 || k == 16 || k == 32)) || N == 0 || B == 0)
+        return dmet_gather_max_f32(P, Q, nbr, ptr, B, N, k, H, out, arg, stream);
+    const int rc = gather_max_lds_impl(P, Q, nbr, nbr_local, ptr, B, N, k, H, out, arg, false, stream, 1);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    const int64_t blocks = (N + 31) / 32;
+#define DMET_GMM_BIG(K4_)                                                                                            \
+    do {                                                                                                             \
+        if (arg)                                                                                                     \
+            hipLaunchKernelGGL((gather_max_mlp_kernel<32, true, K4_, true>), dim3((unsigned)blocks), dim3(256), 0,   \
+                               st, P, Q, nbr, N, out, arg, ptr, B, kLdsGatherRows);                                  \
+        else                                                                                                         \
+            hipLaunchKernelGGL((gather_max_mlp_kernel<32, false, K4_, true>), dim3((unsigned)blocks), dim3(256), 0,  \
+                               st, P, Q, nbr, N, out, arg, ptr, B, kLdsGatherRows);                                  \
+    } while (0)
+    if (k == 8) DMET_GMM_BIG(2);
+    else if (k == 16) DMET_GMM_BIG(4);
+    else DMET_GMM_BIG(8);
+#undef DMET_GMM_BIG
+    DMET_LAUNCH_CHECK("gather_max_mlp_kernel (large events)");
+    return 0;
 }
 
 extern "C" int dmet_gather_max_lds_sliced_f32(const float *P, const float *Q, const int32_t *nbr,

@@ -148,6 +148,15 @@ int dmet_gather_max_counted_lds_f32(const float *P, const float *Q, const int32_
 int dmet_gather_max_lds16_f32(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr_local,
                               const int64_t *ptr, int B, int64_t N, int k, int H, float *out, uint8_t *arg,
                               dmet_stream_t stream);
+/* Ragged batches (BASELINE configs[4]: events of 500..8000 nodes): the gather form is chosen PER EVENT inside one call.
+ * Events whose Q slice fits the LDS image (<= 5119 nodes) take the LDS-resident kernel, larger ones the L2-form kernel
+ * (8 lanes per node, 16 row gathers in flight); both read the row-major P / Q tables and each skips the other's
+ * events.  nbr_local may be NULL.  H = 32 and k in {8,16,32}; anything else is dmet_gather_max_f32.  Results are
+ * identical to dmet_gather_max_f32.  Replaces the same reference lines as dmet_gather_max_f32
+ * (model/graph_met_network.py:63,65 through torch_geometric.nn.EdgeConv / torch_scatter.scatter(max)). */
+int dmet_gather_max_mixed_f32(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr_local,
+                              const int64_t *ptr, int B, int64_t N, int k, int H, float *out, uint8_t *arg,
+                              dmet_stream_t stream);
 /* bf16 variant (BASELINE configs[2]): x and the split weights rounded to bf16 (RNE), multiplied on the bf16 matrix
  * cores with fp32 accumulation; P stays fp32, Q is stored as bf16 (raw bits) and gathered as 64-B rows.
  * Built for Hin = Hout = 32, k in {8,16,32}.  Backward is shared with the fp32 path (arg-based, fp32). */
