@@ -325,6 +325,35 @@ def edgeconv_fused_lds(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tenso
     return out, arg
 
 
+def edge_mlp2_supported(Hin: int, H1: int, H2: int, k: int) -> bool:
+    return bool(_lib.load().dmet_edge_mlp2_supported(int(Hin), int(H1), int(H2), int(k)))
+
+
+def edge_mlp2_bf16(x: torch.Tensor, nbr: torch.Tensor, W1: torch.Tensor, b1: Optional[torch.Tensor], W2: torch.Tensor,
+                   b2: Optional[torch.Tensor], act2: bool, add: bool) -> torch.Tensor:
+    """out[N,H2] = aggr_s nn([x_i || x_j - x_i]) for nn = Linear - ELU - Linear [- ELU] on the bf16 matrix cores,
+    fused with the max / add aggregation over the fixed-width table (include/dmet.h: dmet_edge_mlp2_bf16)."""
+    dev = _require_device(x, nbr, W1, W2, b1, b2)
+    L = _lib.load()
+    x = _f32c(x, "x"); W1 = _f32c(W1, "W1"); W2 = _f32c(W2, "W2")
+    N, Hin = x.shape
+    H1, H2, k = W1.shape[0], W2.shape[0], nbr.shape[1]
+    if W1.shape[1] != 2 * Hin or W2.shape[1] != H1:
+        raise ValueError(f"edge_mlp2: W1 must be [H1, {2 * Hin}] and W2 [H2, H1], got {tuple(W1.shape)}, {tuple(W2.shape)}")
+    if nbr.dtype != torch.int32 or not nbr.is_contiguous():
+        raise TypeError("edge_mlp2: nbr must be a contiguous int32 [N, k] table")
+    out = torch.empty((N, H2), dtype=torch.float32, device=dev)
+    _t = timer.record('edge_mlp2', dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_edge_mlp2_bf16(x.data_ptr(), N, Hin, nbr.data_ptr(), k, W1.data_ptr(),
+                                         _f32c(b1, "b1").data_ptr() if b1 is not None else None, H1, W2.data_ptr(),
+                                         _f32c(b2, "b2").data_ptr() if b2 is not None else None, H2, 1 if act2 else 0,
+                                         1 if add else 0, out.data_ptr(), _stream(dev)), "dmet_edge_mlp2_bf16")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
+    return out
+
+
 def node_linear_split_bf16(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
     """bf16-MFMA variant: P fp32 [N,H], Q as bf16 [N,H] (gathered table)."""
     dev = _require_device(x, W, b)

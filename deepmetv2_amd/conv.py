@@ -147,6 +147,51 @@ class _EdgeConvLinearMax(torch.autograd.Function):
         return gx, gW, gb, None, None, None
 
 
+def _as_mlp2(nn_module):
+    """(lin1, lin2, act2) when `nn` is Sequential(Linear, ELU, Linear[, ELU]) (ELU alpha = 1): the edge MLP of
+    model/dynamic_reduction_network.py:59-63 without its trailing BatchNorm; else None."""
+    if not isinstance(nn_module, torch.nn.Sequential) or len(nn_module) not in (3, 4):
+        return None
+    l1, a1, l2 = nn_module[0], nn_module[1], nn_module[2]
+    if not (isinstance(l1, torch.nn.Linear) and isinstance(l2, torch.nn.Linear) and isinstance(a1, torch.nn.ELU)):
+        return None
+    if a1.alpha != 1.0 or l1.weight.dtype != torch.float32 or l2.in_features != l1.out_features:
+        return None
+    act2 = False
+    if len(nn_module) == 4:
+        if not isinstance(nn_module[3], torch.nn.ELU) or nn_module[3].alpha != 1.0:
+            return None
+        act2 = True
+    return l1, l2, act2
+
+
+class _EdgeMLP2Bf16(torch.autograd.Function):
+    """aggr_s nn([x_i || x_j - x_i]) for a two-layer nn on the bf16 matrix cores (csrc/edgemlp.hip).  The backward
+    recomputes the message passing through the fp32 operators (edge features -> nn -> segment max / sum) and
+    differentiates that: straight-through over the bf16 roundings, no per-edge tensor kept between the passes."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, table, act2, add, recompute):
+        out = _native.edge_mlp2_bf16(x, table.nbr, W1, b1, W2, b2, act2, add)
+        ctx.save_for_backward(x, W1, b1, W2, b2)
+        ctx.recompute = recompute
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, W1, b1, W2, b2 = ctx.saved_tensors
+        with torch.enable_grad():
+            xx = x.detach().requires_grad_(True)
+            out = ctx.recompute(xx)
+        wanted = [(0, xx), (1, W1), (2, b1), (3, W2), (4, b2)]
+        wanted = [(i, t) for i, t in wanted if t is not None and ctx.needs_input_grad[i]]
+        grads = torch.autograd.grad(out, [t for _, t in wanted], g_out.contiguous(), allow_unused=True)
+        res = [None] * 9
+        for (i, _), g in zip(wanted, grads):
+            res[i] = g
+        return tuple(res)
+
+
 class _EdgeFeatures(torch.autograd.Function):
     """feat[e] = [x[tgt] || x[src] - x[tgt]] for a by-target grouped edge list."""
 
@@ -205,8 +250,24 @@ class EdgeConv(torch.nn.Module):
         lin = _as_fusable_linear(self.nn) if self.aggr == "max" else None
         if lin is not None and x.shape[1] * 2 == lin.in_features and table.k <= 255:  # arg slot is uint8
             return _EdgeConvLinearMax.apply(x, lin.weight, lin.bias, table, self._use_bf16(lin, table), passthrough)
+        mlp = _as_mlp2(self.nn) if self.aggr in ("max", "add", "sum") else None
+        if (mlp is not None and table.cnt is None and self._wants_bf16()
+                and mlp[0].in_features == 2 * x.shape[1]
+                and _native.edge_mlp2_supported(x.shape[1], mlp[0].out_features, mlp[1].out_features, table.k)):
+            # generic two-layer nn, bf16 compute requested: both dense layers on the matrix cores, fused with the
+            # aggregation (no [E, 2H] tensor); the fp32 route below stays the default and the backward's reference
+            l1, l2, act2 = mlp
+            out = _EdgeMLP2Bf16.apply(x, l1.weight, l1.bias, l2.weight, l2.bias, table, act2, self.aggr != "max",
+                                      lambda xx: self._forward_edges(xx, table.edge_list()))
+            return (out, x) if passthrough else out
         out = self._forward_edges(x, table.edge_list())
         return (out, x) if passthrough else out
+
+    def _wants_bf16(self) -> bool:
+        dt = self.compute_dtype
+        if dt is None and torch.is_autocast_enabled():
+            dt = torch.get_autocast_gpu_dtype()
+        return dt == torch.bfloat16
 
     def _use_bf16(self, lin: torch.nn.Linear, table: NeighborTable) -> bool:
         dt = self.compute_dtype

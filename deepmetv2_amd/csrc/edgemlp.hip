@@ -1,0 +1,229 @@
+// edgemlp.hip -- K2 for a generic two-layer edge MLP on the bf16 matrix cores (gfx950), fused with the aggregation.
+//
+// Replaces, for  nn = Sequential(Linear(2H, H1), ELU, Linear(H1, H2)[, ELU])  over a fixed-width neighbour table,
+//   torch_geometric.nn.EdgeConv.forward = index_select x2 -> cat([x_i, x_j - x_i]) -> nn -> scatter(max | add)
+// i.e. the call shape of /root/reference/model/dynamic_reduction_network.py:59-73,86-87 (Linear-ELU-Linear-ELU) and
+// BASELINE configs[2] ("bf16 with MFMA edge-MLP").  No [E, 2H] tensor, no [E, H1] tensor and no [E, H2] message tensor
+// ever exists in HBM: a wavefront takes 32 edges (32 / k target nodes), builds their [x_i || x_j - x_i] rows as bf16
+// MFMA operands straight from the node table, runs both dense layers with v_mfma_f32_32x32x16_bf16 (fp32 accumulate),
+// applies ELU in fp32 and reduces the 32 messages to their targets with DPP row reductions.
+//
+// Both products are computed TRANSPOSED (channels x edges): z1^T = W1 . feat^T, z2^T = W2 . h1^T.  The accumulator of
+// the first product then has the edge on the lane and the hidden channel in the registers, which is exactly the B
+// operand the second product needs (it sums over the hidden channel): registers 8s..8s+7 converted to bf16 are the
+// fragment of k-step s, no LDS round trip, no lane movement; the permuted k order that comes with it is absorbed into
+// the way W2 is laid out in LDS.  Biases enter as the accumulators' initial values.
+//   MFMA operand maps (32x32x16 bf16): lane (r = lane & 31, hh = lane >> 5) holds A[row r][k = 8 hh + j],
+//   B[k = 8 hh + j][col r], j = 0..7;  C/D: col = r, row = (reg & 3) + 8 (reg >> 2) + 4 hh.
+// Numerics: inputs and weights rounded to bf16 (RNE), products exact, fp32 accumulation, ELU / max / sum in fp32:
+// the R6 bf16 bar (rtol 2e-2) against the fp32 oracle.
+#include "common.h"
+
+namespace dmet {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short bf16_rne(float f)
+{
+    // hipcc turns this cast into v_cvt_pk_bf16_f32 (keeps a NaN a NaN; guides/MI355X_MICROARCH.md)
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+__device__ __forceinline__ float elu1(float z)
+{
+    // ELU(alpha = 1): z > 0 ? z : exp(z) - 1
+    const float e = __builtin_amdgcn_exp2f(z * 1.44269504088896341f) - 1.0f;
+    return z > 0.0f ? z : e;
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// all-lanes reduction over the groups of `k` consecutive lanes (k = 8, 16, 32) that hold one target node's edges;
+// every lane of a group ends up with the group's result (butterfly: same association in every lane, deterministic)
+template <bool ADD>
+__device__ __forceinline__ float group_reduce(float v, int k)
+{
+    auto op = [](float a, float b) { return ADD ? a + b : __builtin_fmaxf(a, b); };
+    v = op(v, dpp<0xB1>(v));      // quad_perm [1,0,3,2]
+    v = op(v, dpp<0x4E>(v));      // quad_perm [2,3,0,1]
+    v = op(v, dpp<0x141>(v));     // row_half_mirror: lanes l <-> 7 - l of each 8
+    if (k >= 16) v = op(v, dpp<0x140>(v));   // row_mirror: l <-> 15 - l of each 16
+    if (k >= 32) v = op(v, __shfl_xor(v, 16, 64));
+    return v;
+}
+
+template <int HIN, int H1P, int H2>
+struct EdgeMlpLds {
+    static constexpr int MB1 = H1P / 32, KS1 = 2 * HIN / 16, MB2 = H2 / 32, KS2 = H1P / 16;
+    bf16x8 w1[MB1][KS1][kWave];   // A fragments of W1: row 32 mb + r, columns 16 kk + 8 hh + 0..7
+    bf16x8 w2[MB2][KS2][kWave];   // A fragments of W2 in the k order of the converted accumulators
+    float b1[H1P];
+    float b2[H2];
+};
+
+template <int HIN, int H1P, int H2, bool ADD>
+__global__ __launch_bounds__(256, 2) void edge_mlp2_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr,
+                                                            int64_t N, int k, const float *__restrict__ W1,
+                                                            const float *__restrict__ b1, int H1,
+                                                            const float *__restrict__ W2, const float *__restrict__ b2,
+                                                            int act2, float *__restrict__ out)
+{
+    using L = EdgeMlpLds<HIN, H1P, H2>;
+    constexpr int MB1 = L::MB1, KS1 = L::KS1, MB2 = L::MB2, KS2 = L::KS2, KH = HIN / 16;
+    __shared__ L S;
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    // ---- stage the weights once per workgroup, already in fragment order (bf16) ----------------------------------
+    for (int idx = threadIdx.x; idx < MB1 * KS1 * kWave; idx += blockDim.x) {
+        const int l = idx % kWave, kk = (idx / kWave) % KS1, mb = idx / (kWave * KS1);
+        const int row = 32 * mb + (l & 31), col0 = 16 * kk + 8 * (l >> 5);
+        bf16x8 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (short)bf16_rne(row < H1 ? W1[(int64_t)row * (2 * HIN) + col0 + j] : 0.0f);
+        S.w1[mb][kk][l] = f;
+    }
+    for (int idx = threadIdx.x; idx < MB2 * KS2 * kWave; idx += blockDim.x) {
+        const int l = idx % kWave, ks = (idx / kWave) % KS2, mb2 = idx / (kWave * KS2);
+        const int row = 32 * mb2 + (l & 31), mb1 = ks >> 1, s = ks & 1, lh = l >> 5;
+        bf16x8 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 32 * mb1 + 16 * s + 8 * (j >> 2) + 4 * lh + (j & 3);   // hidden channel of element j
+            f[j] = (short)bf16_rne(c < H1 ? W2[(int64_t)row * H1 + c] : 0.0f);
+        }
+        S.w2[mb2][ks][l] = f;
+    }
+    for (int c = threadIdx.x; c < H1P; c += blockDim.x) S.b1[c] = (c < H1 && b1) ? b1[c] : 0.0f;
+    for (int c = threadIdx.x; c < H2; c += blockDim.x) S.b2[c] = b2 ? b2[c] : 0.0f;
+    __syncthreads();
+
+    const int npt = 32 / k;                                  // target nodes per 32-edge tile
+    const int64_t ntiles = (N + npt - 1) / npt;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    const float ninf = -__builtin_inff();
+
+    for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+        const int64_t node = tile * npt + r / k;
+        const int slot = r % k;
+        const bool live = node < N;
+        const int32_t j = live ? nbr[node * k + slot] : -1;
+        const bool valid = j >= 0;
+        const int64_t ni = live ? node : N - 1, nj = valid ? j : ni;
+        // B operands of the first product: feat[edge r][16 kk + 8 hh + 0..7], feat = [x_i || x_j - x_i]
+        bf16x8 fi[KH], fd[KH];
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) {
+            const float4 a0 = x4[ni * (HIN / 4) + 4 * kk + 2 * hh], a1 = x4[ni * (HIN / 4) + 4 * kk + 2 * hh + 1];
+            const float4 c0 = x4[nj * (HIN / 4) + 4 * kk + 2 * hh], c1 = x4[nj * (HIN / 4) + 4 * kk + 2 * hh + 1];
+            const float xi[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const float xj[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                fi[kk][u] = (short)bf16_rne(xi[u]);
+                fd[kk][u] = (short)bf16_rne(xj[u] - xi[u]);
+            }
+        }
+        // ---- first layer, 32 hidden channels at a time; the converted accumulators are the second layer's B operands
+        bf16x8 h1f[MB1][2];
+#pragma unroll
+        for (int mb = 0; mb < MB1; ++mb) {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *reinterpret_cast<const float4 *>(&S.b1[32 * mb + 8 * q + 4 * hh]);
+                acc[4 * q] = bv.x; acc[4 * q + 1] = bv.y; acc[4 * q + 2] = bv.z; acc[4 * q + 3] = bv.w;
+            }
+#pragma unroll
+            for (int kk = 0; kk < KS1; ++kk)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S.w1[mb][kk][lane], kk < KH ? fi[kk] : fd[kk - KH], acc, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) h1f[mb][s][u] = (short)bf16_rne(elu1(acc[8 * s + u]));
+        }
+        // ---- second layer + aggregation, 32 output channels at a time ---------------------------------------------
+#pragma unroll
+        for (int mb2 = 0; mb2 < MB2; ++mb2) {
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *reinterpret_cast<const float4 *>(&S.b2[32 * mb2 + 8 * q + 4 * hh]);
+                acc[4 * q] = bv.x; acc[4 * q + 1] = bv.y; acc[4 * q + 2] = bv.z; acc[4 * q + 3] = bv.w;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S.w2[mb2][ks][lane], h1f[ks >> 1][ks & 1], acc, 0, 0, 0);
+            // messages of this lane's edge for channels 32 mb2 + (e & 3) + 8 (e >> 2) + 4 hh; reduce over the node's k edges
+            float res[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float m = act2 ? elu1(acc[e]) : acc[e];
+                m = valid ? m : (ADD ? 0.0f : ninf);
+                m = group_reduce<ADD>(m, k);
+                res[e] = (!ADD && m == ninf) ? 0.0f : m;      // a node without any neighbour aggregates to 0 (R3)
+            }
+            if (live && slot == 0) {
+                float4 *dst = reinterpret_cast<float4 *>(out + node * H2 + 32 * mb2 + 4 * hh);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[2 * q] = make_float4(res[4 * q], res[4 * q + 1], res[4 * q + 2], res[4 * q + 3]);
+            }
+        }
+    }
+}
+
+template <int HIN, int H1P, int H2>
+int launch_edge_mlp2(const float *x, const int32_t *nbr, int64_t N, int k, const float *W1, const float *b1, int H1,
+                     const float *W2, const float *b2, int act2, int aggr, float *out, hipStream_t st)
+{
+    const int npt = 32 / k;
+    const int64_t ntiles = (N + npt - 1) / npt;
+    int64_t blocks = (ntiles + 3) / 4;
+    if (blocks > 2048) blocks = 2048;     // persistent: the weights are staged once per workgroup
+    if (aggr == 0)
+        hipLaunchKernelGGL((edge_mlp2_kernel<HIN, H1P, H2, false>), dim3((unsigned)blocks), dim3(256), 0, st, x, nbr, N, k, W1,
+                           b1, H1, W2, b2, act2, out);
+    else
+        hipLaunchKernelGGL((edge_mlp2_kernel<HIN, H1P, H2, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, nbr, N, k, W1,
+                           b1, H1, W2, b2, act2, out);
+    DMET_LAUNCH_CHECK("edge_mlp2_kernel");
+    return 0;
+}
+
+}  // namespace
+}  // namespace dmet
+
+using namespace dmet;
+
+extern "C" int dmet_edge_mlp2_supported(int Hin, int H1, int H2, int k)
+{
+    if (!(k == 8 || k == 16 || k == 32)) return 0;
+    if (Hin == 32 && H1 >= 1 && H1 <= 64 && (H2 == 32 || H2 == 64)) return 1;
+    if (Hin == 64 && H1 >= 1 && H1 <= 128 && H2 == 64) return 1;
+    return 0;
+}
+
+extern "C" int dmet_edge_mlp2_bf16(const float *x, int64_t N, int Hin, const int32_t *nbr, int k, const float *W1,
+                                   const float *b1, int H1, const float *W2, const float *b2, int H2, int act2, int aggr,
+                                   float *out, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647 / 64, "dmet_edge_mlp2_bf16: N out of range");
+    DMET_REQUIRE(dmet_edge_mlp2_supported(Hin, H1, H2, k), "dmet_edge_mlp2_bf16: unsupported shape Hin=%d H1=%d H2=%d k=%d", Hin,
+                 H1, H2, k);
+    DMET_REQUIRE(aggr == 0 || aggr == 1, "dmet_edge_mlp2_bf16: aggr must be 0 (max) or 1 (add)");
+    if (N == 0) return 0;
+    DMET_REQUIRE(x && nbr && W1 && W2 && out, "dmet_edge_mlp2_bf16: null pointer");
+    DMET_REQUIRE(aligned16(x) && aligned16(out), "dmet_edge_mlp2_bf16: x and out must be 16-B aligned");
+    hipStream_t st = as_stream(stream);
+    if (Hin == 32 && H2 == 32) return launch_edge_mlp2<32, 64, 32>(x, nbr, N, k, W1, b1, H1, W2, b2, act2, aggr, out, st);
+    if (Hin == 32 && H2 == 64) return launch_edge_mlp2<32, 64, 64>(x, nbr, N, k, W1, b1, H1, W2, b2, act2, aggr, out, st);
+    if (H1 <= 96) return launch_edge_mlp2<64, 96, 64>(x, nbr, N, k, W1, b1, H1, W2, b2, act2, aggr, out, st);
+    return launch_edge_mlp2<64, 128, 64>(x, nbr, N, k, W1, b1, H1, W2, b2, act2, aggr, out, st);
+}

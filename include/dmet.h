@@ -157,6 +157,19 @@ int dmet_gather_max_lds16_f32(const float *P, const float *Q, const int32_t *nbr
 int dmet_gather_max_mixed_f32(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr_local,
                               const int64_t *ptr, int B, int64_t N, int k, int H, float *out, uint8_t *arg,
                               dmet_stream_t stream);
+/* Two-layer edge MLP on the bf16 matrix cores, fused with the aggregation (BASELINE configs[2]; the DRN call shape
+ * model/dynamic_reduction_network.py:59-73,86-87): for nn = Linear(2 Hin, H1) - ELU - Linear(H1, H2) [- ELU] (act2 != 0)
+ * over a fixed-width table nbr[N,k] (-1 = empty slot):
+ *   out[i,:] = aggr_{s: nbr[i,s] >= 0} nn([x_i || x_{nbr[i,s]} - x_i]),  aggr = 0: max (0 for a node without neighbours,
+ *   rule R3), 1: add.   W1[H1, 2 Hin], W2[H2, H1] row-major as torch.nn.Linear.weight; b1 / b2 may be NULL.
+ * Inputs and weights are rounded to bf16, products accumulate in fp32, ELU and the aggregation are fp32: the bf16 bar
+ * of rule R6 (rtol 2e-2) against the fp32 operators.  Nothing per-edge is written to memory.
+ * Built for (Hin, H1, H2) in {(32, <= 64, 32 | 64), (64, <= 128, 64)} and k in {8, 16, 32}: dmet_edge_mlp2_supported.
+ * Replaces torch_geometric.nn.EdgeConv.forward (index_select x2 -> cat -> nn -> scatter) for that `nn`. */
+int dmet_edge_mlp2_supported(int Hin, int H1, int H2, int k);
+int dmet_edge_mlp2_bf16(const float *x, int64_t N, int Hin, const int32_t *nbr, int k, const float *W1, const float *b1,
+                        int H1, const float *W2, const float *b2, int H2, int act2, int aggr, float *out,
+                        dmet_stream_t stream);
 /* bf16 variant (BASELINE configs[2]): x and the split weights rounded to bf16 (RNE), multiplied on the bf16 matrix
  * cores with fp32 accumulation; P stays fp32, Q is stored as bf16 (raw bits) and gathered as 64-B rows.
  * Built for Hin = Hout = 32, k in {8,16,32}.  Backward is shared with the fp32 path (arg-based, fp32). */

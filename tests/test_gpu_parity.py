@@ -892,3 +892,58 @@ def test_ops_fail_loudly_without_gpu_tensor(dev):
     import deepmetv2_amd as dm
     with pytest.raises(RuntimeError, match="non-GPU tensor"):
         dm.knn_graph(torch.randn(10, 4), 2)
+
+
+@pytest.mark.parametrize("H,H1,H2,k,aggr,act2", [(32, 48, 32, 16, "max", True), (32, 64, 64, 8, "add", True),
+                                               (64, 96, 64, 16, "max", True), (64, 128, 64, 32, "add", False),
+                                               (32, 33, 32, 16, "max", False)])
+def test_edge_mlp2_bf16_mfma(dev, H, H1, H2, k, aggr, act2):
+    """BASELINE configs[2] for a GENERIC nn (the DRN call shape, model/dynamic_reduction_network.py:59-63,86-87):
+    Linear - ELU - Linear [- ELU] per edge on the bf16 matrix cores, fused with the max / add aggregation
+    (csrc/edgemlp.hip).  (a) tight against a torch emulation of the same recipe (inputs, weights and the hidden
+    activations rounded to bf16, fp32 accumulation); (b) within the bf16 bar of rule R6 (rtol 2e-2 of the output scale)
+    of the fp32 PyG-shaped oracle; (c) gradients -- the backward differentiates the fp32 operators -- against the
+    oracle's; the graph is the fp32-exact kNN either way."""
+    import deepmetv2_amd as dm
+    from oracle import ref_ops
+    sizes = [300, 5, 0, 131, 64]          # an event smaller than k (empty slots) and an empty event
+    x, batch, ptr = _ragged(sizes, H, seed=300 + H1 + k)
+    layers = [torch.nn.Linear(2 * H, H1), torch.nn.ELU(), torch.nn.Linear(H1, H2)] + ([torch.nn.ELU()] if act2 else [])
+    nn_ = torch.nn.Sequential(*layers)
+    conv = dm.DynamicEdgeConv(nn=nn_, k=k, aggr=aggr)
+    conv.compute_dtype = torch.bfloat16
+    xr = x.clone().requires_grad_(True)
+    out_ref = ref_ops.dynamic_edge_conv(xr, batch, nn_, k, aggr)
+    gup = torch.randn(out_ref.shape, generator=torch.Generator().manual_seed(2))
+    out_ref.backward(gup)
+    g_ref = [xr.grad.clone()] + [p.grad.clone() for p in nn_.parameters()]
+    nn_.zero_grad()
+    # torch emulation of the bf16 recipe on the oracle's graph
+    nbr_ref, _ = ref_ops.knn_table(x, ptr, k)
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    l1, l2 = nn_[0], nn_[2]
+    j = nbr_ref.long().clamp(min=0)
+    xi = x.unsqueeze(1).expand(-1, k, -1)
+    feat = torch.cat([bf(xi), bf(x[j] - xi)], -1)
+    h1 = bf(torch.nn.functional.elu(feat @ bf(l1.weight.detach()).T + l1.bias.detach()))
+    m = h1 @ bf(l2.weight.detach()).T + l2.bias.detach()
+    if act2:
+        m = torch.nn.functional.elu(m)
+    ok = (nbr_ref >= 0).unsqueeze(-1)
+    if aggr == "max":
+        emu = torch.where(ok, m, torch.full_like(m, float("-inf"))).max(1).values
+        emu = torch.where(torch.isinf(emu), torch.zeros_like(emu), emu)
+    else:
+        emu = torch.where(ok, m, torch.zeros_like(m)).sum(1)
+
+    conv = conv.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    out = conv(xd, batch.to(dev))
+    out.backward(gup.to(dev))
+    o = out.detach().cpu()
+    scale = float(out_ref.detach().abs().max())
+    torch.testing.assert_close(o, emu, rtol=2e-3, atol=2e-3 * scale)                        # (a)
+    torch.testing.assert_close(o, out_ref.detach(), rtol=2e-2, atol=2e-2 * scale)           # (b)
+    got = [xd.grad.cpu()] + [p.grad.cpu() for p in nn_.parameters()]
+    for g, gr in zip(got, g_ref):                                                           # (c)
+        torch.testing.assert_close(g, gr, rtol=2e-3, atol=2e-4 * max(float(gr.abs().max()), 1e-6))
