@@ -49,6 +49,10 @@ def parse_args():
     ap.add_argument("--hip-graph", action="store_true",
                     help="replay the step as two hipGraphs around the gradient all-reduce (launch-bound small batches; "
                          "per-kernel HIP-event timing, hence the roofline block, is not available in this mode)")
+    ap.add_argument("--input", choices=["device", "host"], default="device",
+                    help="device: the batch is resident in HBM when the timed region starts (the metric's definition); "
+                         "host: every step takes its batch from pinned host memory through deepmetv2_amd.DeviceLoader "
+                         "(copied on a side stream two batches ahead), i.e. the PCIe-inclusive rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-events", type=int, default=0, help="0 = one event per host core (max 16)")
     return ap.parse_args()
@@ -343,7 +347,18 @@ def main():
                 return dm.radius_table(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255)
             return dm.radius_graph(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255)
 
-        if args.hip_graph:
+        if args.input == "host":
+            if args.hip_graph or args.graph != "dynamic":
+                raise SystemExit("--input host is built for the eager dynamic flow")
+            import itertools
+            from deepmetv2_amd.data import Batch, DeviceLoader
+            hb = Batch(x.cpu(), y.cpu(), batch.cpu(), ptr.cpu(), max(sizes)).pin_memory()
+            feed = iter(DeviceLoader(itertools.repeat(hb), dev, depth=2))     # the same batch every step: rate only
+
+            def step():
+                b = next(feed)
+                return train_step(model, flat, sync, opt, b.x, b.y, b.batch, b.ptr)
+        elif args.hip_graph:
             if args.graph != "dynamic":
                 raise SystemExit("--hip-graph: the static flow sizes its edge_index on the host (one sync per step)")
             from deepmetv2_amd.parallel import GraphedTrainStep
@@ -418,7 +433,7 @@ def main():
             "config": {"workload": workload_label(args, B, n, k), "events_per_gpu": B,
                        "nodes_per_event": n if args.ragged is None else f"U[{args.ragged[0]},{args.ragged[1]}]", "k": k,
                        "global_batch": B * world, "mode": args.mode, "graph": args.graph, "parallelism": f"dp{world}",
-                       "hip_graph": bool(args.hip_graph)},
+                       "hip_graph": bool(args.hip_graph), "input": args.input},
             "roofline": roof, "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:

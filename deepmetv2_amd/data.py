@@ -11,6 +11,7 @@ pt, eta, phi, d0, dz, mass, puppiWeight, pdgId, charge, fromPV, pvRef, pvAssocQu
 from __future__ import annotations
 
 from dataclasses import dataclass
+import collections
 from typing import Iterable, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -114,3 +115,55 @@ class EventLoader:
         train, val = perm[: n - n_val], perm[n - n_val:]
         return {"train": EventLoader(events, batch_size, train, device),
                 "test": EventLoader(events, batch_size, val, device)}
+
+
+class DeviceLoader:
+    """Feeds host Batches to the GPU the way `for data in dataloader: data.to(device)` does in the reference
+    (train.py:39-41), with the copy taken off the critical path: every batch is staged in pinned host memory and copied
+    host->device on a side stream `depth` batches ahead of the one the caller is computing on; the compute stream only
+    waits for the copy's event.  The batch structure (ptr, event count, largest event) is registered with the operators
+    from the host-side values, so the forward pass needs no device->host sync.
+
+    `batches` is any iterable of host `Batch` objects (an `EventLoader` without a device)."""
+
+    def __init__(self, batches: Iterable[Batch], device, depth: int = 2):
+        self.batches = batches
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceLoader copies to a ROCm device; got " + str(device))
+        self.depth = max(1, int(depth))
+
+    def __len__(self) -> int:
+        return len(self.batches)  # type: ignore[arg-type]
+
+    def __iter__(self) -> Iterator[Batch]:
+        dev = self.device
+        copy_stream = torch.cuda.Stream(dev)
+        inflight = collections.deque()
+
+        def stage(hb: Batch):
+            pinned = hb if hb.x.is_pinned() else hb.pin_memory()     # torch's caching host allocator reuses the blocks
+            with torch.cuda.stream(copy_stream):
+                db = Batch(pinned.x.to(dev, non_blocking=True), pinned.y.to(dev, non_blocking=True),
+                           pinned.batch.to(dev, non_blocking=True), pinned.ptr.to(dev, non_blocking=True), hb.max_nodes)
+                done = torch.cuda.Event()
+                done.record(copy_stream)
+            inflight.append((pinned, db, done))
+
+        it = iter(self.batches)
+        for hb in it:
+            stage(hb)
+            if len(inflight) > self.depth:
+                yield self._hand_over(inflight.popleft(), dev)
+        while inflight:
+            yield self._hand_over(inflight.popleft(), dev)
+
+    @staticmethod
+    def _hand_over(item, dev) -> Batch:
+        _pinned, db, done = item
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_event(done)                       # device-side wait: the host does not block
+        for t in (db.x, db.y, db.batch, db.ptr):
+            t.record_stream(cur)                   # allocated on the copy stream, used on the compute stream
+        register_batch(db.batch, db.ptr, db.num_graphs, max_nodes=db.max_nodes)
+        return db
