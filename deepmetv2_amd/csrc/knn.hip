@@ -1540,71 +1540,92 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter2_kernel(
 }
 
 // Split (tail) tiles of the second form: merge the two exact partial lists of a query by (d, j) and certify against
-// each sub-sweep's threshold.  One lane per query.
+// each sub-sweep's threshold.  LPQ lanes per query (element p of both sorted lists on lane p): an element's final rank
+// is its own index plus the number of elements of the OTHER list that precede it -- 2 x KP shuffles and compares per
+// lane, every load issued at once, no dependent chain (a head-pointer merge with one lane per query took 22 us, a
+// register-resident rank merge with one lane per query 37 us).  (d, j) pairs are distinct; empty slots are
+// (sentinel, -1) and are never written.
 template <int KP>
 __global__ __launch_bounds__(256) void knn_filter2_merge_kernel(const KnnFilterArgs a)
 {
     constexpr int M = filter_list_len(KP);
     constexpr int MS = (M + 1 + 3) & ~3;
+    constexpr int LPQ = KP <= 16 ? 16 : 32;          // lanes per query
+    constexpr int QPB = 256 / LPQ;                   // queries per workgroup
+    static_assert(kFilterMaxSplit == 2, "two sub-sweeps");
     const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
     if (split <= 1) return;
-    const int64_t fslot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int ft = n_full + (int)(fslot / kFQ);
+    // one workgroup per tail tile (its event is looked up once, on the scalar unit), kFQ / QPB rounds of QPB queries
+    const int ft = n_full + (int)blockIdx.x;
     if (ft >= total) return;
     const int pos = find_tile_event(a.tile_ptr, a.B, ft);
     const int ev = a.order[pos];
     const int64_t ev_lo = a.ptr[ev], ev_hi = a.ptr[ev + 1];
     if (!f2_in_domain((int)(ev_hi - ev_lo))) return;
-    const int64_t q = ev_lo + (int64_t)(ft - a.tile_ptr[pos]) * kFQ + (fslot % kFQ);
-    if (q >= ev_hi) return;
-    const float *pd = a.psd + fslot * split * MS;
-    const int32_t *pj = a.psj + fslot * split * MS;
+    const int p = threadIdx.x % LPQ;
+    for (int round = 0; round < kFQ / QPB; ++round) {
+    const int qoff = round * QPB + threadIdx.x / LPQ;
+    const int64_t fslot = (int64_t)blockIdx.x * kFQ + qoff;
+    const int64_t q = ev_lo + (int64_t)(ft - a.tile_ptr[pos]) * kFQ + qoff;
+    const bool act = q < ev_hi;
+    const float *pd = a.psd + (act ? fslot : 0) * 2 * MS;
+    const int32_t *pj = a.psj + (act ? fslot : 0) * 2 * MS;
     const int k = a.k;
-    // both sorted lists into registers with every load issued up front (a head-pointer merge is a chain of dependent
-    // global round trips), then rank-based merge: element i of one list lands at i + (elements of the other list that
-    // precede it in (d, j) order); (d, j) pairs are distinct, empty slots are (sentinel, -1) and sort last
-    static_assert(kFilterMaxSplit == 2, "two sub-sweeps");
-    float da[KP], db[KP];
-    int32_t ja[KP], jb[KP];
+    const bool has = act && p < KP;
+    const float da = has ? pd[p] : kKnnSentinel, db = has ? pd[MS + p] : kKnnSentinel;
+    const int32_t ja = has ? pj[p] : -1, jb = has ? pj[MS + p] : -1;
+    float nx = 0.0f, tau = kKnnSentinel;
+    int32_t of = 0;
+    if (act && p < 2) { tau = pd[p * MS + M]; of = pj[p * MS + M]; nx = a.nrm[q]; }
+    const int base = (threadIdx.x & 63) - p;          // lane of element 0 of this query inside the wavefront
+    int ra = p, rb = p;
 #pragma unroll
-    for (int p = 0; p < KP; ++p) {
-        da[p] = pd[p]; ja[p] = pj[p];
-        db[p] = pd[MS + p]; jb[p] = pj[MS + p];
+    for (int o = 0; o < KP; ++o) {
+        const float dbo = __shfl(db, base + o, 64), dao = __shfl(da, base + o, 64);
+        const int32_t jbo = __shfl(jb, base + o, 64), jao = __shfl(ja, base + o, 64);
+        ra += (jbo >= 0 && (dbo < da || (dbo == da && jbo < ja))) ? 1 : 0;
+        rb += (jao >= 0 && (dao < db || (dao == db && jao < jb))) ? 1 : 0;
     }
-    const float nx = a.nrm[q];
-    const float tau0 = pd[M], tau1 = pd[MS + M];
-    const int32_t of0 = pj[M], of1 = pj[MS + M];
+    // slots beyond the number of real candidates stay empty: lane p < k clears slot p first if nothing will land there
+    int na = ja >= 0 ? 1 : 0, nb = jb >= 0 ? 1 : 0;
+#pragma unroll
+    for (int off = 1; off < LPQ; off <<= 1) {
+        na += __shfl_xor(na, off, 64);
+        nb += __shfl_xor(nb, off, 64);
+    }
     float kth = -1.0f;
-    for (int p = 0; p < k; ++p) { a.dist[q * k + p] = kKnnSentinel; a.nbr[q * k + p] = -1; if (a.nbr16) a.nbr16[q * k + p] = 0xFFFFu; }
-#pragma unroll
-    for (int i = 0; i < KP; ++i) {
-        int ra = i, rb = i;
-#pragma unroll
-        for (int o = 0; o < KP; ++o) {
-            ra += (jb[o] >= 0 && (db[o] < da[i] || (db[o] == da[i] && jb[o] < ja[i]))) ? 1 : 0;
-            rb += (ja[o] >= 0 && (da[o] < db[i] || (da[o] == db[i] && ja[o] < jb[i]))) ? 1 : 0;
+    if (act) {
+        if (p < k && p >= na + nb) {
+            a.dist[q * k + p] = kKnnSentinel; a.nbr[q * k + p] = -1;
+            if (a.nbr16) a.nbr16[q * k + p] = 0xFFFFu;
         }
-        if (ja[i] >= 0 && ra < k) {
-            a.dist[q * k + ra] = da[i]; a.nbr[q * k + ra] = ja[i];
-            if (a.nbr16) a.nbr16[q * k + ra] = local_id16(ja[i], (int)ev_lo);
-            if (ra == k - 1) kth = da[i];
+        if (ja >= 0 && ra < k) {
+            a.dist[q * k + ra] = da; a.nbr[q * k + ra] = ja;
+            if (a.nbr16) a.nbr16[q * k + ra] = local_id16(ja, (int)ev_lo);
+            if (ra == k - 1) kth = da;
         }
-        if (jb[i] >= 0 && rb < k) {
-            a.dist[q * k + rb] = db[i]; a.nbr[q * k + rb] = jb[i];
-            if (a.nbr16) a.nbr16[q * k + rb] = local_id16(jb[i], (int)ev_lo);
-            if (rb == k - 1) kth = db[i];
+        if (jb >= 0 && rb < k) {
+            a.dist[q * k + rb] = db; a.nbr[q * k + rb] = jb;
+            if (a.nbr16) a.nbr16[q * k + rb] = local_id16(jb, (int)ev_lo);
+            if (rb == k - 1) kth = db;
         }
     }
-    const float an = __builtin_sqrtf(nx) * 1.000001f;
-    const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
-    const float slack = 2.0f * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1e-30f;
-    bool fail = of0 != 0 || of1 != 0;
-    if (tau0 < kKnnSentinel && !(tau0 + nx - slack > kth)) fail = true;
-    if (tau1 < kKnnSentinel && !(tau1 + nx - slack > kth)) fail = true;
-    if (fail) {
+    // the k-th distance to the two lanes that hold a sub-sweep's threshold
+#pragma unroll
+    for (int off = 1; off < LPQ; off <<= 1) kth = fmaxf(kth, __shfl_xor(kth, off, 64));
+    bool fail = false;
+    if (act && p < 2) {
+        const float an = __builtin_sqrtf(nx) * 1.000001f;
+        const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
+        const float slack = 2.0f * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1e-30f;
+        fail = of != 0 || (tau < kKnnSentinel && !(tau + nx - slack > kth));
+    }
+    const bool other = __shfl_xor(fail ? 1 : 0, 1, 64) != 0;
+    if (act && p == 0 && (fail || other)) {          // count the query once
         const int xt = a.xtile_ptr[pos] + (int)((q - ev_lo) / a.xtile_queries);
         a.qflag[q] = 1;
         atomicAdd(a.flags + xt, 1);
+    }
     }
 }
 
@@ -1957,7 +1978,7 @@ int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, cons
     hipLaunchKernelGGL((knn_rerank_kernel<KF>), dim3((unsigned)(tail_max * kRerankParts)), dim3(256), 0, st, f);
     DMET_LAUNCH_CHECK("knn_rerank_kernel");
     if (f.form2) {
-        hipLaunchKernelGGL((knn_filter2_merge_kernel<KF>), dim3((unsigned)((tail_max * kFQ + 255) / 256)), dim3(256), 0, st, f);
+        hipLaunchKernelGGL((knn_filter2_merge_kernel<KF>), dim3((unsigned)tail_max), dim3(256), 0, st, f);
         DMET_LAUNCH_CHECK("knn_filter2_merge_kernel");
     }
     return 0;

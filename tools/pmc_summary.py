@@ -1,4 +1,4 @@
-"""Derive profiles/pmc_gather_max.json and the filtered counter csvs from two rocprofv3 --pmc passes.
+"""Derive profiles/<tag>_pmc_gather_max.json and the filtered counter csvs from two rocprofv3 --pmc passes.
 
   python tools/pmc_summary.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> <round tag>
 
@@ -58,5 +58,5 @@ out = {
     "note": "algorithmic bytes (SURVEY 8d) = 101.4 MB (P rows, int32 ids, out, uint8 arg); the kernel reads the Q table "
             "once (36.9 MB) and takes its ids from the uint16 event-local table (9.2 MB instead of 18.4 MB)",
 }
-json.dump(out, open(os.path.join(root, "profiles", "pmc_gather_max.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(root, "profiles", f"{tag}_pmc_gather_max.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
