@@ -1183,10 +1183,12 @@ struct F2Ops {
 // MFMA (tools/mfma_overlap_micro.hip: 12 v_add per 32x32x16 MFMA interleaved cost 62 cycles per slot against 85 when
 // the two run in phases), but only if it is in program order between the MFMAs: the scheduler is told to emit
 // 1 MFMA + 11 VALU groups.  UPD: the tile minima feed tk / tau;  REC: hit masks are recorded.
-template <int M, bool UPD, bool REC>
+// INS: this call inserts min(carry, its tile minimum) into the threshold list (every second tile: the list then holds the
+// M smallest minima of tile PAIRS -- still M groups that each contain a key <= tau); otherwise it only updates `carry`.
+template <int M, bool UPD, bool REC, bool INS>
 __device__ __forceinline__ void f2_tile(F2Lane<M> &L, F2Wave &S, const uint8_t *__restrict__ rec, int64_t rbase, int t,
                                         int t_hi, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1, const F2Ops &use,
-                                        F2Ops &ld, const bf16x8 (&bq)[2][4], int lane, int hh, bool alive)
+                                        F2Ops &ld, const bf16x8 (&bq)[2][4], int lane, int hh, bool alive, float &carry)
 {
 #if defined(DMET_F2_ABL) && DMET_F2_ABL >= 2
     constexpr bool kRec = false;     // cycle-budget experiment (tools/knn_budget2.sh)
@@ -1227,6 +1229,7 @@ __device__ __forceinline__ void f2_tile(F2Lane<M> &L, F2Wave &S, const uint8_t *
         // candidate row r = 8 (r >> 3) + 4 a + (r & 3) sits in c{a}[(r & 3) + 4 (r >> 3)]; rows in ascending order, so
         // row r ends up in bit 31 - r.  Two VALU ops per key: key - tau, then v_alignbit shifts its sign bit into the
         // mask (a NaN key may set a bit: its exact distance is NaN and never enters the result).
+        // (v_pk_add_f32 for two rows at once was measured: no gain -- packed fp32 issues at half rate here)
         unsigned mlo = 0u, mhi = 0u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1255,10 +1258,17 @@ __device__ __forceinline__ void f2_tile(F2Lane<M> &L, F2Wave &S, const uint8_t *
         L.cnt += (mask != 0u) ? 1 : 0;
     }
     if (kUpd) {
+        if (INS) {
+            float v = tmin;
+            asm("v_min_f32 %0, %0, %1" : "+v"(v) : "v"(carry));     // (both operands are clamped to the sentinel: no NaN)
+            carry = kKnnSentinel;
 #pragma unroll
-        for (int p = M - 1; p >= 1; --p) L.tk[p] = __builtin_amdgcn_fmed3f(L.tk[p - 1], tmin, L.tk[p]);
-        L.tk[0] = __builtin_fminf(L.tk[0], tmin);
-        if (alive && !L.overflow) L.tau = L.tk[M - 1];
+            for (int p = M - 1; p >= 1; --p) L.tk[p] = __builtin_amdgcn_fmed3f(L.tk[p - 1], v, L.tk[p]);
+            asm("v_min_f32 %0, %0, %1" : "+v"(L.tk[0]) : "v"(v));
+            if (alive && !L.overflow) L.tau = L.tk[M - 1];
+        } else {
+            carry = tmin;
+        }
     }
 #ifdef DMET_F2_SCHED
     // experiment: force 1 MFMA + 11 VALU groups (measured 4 % SLOWER than hipcc's own order at two wavefronts per SIMD)
@@ -1282,11 +1292,14 @@ __device__ __forceinline__ void f2_sweep(F2Lane<M> &L, F2Wave &S, const uint8_t 
     f32x16 c1 = filter_block(A.a, bq[1], A.c);
     f32x16 n0, n1;
     filter_load(A.a, A.c, rec, rbase + min(t_lo + 1, t_hi - 1), lane, hh);
+    float carry = kKnnSentinel;
     for (int t = t_lo; t < t_hi; t += 2) {
-        f2_tile<M, UPD, REC>(L, S, rec, rbase, t, t_hi, c0, c1, n0, n1, A, B, bq, lane, hh, alive);
-        if (t + 1 < t_hi) {
-            f2_tile<M, UPD, REC>(L, S, rec, rbase, t + 1, t_hi, n0, n1, c0, c1, B, A, bq, lane, hh, alive);
-        }
+        // every tile inserts its own minimum (INS = true).  Inserting the minimum of tile PAIRS instead (half the
+        // v_med3 chains) was tried: the threshold then admits up to 2M tiles, more than the 26 entries a lane can keep
+        // -> 3 761 overflowed queries per launch and twice the kernel time
+        f2_tile<M, UPD, REC, true>(L, S, rec, rbase, t, t_hi, c0, c1, n0, n1, A, B, bq, lane, hh, alive, carry);
+        if (t + 1 < t_hi)
+            f2_tile<M, UPD, REC, true>(L, S, rec, rbase, t + 1, t_hi, n0, n1, c0, c1, B, A, bq, lane, hh, alive, carry);
     }
 }
 
