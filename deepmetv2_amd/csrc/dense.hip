@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64 * kXtyWavesPerBlock) void xty_partial_kernel(con
 {
     const int lane = threadIdx.x & 63;
     const int c = lane & 31, h = lane >> 5;
-    const int64_t wave = (int64_t)blockIdx.x * kXtyWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * kXtyWavesPerBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t r_lo = wave * rows_per_wave;
     const int64_t r_hi = min(N, r_lo + rows_per_wave);
     f32x16 acc[MT][NT];
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64 * kXtyWavesPerBlock) void xty_partial_kernel(con
     }
     // the block's wavefronts are summed in wavefront order through LDS: partial[block][a][b], a < MT*32, b < NT*32
     __shared__ float red[kXtyWavesPerBlock - 1][MT * NT * 16 * 64];
-    const int wv = threadIdx.x >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wv > 0) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void node_linear_split_kernel(const float *__r
     __shared__ __attribute__((aligned(16))) float tpose[SLICED ? 4 : 1][SLICED ? 2 : 1][SLICED ? 32 * TP : 1];
     const int lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t ntiles = (N + 31) / 32;
 
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void node_linear_split_bf16_kernel(const float
     constexpr int JT = HOUT / 32;
     const int lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t ntiles = (N + 31) / 32;
 

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd
     __shared__ float sP[kWavesPerBlock][kChunk * kPad];
     __shared__ float sQ[kWavesPerBlock][kChunk * kPad];
     __shared__ float sX[kWavesPerBlock][kChunk * kPad];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int c = lane & 31, hh = lane >> 5;
     if (blockIdx.x == 0 && threadIdx.x < kFinGroups) fin_counters[threadIdx.x] = 0;   // tickets of the finalize kernel
     float *P = sP[wv], *Q = sQ[wv], *X = sX[wv];

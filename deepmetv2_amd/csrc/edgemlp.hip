@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void edge_mlp2_kernel(const float *__restri
 
     const int npt = 32 / k;                                  // target nodes per 32-edge tile
     const int64_t ntiles = (N + npt - 1) / npt;
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
     const float ninf = -__builtin_inff();

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64 * kEncBwdWaves, 2) void encode_bwd_kernel(const 
     __shared__ float bufA[kEncBwdWaves][64 * 33];
     __shared__ float bufB[kEncBwdWaves][64 * 33];
     __shared__ int bufI[kEncBwdWaves][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *A = bufA[wv], *Bm = bufB[wv];
     int *packed = bufI[wv];
     const int64_t wave = (int64_t)blockIdx.x * kEncBwdWaves + wv;

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
                                                         float *__restrict__ out)
 {
     __shared__ float sX[4][64 * kXPad];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float *X = sX[wv];
     const int64_t base = ((int64_t)blockIdx.x * 4 + wv) * 64;
     if (base >= N) return;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64 * kHeadWaves, 2) void head_bwd_kernel(const floa
     __shared__ float sX[kHeadWaves][64 * kXPad];
     __shared__ float sA[kHeadWaves][64 * kAPad];
     __shared__ float sB[kHeadWaves][64 * kAPad];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float *X = sX[wv], *A = sA[wv], *Bt = sB[wv];
     const int64_t wave = (int64_t)blockIdx.x * kHeadWaves + wv;
     const int64_t lo = wave * nodes_per_wave, hi = min(N, lo + nodes_per_wave);

@@ -1,11 +1,18 @@
-// knn.hip -- K1: exact brute-force kNN graph build over ragged events, one launch (gfx950).
+// knn.hip -- K1: kNN graph build over ragged events (gfx950), and the radius graph (N1).
 //
 // Replaces torch_cluster.knn_graph / knn (call sites /root/reference/model/graph_met_network.py:63,
 // model/dynamic_reduction_network.py:86,94).  Results are bit-identical to oracle/dmet_oracle.c:
 //   R1  d(i,j) = chain of fmaf(diff, diff, acc) over the feature index, fp32, diff = x[j,c]-x[i,c]
 //   R2  top-k by (d, j) lexicographic order == upstream's strict-'>' insertion in ascending j
+// R1 / R2 define the RESULT, not the work done on pairs that cannot win.  Three paths, one stream, no host sync:
+//   * D = 32, k <= 20 (the model's shape): a matrix-core FILTER ranks all pairs approximately
+//     (key = |x_j|^2 - 2 x_i.x_j from a bf16 split on v_mfma_f32_32x32x16_bf16), keeps a certified superset of every
+//     query's neighbours, and only those go through the exact R1 chain and the (d, j) order.  Second form
+//     (knn_filter2_kernel, events of 2048..65536 nodes): per-tile hit masks, threshold from tile minima; first form
+//     (knn_filter_kernel): per-key queue.  A query whose certificate does not hold is recomputed exactly.
+//   * everything else, and the recomputation: the exact kernel below (knn_kernel).
 //
-// The kernel is fp32-VALU bound (a subtract and an fma per (query, candidate, feature); the difference form
+// The exact kernel is fp32-VALU bound (a subtract and an fma per (query, candidate, feature); the difference form
 // cannot go to the matrix cores without changing the rounding).  Measured on MI355X (tools/valu_micro.hip) this
 // instruction mix saturates at ~75-80 TFLOP/s (3 flop per element) and needs packed math plus >= 3 wavefronts per
 // SIMD to get there, which shapes the design:
@@ -325,8 +332,10 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 3) void knn_kernel(const Kn
     // and whole-sweep and sub-sweep items mix evenly per SIMD (single-wave workgroups left some SIMDs with 3 whole
     // sweeps: measured 3.1 ms stragglers against a 2.4 ms median).
     __shared__ KnnShared<DP, TQ> sh_all[kWavesPerGroup];
-    KnnShared<DP, TQ> &sh = sh_all[threadIdx.x >> 6];
-    const int item = blockIdx.x * kWavesPerGroup + (threadIdx.x >> 6);
+    // (wave-uniform, and said so: without readfirstlane the tile, the event and every derived address are per-lane math)
+    const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    KnnShared<DP, TQ> &sh = sh_all[wv_];
+    const int item = blockIdx.x * kWavesPerGroup + wv_;
     const int lane = threadIdx.x & 63;
 #ifdef DMET_KNN_STAMP
     if (lane == 0 && item < (1 << 16)) {
@@ -866,7 +875,7 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
     constexpr int QF = filter_queue_len(M);
     constexpr int MS = (M + 1 + 3) & ~3;   // list stride in the workspace: M entries, then tau (d array) / overflow (j array)
     __shared__ FilterQueue<QF> queue_all[kWavesPerGroup];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int col = lane & 31, hh = lane >> 5;
     const int item = blockIdx.x * kWavesPerGroup + wv;
     const uint8_t *__restrict__ rec = a.rec;
@@ -1208,7 +1217,7 @@ __device__ __forceinline__ void f2_tile(F2Lane<M> &L, F2Wave &S, const uint8_t *
 #else
     filter_load(ld.a, ld.c, rec, rbase + min(t + 2, t_hi - 1), lane, hh);   // clamped: the last two calls re-read the last tile
 #endif
-    n0 = filter_block(use.a, bq[0], use.c);
+    n0 = filter_block(use.a, bq[0], use.c);     // (s_setprio 1 around these was measured: 10 % slower)
     n1 = filter_block(use.a, bq[1], use.c);
     // lanes 32..63 of block 0 <-> lanes 0..31 of block 1: afterwards c0 = rows {0-3, 8-11, ..} and c1 = rows
     // {4-7, 12-15, ..} of THIS lane's query
@@ -1659,7 +1668,7 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
     __shared__ int sfail[QPB];
     __shared__ float qbuf[QPB][32];
     constexpr int PARTS = (kFQ + QPB - 1) / QPB;         // workgroups per 64-query filter tile
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int qw = lane / M, l = lane - qw * M;          // query slot of the wavefront, lane within the query
     const int slot = wv * QPW + min(qw, QPW - 1);
     // workgroup -> (filter tile, part): the event lookup is per workgroup (wave-uniform: scalar loads), not per lane
@@ -1952,12 +1961,18 @@ inline KnnWorkspace carve_workspace(void *ws, int64_t N, int B, int KP)
     return w;
 }
 
-// DMET_KNN_PATH=exact disables the matrix-core filter (tests and A/B timing); =filter_only skips the exact fallback
-// of uncertified tiles (diagnostics: output may then be wrong); anything else: filter when eligible + fallback
+// DMET_KNN_PATH=exact disables the matrix-core filter (tests and A/B timing); =filter_only (experiment builds only)
+// skips the exact fallback of uncertified tiles; anything else: filter when eligible + fallback
 inline int filter_mode()
 {
     const char *e = getenv("DMET_KNN_PATH");   // read per call: tests switch paths inside one process
-    return (e && strcmp(e, "exact") == 0) ? 0 : (e && strcmp(e, "filter_only") == 0) ? 2 : 1;
+    if (e && strcmp(e, "exact") == 0) return 0;
+#if defined(DMET_KNN_EXPERIMENT) || defined(DMET_FILTER_ABL) || defined(DMET_F2_ABL) || defined(DMET_F2_SAMEREC)
+    // timing builds only (tools/knn_budget*.sh): skipping the exact fallback can return uncertified neighbours, so
+    // the product library does not honour it
+    if (e && strcmp(e, "filter_only") == 0) return 2;
+#endif
+    return 1;
 }
 
 // DMET_KNN_FILTER=1: first form (per-key queue) for every event (A/B timing, tests); default: second form where it applies
@@ -2089,7 +2104,7 @@ __global__ __launch_bounds__(kWave * 4) void radius_kernel(const float *__restri
                                                             int32_t *__restrict__ nbr, int32_t *__restrict__ cntout)
 {
     __shared__ f2 tile_all[4][(kRadTile / 2) * DP];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     f2 *tile = tile_all[wv];
     const int64_t q_first = ((int64_t)blockIdx.x * 4 + wv) * kWave;
     if (q_first >= N) return;
@@ -2237,7 +2252,7 @@ __global__ __launch_bounds__(kWave * 4) void radius_window_kernel(const float *_
 {
     __shared__ f2 tile_all[4][(kRadTile / 2) * DP];
     __shared__ int queue_all[4][kRadQueue];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     f2 *tile = tile_all[wv];
     int *queue = queue_all[wv];
     // wavefronts are aligned to events: event b owns the wavefront ids from (ptr[b] >> 6) + b on (strictly increasing

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kMetThreads) void event_sum_kernel(const float *__r
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v) s[v] = wave_sum(s[v]);
-    const int wv = threadIdx.x >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) part[v][wv] = s[v];
