@@ -301,6 +301,60 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
     return out, arg
 
 
+def table_order_by_count(cnt: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:
+    """order[N] int32: per event, its local node indices grouped by slot count (deepest rows first)."""
+    dev = _require_device(cnt, ptr)
+    L = _lib.load()
+    N = cnt.numel()
+    order = torch.empty((N,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_table_order_by_count(cnt.data_ptr(), ptr.data_ptr(), ptr.numel() - 1, N, order.data_ptr(),
+                                               _stream(dev)), "dmet_table_order_by_count")
+    return order
+
+
+def gather_max_counted_j16(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, cnt: torch.Tensor,
+                           order: Optional[torch.Tensor], ptr: torch.Tensor, sliced: bool):
+    """(out[N,H], argj[N,H] int16-typed uint16 winner ids) of the counted LDS gather (radius tables)."""
+    dev = _require_device(P, Q, nbr, cnt, ptr)
+    L = _lib.load()
+    if sliced:
+        N, H = P.shape[1], P.shape[0] * 8
+    else:
+        N, H = P.shape
+    k = nbr.shape[1]
+    out = torch.empty((N, H), dtype=torch.float32, device=dev)
+    argj = torch.empty((N, H), dtype=torch.int16, device=dev)
+    _t = timer.record('gather_max', dev)
+    _note_gather("gather_max_lds_kernel, counted rows (radius table; Q slice resident in LDS, winner ids, rows ordered by "
+                 "depth" + (", slice-major P/Q)" if sliced else ")"))
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_gather_max_counted_lds_j16_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), cnt.data_ptr(),
+                                                         order.data_ptr() if order is not None else None, ptr.data_ptr(),
+                                                         ptr.numel() - 1, N, k, H, 1 if sliced else 0, out.data_ptr(),
+                                                         argj.data_ptr(), _stream(dev)), "dmet_gather_max_counted_lds_j16_f32")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
+    return out, argj
+
+
+def gather_max_bwd_j16(g_out: torch.Tensor, argj: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:
+    dev = _require_device(g_out, argj, ptr)
+    L = _lib.load()
+    g_out = _f32c(g_out, "g_out")
+    N, H = g_out.shape
+    if argj.dtype != torch.int16 or argj.shape != g_out.shape or not argj.is_contiguous():
+        raise TypeError("gather_max_bwd_j16: argj must be the contiguous int16 [N,H] tensor of gather_max_counted_j16")
+    gQ = torch.empty((N, H), dtype=torch.float32, device=dev)
+    _t = timer.record('gather_max_bwd', dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_gather_max_bwd_j16_f32(g_out.data_ptr(), argj.data_ptr(), ptr.data_ptr(), ptr.numel() - 1, N, H,
+                                                 gQ.data_ptr(), _stream(dev)), "dmet_gather_max_bwd_j16_f32")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
+    return gQ
+
+
 def edgeconv_fused_lds(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor], nbr: torch.Tensor,
                        ptr: torch.Tensor, want_arg: bool):
     """EdgeConv(Linear(64->32), max) in one launch (LDS-resident Q slice per event); see include/dmet.h."""

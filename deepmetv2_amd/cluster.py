@@ -87,7 +87,8 @@ def radius_table(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None
     info = batch_info(batch, x.shape[0], x.device, num_events)
     # no -1 fill of the unused slots: every consumer of a table with `cnt` goes by cnt
     nbr, _cnt = _native.radius(x, info.ptr, r, m, skip_self=not loop, pad=False)
-    return NeighborTable(nbr, info.ptr, dense=False, max_nodes=info.max_nodes, cnt=_cnt)
+    # with self loops every node finds at least itself (the cap counts hits in index order, but a full row is not empty)
+    return NeighborTable(nbr, info.ptr, dense=False, max_nodes=info.max_nodes, cnt=_cnt, nonempty=bool(loop))
 
 
 def radius_graph(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None, loop: bool = False,

@@ -73,6 +73,7 @@ class _EdgeConvLinearMax(torch.autograd.Function):
     def forward(ctx, x, weight, bias, table: NeighborTable, bf16: bool = False, passthrough: bool = False):
         need_grad = any(ctx.needs_input_grad[:3])
         ctx.passthrough = passthrough
+        ctx.j16 = False
         if bf16:
             # BASELINE configs[2]: dense layer on the bf16 matrix cores, bf16 Q table (half the gathered bytes);
             # max / add / backward stay fp32 (straight-through over the bf16 roundings)
@@ -83,8 +84,16 @@ class _EdgeConvLinearMax(torch.autograd.Function):
                    and table.max_nodes is not None and table.max_nodes <= _LDS_MAX_EVENT_NODES)
             sliced = lds and _native.GATHER_MAX_FORM != "l2-only" and os.environ.get("DMET_PQ_SLICED", "1") != "0"
             P, Q = _native.node_linear_split(x, weight, bias, sliced=sliced)
-            out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad, cnt=table.cnt, lds=lds,
-                                          sliced=sliced)
+            # radius tables with self loops (train.py:48): remember the winner's id, not its slot, so that the backward
+            # needs no look-up in the 255-wide table, and walk the rows in order of their depth
+            ctx.j16 = (lds and need_grad and table.nonempty and _native.GATHER_MAX_FORM == "auto"
+                       and os.environ.get("DMET_RADIUS_J16", "1") != "0")
+            if ctx.j16:
+                out, arg = _native.gather_max_counted_j16(P, Q, table.nbr, table.cnt, table.order_by_count(), table.ptr,
+                                                          sliced)
+            else:
+                out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad, cnt=table.cnt, lds=lds,
+                                              sliced=sliced)
         elif EDGECONV_FORM == "fused" and _lds_eligible(x, weight, table):
             # gather + edge MLP + max in one launch, the event's Q slice resident in LDS
             out, arg = _native.edgeconv_fused_lds(x, weight, bias, table.nbr, table.ptr, want_arg=need_grad)
@@ -117,7 +126,11 @@ class _EdgeConvLinearMax(torch.autograd.Function):
         table: NeighborTable = ctx.table
         H = x.shape[1]
         g_out = g_out.contiguous()
-        if H == 32 and g_out.dtype == torch.float32 and table.ptr is not None and GATHER_BWD_FORM != "reverse":
+        if ctx.j16:
+            # arg holds the winners' event-local ids (every row is non-empty: no mask needed further down)
+            gQ = _native.gather_max_bwd_j16(g_out, arg, table.ptr)
+            arg = None
+        elif H == 32 and g_out.dtype == torch.float32 and table.ptr is not None and GATHER_BWD_FORM != "reverse":
             # per-event LDS scatter with exact integer sums: no reverse index (radix sort) needed
             gQ = _native.gather_max_bwd_lds(g_out, arg, table.nbr, table.ptr, nbr_local=table.nbr_local)
         else:
@@ -125,7 +138,8 @@ class _EdgeConvLinearMax(torch.autograd.Function):
             gQ = _native.gather_max_bwd(g_out, arg, rev_ptr, rev_pos, table.k)
         if H == 32 and tuple(weight.shape) == (32, 64) and g_out.dtype == torch.float32:
             # one pass over the rows: gx, gW and gb on the fp32 matrix cores (csrc/edgeconv_bwd.hip)
-            gx, gW, gb = _native.edgeconv_linear_bwd(x, weight.detach(), g_out, None if table.dense else arg, gQ,
+            gx, gW, gb = _native.edgeconv_linear_bwd(x, weight.detach(), g_out,
+                                                     None if (table.dense or ctx.j16) else arg, gQ,
                                                      want_bias=ctx.has_bias, g_add=g_pass)
             return (gx if ctx.needs_input_grad[0] else None, gW if ctx.needs_input_grad[1] else None,
                     gb if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None, None, None)

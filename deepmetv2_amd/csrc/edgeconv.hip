@@ -677,11 +677,15 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
 // LDS-resident form for COUNTED tables (radius graphs: kmax = 255 slots, cnt[i] ~ 36 of them used): the same
 // (event, 8-channel slice) workgroups and Q image as gather_max_lds_kernel; a lane pair walks the first cnt[i] slots
 // of its node's row eight at a time (ids -> 8 LDS rows -> compare chain, strict > keeps the lowest slot on ties).
-template <bool WITH_ARG, bool SLICED>
+// ARGJ: instead of the winning SLOT (uint8) the kernel stores the winner's event-local node id (uint16, 0xFFFF =
+// none) -- the backward scatter then needs no look-up in the 255-wide table (dmet_gather_max_bwd_j16_f32).
+// `order` (optional): the event's nodes are processed in this order (table_order_kernel: by slot count), so that the
+// lane pairs of a wavefront walk rows of similar depth.
+template <bool WITH_ARG, bool SLICED, bool ARGJ = false>
 __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_counted_kernel(
     const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ nbr,
     const int32_t *__restrict__ cnt, const int64_t *__restrict__ ptr, int B, int kmax, int H,
-    float *__restrict__ out, uint8_t *__restrict__ arg, int64_t N)
+    float *__restrict__ out, uint8_t *__restrict__ arg, int64_t N, const int32_t *__restrict__ order = nullptr)
 {
     __shared__ __attribute__((aligned(16))) float4 qs[kLdsGatherRows * 2];   // [n_b + 1][2] float4 = 8 channels/node
     constexpr int RPI = kLdsGatherThreads / 2;
@@ -721,12 +725,13 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_counted_kern
         __syncthreads();
     }
     for (int r = r0; r < n; r += RPI) {
-        const int64_t node = lo + r;
+        const int64_t node = lo + (order ? order[lo + r] : r);
         const int32_t *row = nbr + node * kmax;
         const int m = min(kmax, cnt[node]);
         const float4 p = P4[pq_at(node)];
         float4 best = make_float4(ninf, ninf, ninf, ninf);
-        int a0 = 255, a1 = 255, a2 = 255, a3 = 255;
+        constexpr int kNone = ARGJ ? 0xFFFF : 255;
+        int a0 = kNone, a1 = kNone, a2 = kNone, a3 = kNone;
         bool any = false;
         for (int s0 = 0; s0 < m; s0 += 8) {
             int32_t j[8];
@@ -754,20 +759,52 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_counted_kern
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 any = any || (j[u] >= 0);
-                if (v[u].x > best.x) { best.x = v[u].x; a0 = s0 + u; }
-                if (v[u].y > best.y) { best.y = v[u].y; a1 = s0 + u; }
-                if (v[u].z > best.z) { best.z = v[u].z; a2 = s0 + u; }
-                if (v[u].w > best.w) { best.w = v[u].w; a3 = s0 + u; }
+                const int tag = ARGJ ? (j[u] - lo) : (s0 + u);   // what a winner is remembered by
+                if (v[u].x > best.x) { best.x = v[u].x; a0 = tag; }
+                if (v[u].y > best.y) { best.y = v[u].y; a1 = tag; }
+                if (v[u].z > best.z) { best.z = v[u].z; a2 = tag; }
+                if (v[u].w > best.w) { best.w = v[u].w; a3 = tag; }
             }
         }
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
         if (any) o = make_float4(p.x + best.x, p.y + best.y, p.z + best.z, p.w + best.w);
         reinterpret_cast<float4 *>(out)[node * h4 + col4] = o;
         if (WITH_ARG) {
-            uchar4 a = make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
-            if (!any) a = make_uchar4(255, 255, 255, 255);
-            reinterpret_cast<uchar4 *>(arg)[node * h4 + col4] = a;
+            if (ARGJ) {
+                ushort4 a = make_ushort4((unsigned short)a0, (unsigned short)a1, (unsigned short)a2, (unsigned short)a3);
+                if (!any) a = make_ushort4(0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF);
+                reinterpret_cast<ushort4 *>(arg)[node * h4 + col4] = a;
+            } else {
+                uchar4 a = make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
+                if (!any) a = make_uchar4(255, 255, 255, 255);
+                reinterpret_cast<uchar4 *>(arg)[node * h4 + col4] = a;
+            }
         }
+    }
+}
+
+// order[ptr[b] .. ptr[b+1]) = the event's local node indices grouped by slot count, deepest rows first (counting sort
+// in LDS; the order inside a group is arbitrary and influences no result -- every node is computed independently).
+__global__ __launch_bounds__(1024) void table_order_kernel(const int32_t *__restrict__ cnt, const int64_t *__restrict__ ptr,
+                                                           int B, int32_t *__restrict__ order)
+{
+    __shared__ int hist[256], start[256];
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int64_t lo = ptr[b], hi = ptr[b + 1];
+    const int n = (int)(hi - lo), tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[255 - min(255, max(0, cnt[lo + i]))], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int c = 0; c < 256; ++c) { start[c] = run; run += hist[c]; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int pos = atomicAdd(&start[255 - min(255, max(0, cnt[lo + i]))], 1);
+        order[lo + pos] = i;
     }
 }
 
@@ -1398,6 +1435,45 @@ extern "C" int dmet_gather_max_counted_lds_f32(const float *P, const float *Q, c
     else { if (pq_sliced) DMET_GCL(false, true); else DMET_GCL(false, false); }
 #undef DMET_GCL
     DMET_LAUNCH_CHECK("gather_max_lds_counted_kernel");
+    return 0;
+}
+
+extern "C" int dmet_table_order_by_count(const int32_t *cnt, const int64_t *ptr, int B, int64_t N, int32_t *order,
+                                         dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && B >= 0, "dmet_table_order_by_count: bad sizes");
+    if (N == 0 || B == 0) return 0;
+    DMET_REQUIRE(cnt && ptr && order, "dmet_table_order_by_count: null pointer");
+    hipLaunchKernelGGL(table_order_kernel, dim3((unsigned)B), dim3(1024), 0, as_stream(stream), cnt, ptr, B, order);
+    DMET_LAUNCH_CHECK("table_order_kernel");
+    return 0;
+}
+
+extern "C" int dmet_gather_max_counted_lds_j16_f32(const float *P, const float *Q, const int32_t *nbr, const int32_t *cnt,
+                                                   const int32_t *order, const int64_t *ptr, int B, int64_t N, int k,
+                                                   int H, int pq_sliced, float *out, uint16_t *argj,
+                                                   dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_gather_max_counted_lds_j16_f32: N out of range");
+    DMET_REQUIRE(k >= 1 && k <= 255, "dmet_gather_max_counted_lds_j16_f32: k=%d not in [1,255]", k);
+    DMET_REQUIRE(H >= kSliceC && H % kSliceC == 0 && H <= DMET_MAX_H,
+                 "dmet_gather_max_counted_lds_j16_f32: H=%d must be a multiple of %d", H, kSliceC);
+    if (N == 0 || B == 0) return 0;
+    DMET_REQUIRE(P && Q && nbr && cnt && ptr && out && argj, "dmet_gather_max_counted_lds_j16_f32: null pointer");
+    DMET_REQUIRE(aligned16(P) && aligned16(Q) && aligned16(out) && (reinterpret_cast<uintptr_t>(argj) & 7u) == 0,
+                 "dmet_gather_max_counted_lds_j16_f32: pointers must be 16-B (argj: 8-B) aligned");
+    const int nsl = H / kSliceC;
+    const int64_t groups = (B + kNumXcd - 1) / kNumXcd;
+    const int64_t blocks = groups * kNumXcd * nsl;
+    hipStream_t st = as_stream(stream);
+    uint8_t *a8 = reinterpret_cast<uint8_t *>(argj);
+    if (pq_sliced)
+        hipLaunchKernelGGL((gather_max_lds_counted_kernel<true, true, true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads),
+                           0, st, P, Q, nbr, cnt, ptr, B, k, H, out, a8, N, order);
+    else
+        hipLaunchKernelGGL((gather_max_lds_counted_kernel<true, false, true>), dim3((unsigned)blocks),
+                           dim3(kLdsGatherThreads), 0, st, P, Q, nbr, cnt, ptr, B, k, H, out, a8, N, order);
+    DMET_LAUNCH_CHECK("gather_max_lds_counted_kernel (winner ids)");
     return 0;
 }
 

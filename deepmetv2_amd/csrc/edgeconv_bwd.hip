@@ -242,6 +242,9 @@ inline int64_t ecb_nodes_per_wave(int64_t N, int64_t *nwaves)
 constexpr int kBwdThreads = 1024;
 constexpr int kBwdCells = 18432;             // 64-bit cells in LDS (144 KB)
 
+// J16: `arg` holds the winner's event-local node id per (node, channel) (uint16, 0xFFFF = none; written by
+// dmet_gather_max_counted_lds_j16_f32) instead of the winning slot: no table look-up at all.
+template <bool J16 = false>
 __global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const float *__restrict__ g_out,
                                                                           const uint8_t *__restrict__ arg,
                                                                           const int32_t *__restrict__ nbr,
@@ -307,7 +310,14 @@ __global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const f
                 int u_keep = 0;
                 for (int i = tid; i < n; i += kBwdThreads, ++u_keep) {
                     const int64_t gi = lo + i;
-                    const uchar4 a4 = reinterpret_cast<const uchar4 *>(arg + gi * kH + c0)[0];
+                    unsigned as[4];
+                    if (J16) {
+                        const ushort4 a4 = reinterpret_cast<const ushort4 *>(arg)[(gi * kH + c0) >> 2];
+                        as[0] = a4.x; as[1] = a4.y; as[2] = a4.z; as[3] = a4.w;
+                    } else {
+                        const uchar4 a4 = reinterpret_cast<const uchar4 *>(arg + gi * kH + c0)[0];
+                        as[0] = a4.x; as[1] = a4.y; as[2] = a4.z; as[3] = a4.w;
+                    }
                     float4 g4;
                     if (keep) {   // static register indices: select, do not index
                         g4 = gk[0];
@@ -316,11 +326,18 @@ __global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const f
                     } else {
                         g4 = reinterpret_cast<const float4 *>(g_out + gi * kH + c0)[0];
                     }
-                    const uint8_t as[4] = {a4.x, a4.y, a4.z, a4.w};
                     const float gs[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        if (u >= cb && u < cb + CH && as[u] != 255) {
+                        if (J16) {
+                            if (u >= cb && u < cb + CH && as[u] != 0xFFFFu) {
+                                const int j = (int)as[u] - j0;
+                                if (j >= 0 && j < jn) {
+                                    const long long q = __float2ll_rn(gs[u] * scale);
+                                    atomicAdd(&cells[j * CH + (u - cb)], (unsigned long long)q);
+                                }
+                            }
+                        } else if (u >= cb && u < cb + CH && as[u] != 255) {
 #ifdef DMET_KNN_EXPERIMENT
                             const int j = (k == 1 ? i : (loc16 ? (int)nbr16[gi * k + as[u]] : nbr[gi * k + as[u]] - (int)lo)) - j0;   // k == 1: upper bound of what skipping the id fetch would save
 #else
@@ -412,13 +429,13 @@ extern "C" int dmet_gather_max_bwd_lds16_f32(const float *g_out, const uint8_t *
     static bool attr_set = false;
     const size_t lds = sizeof(unsigned long long) * (size_t)kBwdCells;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gather_max_bwd_lds_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gather_max_bwd_lds_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gather_max_bwd_lds_kernel)");
         attr_set = true;
     }
-    hipLaunchKernelGGL(gather_max_bwd_lds_kernel, dim3((unsigned)B * 8u), dim3(kBwdThreads), lds, as_stream(stream), g_out,
-                       arg, nbr, nbr_local, ptr, B, k, gQ);
+    hipLaunchKernelGGL(gather_max_bwd_lds_kernel<false>, dim3((unsigned)B * 8u), dim3(kBwdThreads), lds, as_stream(stream),
+                       g_out, arg, nbr, nbr_local, ptr, B, k, gQ);
     DMET_LAUNCH_CHECK("gather_max_bwd_lds_kernel");
     return 0;
 }
@@ -428,4 +445,28 @@ extern "C" int dmet_gather_max_bwd_lds_f32(const float *g_out, const uint8_t *ar
                                            dmet_stream_t stream)
 {
     return dmet_gather_max_bwd_lds16_f32(g_out, arg, nbr, nullptr, ptr, B, N, k, H, gQ, stream);
+}
+
+extern "C" int dmet_gather_max_bwd_j16_f32(const float *g_out, const uint16_t *argj, const int64_t *ptr, int B, int64_t N,
+                                           int H, float *gQ, dmet_stream_t stream)
+{
+    DMET_REQUIRE(H == kH, "dmet_gather_max_bwd_j16_f32: H=%d (only 32 is built)", H);
+    DMET_REQUIRE(N >= 0 && B >= 0, "dmet_gather_max_bwd_j16_f32: bad sizes");
+    if (N == 0 || B == 0) return 0;
+    DMET_REQUIRE(g_out && argj && ptr && gQ, "dmet_gather_max_bwd_j16_f32: null pointer");
+    DMET_REQUIRE(aligned16(g_out) && aligned16(gQ) && (reinterpret_cast<uintptr_t>(argj) & 7u) == 0,
+                 "dmet_gather_max_bwd_j16_f32: rows must be 16-byte (argj: 8-byte) aligned");
+    static bool attr_set = false;
+    const size_t lds = sizeof(unsigned long long) * (size_t)kBwdCells;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gather_max_bwd_lds_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gather_max_bwd_lds_kernel)");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gather_max_bwd_lds_kernel<true>, dim3((unsigned)B * 8u), dim3(kBwdThreads), lds, as_stream(stream),
+                       g_out, reinterpret_cast<const uint8_t *>(argj), (const int32_t *)nullptr, (const uint16_t *)nullptr, ptr,
+                       B, 1, gQ);
+    DMET_LAUNCH_CHECK("gather_max_bwd_lds_kernel (winner ids)");
+    return 0;
 }

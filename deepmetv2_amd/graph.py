@@ -160,8 +160,10 @@ class NeighborTable:
 
     def __init__(self, nbr: torch.Tensor, ptr: Optional[torch.Tensor], dense: bool, dist: Optional[torch.Tensor] = None,
                  max_nodes: Optional[int] = None, cnt: Optional[torch.Tensor] = None,
-                 nbr_local: Optional[torch.Tensor] = None):
+                 nbr_local: Optional[torch.Tensor] = None, nonempty: bool = False):
         self.nbr = nbr
+        self.nonempty = nonempty    # True: every row holds at least one entry (tables built with self loops)
+        self._order = None
         self.nbr_local = nbr_local  # optional int16-typed [N,k]: the same table as event-local uint16 ids (knn_local)
         self.ptr = ptr
         self.max_nodes = max_nodes
@@ -173,6 +175,12 @@ class NeighborTable:
         self._rp = None
         self._edges = None
         self._edge_index = {}
+
+    def order_by_count(self) -> Optional[torch.Tensor]:
+        """Counted tables: per event, the local node indices grouped by slot count (one small kernel, cached)."""
+        if self._order is None and self.cnt is not None and self.ptr is not None:
+            self._order = _native.table_order_by_count(self.cnt, self.ptr)
+        return self._order
 
     def reverse(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """rev_ptr[N+1], rev_slot[...]: the table positions i*k+s that hold node j, ascending, for every j."""

@@ -141,6 +141,21 @@ int dmet_gather_max_counted_lds_f32(const float *P, const float *Q, const int32_
                                     const int64_t *ptr, int B, int64_t N, int k, int H, int pq_sliced, float *out,
                                     uint8_t *arg, dmet_stream_t stream);   /* pq_sliced != 0: P / Q are the slice-major
                                     tables of dmet_node_linear_split_sliced_f32 */
+/* Winner-id form of dmet_gather_max_counted_lds_f32 for the reference's active flow (one 255-wide radius table per
+ * batch, train.py:48): instead of the winning slot it stores, per (node, channel), the winner's EVENT-LOCAL node id
+ * (argj[N,H] uint16, 0xFFFF = no neighbour; events of at most 65534 nodes), so that the backward scatter
+ * (dmet_gather_max_bwd_j16_f32) needs no look-up in the wide table; `order` (optional, from dmet_table_order_by_count:
+ * the event's local node indices grouped by slot count) makes the lane pairs of a wavefront walk rows of similar depth.
+ * out is identical to dmet_gather_max_counted_f32. */
+int dmet_table_order_by_count(const int32_t *cnt, const int64_t *ptr, int B, int64_t N, int32_t *order,
+                              dmet_stream_t stream);
+int dmet_gather_max_counted_lds_j16_f32(const float *P, const float *Q, const int32_t *nbr, const int32_t *cnt,
+                                        const int32_t *order, const int64_t *ptr, int B, int64_t N, int k, int H,
+                                        int pq_sliced, float *out, uint16_t *argj, dmet_stream_t stream);
+/* gQ[j,c] = sum of g_out[i,c] over the (i,c) whose winner is j = ptr[event] + argj[i,c]: the per-event LDS scatter
+ * with exact integer sums of dmet_gather_max_bwd_lds_f32 (bitwise reproducible), H = 32. */
+int dmet_gather_max_bwd_j16_f32(const float *g_out, const uint16_t *argj, const int64_t *ptr, int B, int64_t N, int H,
+                                float *gQ, dmet_stream_t stream);
 /* Same again with the table ALSO given as event-local uint16 ids (nbr_local from dmet_knn_local_f32; k in {8,16,32},
  * 16-byte aligned): events that fit the LDS image read their ids from it -- half the id bytes, and every one of the
  * H/8 slice workgroups of an event re-reads the ids, so this is a third of the kernel's L2 requests.  Larger events

@@ -302,7 +302,45 @@ def table_edges(nbr, cnt, rowptr, num_edges, swap, want_index64, want_int32):
     return ei, (src.contiguous() if want_int32 else None), (tgt.contiguous() if want_int32 else None)
 
 
-_NAMES = ["table_rowptr", "table_edges", "head_fwd", "head_bwd", "met_loss", "gather_max_bwd_lds", "edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "knn_local", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
+def table_order_by_count(cnt, ptr):
+    """Per event: local node indices grouped by slot count, deepest rows first (any order inside a group)."""
+    order = torch.empty(cnt.numel(), dtype=torch.int32)
+    for b in range(ptr.numel() - 1):
+        lo, hi = int(ptr[b]), int(ptr[b + 1])
+        order[lo:hi] = torch.argsort(-cnt[lo:hi].long(), stable=True).int()
+    return order
+
+
+def gather_max_counted_j16(P, Q, nbr, cnt, order, ptr, sliced):
+    """Counted gather that remembers the winner's event-local id (uint16 payload in an int16 tensor, 0xFFFF = none)."""
+    if order is not None:   # a permutation of every event's local indices
+        for b in range(ptr.numel() - 1):
+            lo, hi = int(ptr[b]), int(ptr[b + 1])
+            assert sorted(order[lo:hi].tolist()) == list(range(hi - lo))
+    out, arg8 = gather_max(P, Q, nbr, ptr, True, cnt=cnt)
+    N, H = out.shape
+    counts = (ptr[1:] - ptr[:-1]).long()
+    lo = torch.repeat_interleave(ptr[:-1], counts).view(-1, 1)
+    slot = arg8.long().clamp(max=nbr.shape[1] - 1)
+    j = torch.gather(nbr.long(), 1, slot) - lo
+    j = torch.where(arg8 == 255, torch.full_like(j, 0xFFFF), j)
+    return out, torch.where(j >= 0x8000, j - 0x10000, j).to(torch.int16)
+
+
+def gather_max_bwd_j16(g_out, argj, ptr):
+    N, H = g_out.shape
+    counts = (ptr[1:] - ptr[:-1]).long()
+    lo = torch.repeat_interleave(ptr[:-1], counts).view(-1, 1)
+    u = argj.long() & 0xFFFF
+    valid = u != 0xFFFF
+    j = u + lo
+    gQ = torch.zeros_like(g_out)
+    cols = torch.arange(H).expand(N, H)
+    gQ.index_put_((j[valid], cols[valid]), g_out[valid], accumulate=True)
+    return gQ
+
+
+_NAMES = ["table_order_by_count", "gather_max_counted_j16", "gather_max_bwd_j16", "table_rowptr", "table_edges", "head_fwd", "head_bwd", "met_loss", "gather_max_bwd_lds", "edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "knn_local", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
           "edge_features_bwd", "segment_max", "segment_sum", "segment_max_bwd", "segment_sum_bwd", "met_reduce",
           "met_reduce_bwd", "segment_sum_1d", "batch_to_ptr", "xty", "onehot_xty", "edgeconv_fused_lds"]
 

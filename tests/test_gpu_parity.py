@@ -947,3 +947,44 @@ def test_edge_mlp2_bf16_mfma(dev, H, H1, H2, k, aggr, act2):
     got = [xd.grad.cpu()] + [p.grad.cpu() for p in nn_.parameters()]
     for g, gr in zip(got, g_ref):                                                           # (c)
         torch.testing.assert_close(g, gr, rtol=2e-3, atol=2e-4 * max(float(gr.abs().max()), 1e-6))
+
+
+def test_counted_gather_winner_ids_and_ordered_rows(dev):
+    """N1 / the reference's active flow (train.py:48: one 255-wide radius table per batch): the winner-id form of the
+    counted LDS gather (rows walked in order of their depth) must give the slot form's output bit for bit, its ids must
+    be the slot form's winners, and the backward scatter fed by the ids must equal the one that looks the ids up."""
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import _native
+    g = torch.Generator().manual_seed(31)
+    sizes = [1200, 0, 37, 900, 2100]
+    N = sum(sizes)
+    etaphi = torch.stack([(torch.rand(N, generator=g) - 0.5) * 5, (torch.rand(N, generator=g) - 0.5) * 6.28], 1)
+    etaphi[100:400] = etaphi[100] + 0.05 * torch.randn(300, 2, generator=g)       # rows that overflow the 255 slots
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).to(dev)
+    t = dm.radius_table(etaphi.to(dev), 0.4, batch, loop=True, max_num_neighbors=255)
+    assert t.nonempty and int(t.cnt.min()) >= 1 and int(t.cnt.max()) == 255
+    H = 32
+    x = torch.randn(N, H, generator=g).to(dev)
+    W = (torch.randn(H, 2 * H, generator=g) / 8).to(dev)
+    b = torch.randn(H, generator=g).to(dev)
+    order = t.order_by_count()
+    lo = torch.repeat_interleave(t.ptr[:-1], t.ptr.diff()).view(-1, 1)
+    for b_ in range(len(sizes)):           # a permutation of every event, deepest rows first
+        s, e = int(t.ptr[b_]), int(t.ptr[b_ + 1])
+        o = order[s:e].long()
+        assert sorted(o.tolist()) == list(range(e - s))
+        c = t.cnt[s:e][o]
+        assert bool((c[1:] <= c[:-1]).all())
+    for sliced in (False, True):
+        P, Q = _native.node_linear_split(x, W, b, sliced=sliced)
+        out0, arg8 = _native.gather_max(P, Q, t.nbr, t.ptr, want_arg=True, cnt=t.cnt, lds=True, sliced=sliced)
+        out1, argj = _native.gather_max_counted_j16(P, Q, t.nbr, t.cnt, order, t.ptr, sliced)
+        assert torch.equal(out0, out1)
+        win = torch.gather(t.nbr.long(), 1, arg8.long()) - lo
+        assert torch.equal(argj.long() & 0xFFFF, win)
+        out2, argj2 = _native.gather_max_counted_j16(P, Q, t.nbr, t.cnt, None, t.ptr, sliced)      # without the order
+        assert torch.equal(out1, out2) and torch.equal(argj, argj2)
+    gout = torch.randn(N, H, generator=g).to(dev)
+    gq0 = _native.gather_max_bwd_lds(gout, arg8, t.nbr, t.ptr)
+    gq1 = _native.gather_max_bwd_j16(gout, argj, t.ptr)
+    assert torch.equal(gq0, gq1)           # integer LDS sums: bitwise, whatever the order of the atomics
