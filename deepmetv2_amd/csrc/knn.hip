@@ -151,12 +151,16 @@ __device__ __attribute__((noinline)) float drain_queue(const uint2 (*queue)[kWav
 __device__ unsigned long long g_knn_stamps[1 << 16][4];
 #endif
 
+// events the second matrix-core filter form sweeps (knn_filter2_kernel); the plan counts the others
+constexpr int kF2MinNodes = 2048;   // smaller events: first form (tau of the second form needs M tiles to exist at all)
+constexpr int kF2MaxNodes = 65536;  // tile number must fit 11 bits
+
 // Device-side launch plan (no host synchronisation): tiles never straddle events, so tile -> event needs a prefix.
 struct KnnPlan {
     int total_tiles;   // sum_b ceil(n_b / tile_queries)
     int n_full;        // tiles 0..n_full-1 sweep their whole event in one workgroup
     int split;         // tiles n_full.. are cut into `split` candidate sub-sweeps each (tail balancing)
-    int pad;
+    int form1_events;  // non-empty events outside the second filter form's size range (its kernels exit at once if 0)
 };
 
 struct KnnArgs {
@@ -178,6 +182,7 @@ struct KnnArgs {
     int32_t *psj;
     const int32_t *flags;  // optional [tiles] = number of uncertified queries per tile (matrix-core path): only
     int flag_min;          // tiles with flags[tile] >= flag_min are computed here
+    const int32_t *any;    // optional: total number of uncertified queries (0: nothing to do for any workgroup)
 };
 
 __device__ __forceinline__ uint16_t local_id16(int32_t j, int ev_lo)
@@ -243,14 +248,20 @@ __device__ __forceinline__ void knn_plan_body(const int64_t *__restrict__ ptr, i
     __syncthreads();
     const int chunk = (B + 255) / 256;
     const int lo = min(B, tid * chunk), hi = min(B, lo + chunk);
-    int sum = 0;
+    int sum = 0, nf1 = 0;
     for (int p = lo; p < hi; ++p) {
         const int b = order[p];
-        sum += (int)((ptr[b + 1] - ptr[b] + tile_queries - 1) / tile_queries);
+        const int64_t nb = ptr[b + 1] - ptr[b];
+        sum += (int)((nb + tile_queries - 1) / tile_queries);
+        nf1 += (nb > 0 && !(nb >= kF2MinNodes && nb <= kF2MaxNodes)) ? 1 : 0;
     }
     part[tid] = sum;
+    __shared__ int part_f1[256];
+    part_f1[tid] = nf1;
     __syncthreads();
     if (tid == 0) {
+        int form1_events = 0;
+        for (int i = 0; i < 256; ++i) form1_events += part_f1[i];
         int run = 0;
         const int owners = chunk > 0 ? (B + chunk - 1) / chunk : 0;   // threads beyond this own no event
         for (int i = 0; i < owners; ++i) { const int v = part[i]; part[i] = run; run += v; }
@@ -267,7 +278,7 @@ __device__ __forceinline__ void knn_plan_body(const int64_t *__restrict__ ptr, i
             if (f > max_split) f = max_split;
             if (f >= 2) { n_full = full; split = f; }
         }
-        plan->total_tiles = tiles; plan->n_full = n_full; plan->split = split; plan->pad = 0;
+        plan->total_tiles = tiles; plan->n_full = n_full; plan->split = split; plan->form1_events = form1_events;
         tile_ptr[B] = tiles;
     }
     __syncthreads();
@@ -363,6 +374,7 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 3) void knn_kernel(const Kn
         nsub = split;
     }
     if (tile >= total) return;
+    if (a.any && *a.any == 0) return;   // matrix-core path certified every query: nothing to recompute
     if (a.flags && a.flags[tile] < a.flag_min) return;
     const int pos = find_tile_event(a.tile_ptr, a.B, tile);
     const int ev = a.order[pos];
@@ -522,6 +534,7 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 3) void knn_kernel(const Kn
 template <int KP>
 __global__ __launch_bounds__(256) void knn_merge_kernel(const KnnArgs a, int tile_queries)
 {
+    if (a.any && *a.any == 0) return;
     const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
     if (split <= 1) return;
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -612,6 +625,7 @@ struct KnnFilterArgs {
     float *dist;
     uint16_t *nbr16;            // optional event-local copy of nbr (see KnnArgs)
     int32_t *flags;             // [exact tiles] number of uncertified queries of the tile
+    int32_t *any;               // total number of uncertified queries: the fallback kernels exit at once while it is 0
     uint8_t *qflag;             // [N] 1 = uncertified query
     const int32_t *xtile_ptr;   // tile prefix of the exact kernel's plan (same event order)
     int xtile_queries;
@@ -865,9 +879,7 @@ __device__ __forceinline__ float chain_dist32(const float *__restrict__ xj, cons
     return acc;
 }
 
-// events of the second form (knn_filter2_kernel below)
-constexpr int kF2MinNodes = 2048;   // smaller events: first form (tau of the second form needs M tiles to exist at all)
-constexpr int kF2MaxNodes = 65536;  // tile number must fit 11 bits
+// events of the second form (knn_filter2_kernel below): kF2MinNodes .. kF2MaxNodes nodes (constants with the plan)
 __device__ __forceinline__ bool f2_in_domain(int n) { return n >= kF2MinNodes && n <= kF2MaxNodes; }
 
 template <int KP>
@@ -884,6 +896,7 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
     const int64_t *__restrict__ ptr = a.ptr;
     FilterQueue<QF> &Q = queue_all[wv];
 
+    if (a.form2 && a.plan->form1_events == 0) return;      // every event is swept by knn_filter2_kernel
     const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
     int tile = item, sub = 0, nsub = 1;
     if (item >= n_full) {
@@ -1093,6 +1106,7 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
                 const int xt = a.xtile_ptr[pos] + (myq - ev_lo) / a.xtile_queries;
                 a.qflag[myq] = 1;
                 atomicAdd(a.flags + xt, 1);   // a count: order-independent
+                atomicAdd(a.any, 1);
             }
         }
         return;
@@ -1550,6 +1564,7 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter2_kernel(
             const int xt = a.xtile_ptr[pos] + (myq - ev_lo) / a.xtile_queries;
             a.qflag[myq] = 1;
             atomicAdd(a.flags + xt, 1);   // a count: order-independent
+            atomicAdd(a.any, 1);
         }
         return;
     }
@@ -1649,6 +1664,7 @@ __global__ __launch_bounds__(256) void knn_filter2_merge_kernel(const KnnFilterA
         const int xt = a.xtile_ptr[pos] + (int)((q - ev_lo) / a.xtile_queries);
         a.qflag[q] = 1;
         atomicAdd(a.flags + xt, 1);
+        atomicAdd(a.any, 1);
     }
     }
 }
@@ -1677,6 +1693,7 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
     // no XCD remap here: the grid is a worst-case bound and the live tiles are its first few hundred workgroups,
     // which the round-robin dispatch already spreads over all XCDs
     const int bid = blockIdx.x;
+    if (a.form2 && a.plan->form1_events == 0) return;
     const int n_full = a.plan->n_full, split = a.plan->split;
     const int ft = n_full + bid / PARTS, part = bid % PARTS;   // only the split (tail) tiles come here
     if (ft >= a.plan->total_tiles) return;
@@ -1778,6 +1795,7 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
         const int xt = a.xtile_ptr[pos] + (int)((qq - ev_lo) / a.xtile_queries);
         a.qflag[qq] = 1;
         atomicAdd(a.flags + xt, 1);   // a count: order-independent
+        atomicAdd(a.any, 1);
     }
 }
 
@@ -1799,6 +1817,7 @@ __global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a,
     // has nothing to redo, and a workgroup per tile (each holding the distance cache in LDS) spent 10 us on
     // workgroups that exit at once.  Counters of tiles beyond the plan's total are zero (cleared per call).
     __shared__ int tile_flags[kRequeryTiles];
+    if (*a.any == 0) return;   // (workgroup-uniform) nothing was flagged anywhere
     if (tid < kRequeryTiles) {
         const int tile = blockIdx.x * kRequeryTiles + tid;
         tile_flags[tid] = tile < ntiles ? a.flags[tile] : 0;
@@ -1917,7 +1936,8 @@ struct KnnWorkspace {
     float *nrm;
     uint8_t *rec;         // candidate tile records
     int64_t nrec;
-    int32_t *flags;       // flags[...] and qflag[N] are one zero-filled region
+    int32_t *flags;       // flags[...], any[4] and qflag[N] are one zero-filled region
+    int32_t *any;
     uint8_t *qflag;
     size_t zero_bytes;
     size_t bytes;
@@ -1956,9 +1976,10 @@ inline KnnWorkspace carve_workspace(void *ws, int64_t N, int B, int KP)
     w.nrm = reinterpret_cast<float *>(take(sizeof(float) * (size_t)N));
     w.nrec = (N >> 5) + B + 1;                               // event b owns records from (ptr[b] >> 5) + b
     w.rec = reinterpret_cast<uint8_t *>(take((size_t)w.nrec * kRecBytes));
-    w.zero_bytes = sizeof(int32_t) * (size_t)exact_tiles_max(N, B) + (size_t)N;
+    w.zero_bytes = sizeof(int32_t) * ((size_t)exact_tiles_max(N, B) + 4) + (size_t)N;
     w.flags = reinterpret_cast<int32_t *>(take(w.zero_bytes));
-    w.qflag = reinterpret_cast<uint8_t *>(w.flags + exact_tiles_max(N, B));
+    w.any = w.flags + exact_tiles_max(N, B);
+    w.qflag = reinterpret_cast<uint8_t *>(w.any + 4);
     w.bytes = (size_t)(p - reinterpret_cast<uintptr_t>(ws));
     return w;
 }
@@ -2031,7 +2052,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
         hipLaunchKernelGGL(knn_plan_kernel, dim3(1), dim3(256), 0, st, ptr, B, px, pf);
         DMET_LAUNCH_CHECK("knn_plan_kernel");
     }
-    KnnArgs a{x, ptr, B, N, D, k, nbr, dist, nbr16, w.wsd, w.wsj, w.plan, w.order, w.tile_ptr, w.psd, w.psj, nullptr, 0};
+    KnnArgs a{x, ptr, B, N, D, k, nbr, dist, nbr16, w.wsd, w.wsj, w.plan, w.order, w.tile_ptr, w.psd, w.psj, nullptr, 0, nullptr};
     // uncertified-query counters: zero for every call, so dmet_knn_fallback_stats is meaningful on any path (the
     // matrix-core path clears them in its prep kernel)
     if (!use_filter && hipMemsetAsync(w.flags, 0, w.zero_bytes, st) != hipSuccess)
@@ -2041,7 +2062,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     // the tiles the re-rank could not certify
     if (use_filter) {
         KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.rec, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
-                        w.psd, w.psj, nbr, dist, nbr16, w.flags, w.qflag, w.tile_ptr, QT, filter_form2()};
+                        w.psd, w.psj, nbr, dist, nbr16, w.flags, w.any, w.qflag, w.tile_ptr, QT, filter_form2()};
         int rc = 0;
         if constexpr (KP == 8) rc = launch_filter<8>(f, w, simds, px, pf, st);
         else if constexpr (KP == 16) rc = launch_filter<16>(f, w, simds, px, pf, st);
@@ -2055,6 +2076,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
         DMET_LAUNCH_CHECK("knn_requery_kernel");
         a.flags = w.flags;
         a.flag_min = kRequeryMax + 1;
+        a.any = w.any;
     }
 
     // worst-case grid (the plan is on the device): every event adds at most one partial tile, and splitting the
