@@ -8,8 +8,9 @@
 //   * D = 32, k <= 20 (the model's shape): a matrix-core FILTER ranks all pairs approximately
 //     (key = |x_j|^2 - 2 x_i.x_j from a bf16 split on v_mfma_f32_32x32x16_bf16), keeps a certified superset of every
 //     query's neighbours, and only those go through the exact R1 chain and the (d, j) order.  Second form
-//     (knn_filter2_kernel, events of 2048..65536 nodes): per-tile hit masks, threshold from tile minima; first form
-//     (knn_filter_kernel): per-key queue.  A query whose certificate does not hold is recomputed exactly.
+//     (filter2_wave, events of 2048..65536 nodes): per-tile hit masks, threshold from tile minima; first form
+//     (filter1_wave): per-key queue; one launch (knn_filter12_kernel), each wavefront takes the form its event calls
+//     for.  A query whose certificate does not hold is recomputed exactly.
 //   * everything else, and the recomputation: the exact kernel below (knn_kernel).
 //
 // The exact kernel is fp32-VALU bound (a subtract and an fma per (query, candidate, feature); the difference form
@@ -151,7 +152,7 @@ __device__ __attribute__((noinline)) float drain_queue(const uint2 (*queue)[kWav
 __device__ unsigned long long g_knn_stamps[1 << 16][4];
 #endif
 
-// events the second matrix-core filter form sweeps (knn_filter2_kernel); the plan counts the others
+// events the second matrix-core filter form sweeps (filter2_wave); the plan counts the others
 constexpr int kF2MinNodes = 2048;   // smaller events: first form (tau of the second form needs M tiles to exist at all)
 constexpr int kF2MaxNodes = 65536;  // tile number must fit 11 bits
 
@@ -629,7 +630,7 @@ struct KnnFilterArgs {
     uint8_t *qflag;             // [N] 1 = uncertified query
     const int32_t *xtile_ptr;   // tile prefix of the exact kernel's plan (same event order)
     int xtile_queries;
-    int form2;                  // 1: events of kF2MinNodes..kF2MaxNodes nodes are swept by knn_filter2_kernel
+    int form2;                  // 1: events of kF2MinNodes..kF2MaxNodes nodes are swept by the second form
 };
 
 __device__ __forceinline__ unsigned bf16_rne_bits(float f)   // finite inputs
@@ -879,24 +880,24 @@ __device__ __forceinline__ float chain_dist32(const float *__restrict__ xj, cons
     return acc;
 }
 
-// events of the second form (knn_filter2_kernel below): kF2MinNodes .. kF2MaxNodes nodes (constants with the plan)
+// events of the second form (filter2_wave below): kF2MinNodes .. kF2MaxNodes nodes (constants with the plan)
 __device__ __forceinline__ bool f2_in_domain(int n) { return n >= kF2MinNodes && n <= kF2MaxNodes; }
 
+// One wavefront's item of the first form (work item `group * kWavesPerGroup + wv` of the plan); Q is the wavefront's
+// own LDS.  No workgroup barrier inside: wavefronts of one workgroup may run different forms (knn_filter12_kernel).
 template <int KP>
-__global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(const KnnFilterArgs a)
+__device__ __forceinline__ void filter1_wave(const KnnFilterArgs &a, FilterQueue<filter_queue_len(filter_list_len(KP))> &Q,
+                                             int group, int wv, int lane)
 {
     constexpr int M = filter_list_len(KP);
     constexpr int QF = filter_queue_len(M);
     constexpr int MS = (M + 1 + 3) & ~3;   // list stride in the workspace: M entries, then tau (d array) / overflow (j array)
-    __shared__ FilterQueue<QF> queue_all[kWavesPerGroup];
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int col = lane & 31, hh = lane >> 5;
-    const int item = blockIdx.x * kWavesPerGroup + wv;
+    const int item = group * kWavesPerGroup + wv;
     const uint8_t *__restrict__ rec = a.rec;
     const int64_t *__restrict__ ptr = a.ptr;
-    FilterQueue<QF> &Q = queue_all[wv];
 
-    if (a.form2 && a.plan->form1_events == 0) return;      // every event is swept by knn_filter2_kernel
+    if (a.form2 && a.plan->form1_events == 0) return;      // every event is swept by the second form
     const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
     int tile = item, sub = 0, nsub = 1;
     if (item >= n_full) {
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
     const int pos = find_tile_event(a.tile_ptr, a.B, tile);
     const int ev = a.order[pos];
     const int ev_lo = (int)ptr[ev], ev_hi = (int)ptr[ev + 1];
-    if (a.form2 && f2_in_domain(ev_hi - ev_lo)) return;   // swept by knn_filter2_kernel
+    if (a.form2 && f2_in_domain(ev_hi - ev_lo)) return;   // swept by the second form
     const int q_first = ev_lo + (tile - a.tile_ptr[pos]) * kFQ;
     int clo = ev_lo, chi = ev_hi;
     if (nsub > 1) {
@@ -1135,6 +1136,15 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
     }
 }
 
+// first form alone: DMET_KNN_FILTER=1 (every event), A/B timing
+template <int KP>
+__global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(const KnnFilterArgs a)
+{
+    __shared__ FilterQueue<filter_queue_len(filter_list_len(KP))> queue_all[kWavesPerGroup];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    filter1_wave<KP>(a, queue_all[wv], (int)blockIdx.x, wv, lane);
+}
+
 
 // ---- filter, second form ("tile masks"): events of kF2MinNodes .. 65536 nodes ------------------------------------------
 // Budget of the first form at 64 x 4500 x 32 (tools/knn_budget.sh, ablation builds): once the operands arrive as
@@ -1328,25 +1338,25 @@ __device__ __forceinline__ void f2_sweep(F2Lane<M> &L, F2Wave &S, const uint8_t 
     }
 }
 
+// Plan group of a workgroup.  Whole-sweep tiles: the workgroups of one XCD take one contiguous eighth of the tile list
+// (see xcd_dealt_position); the split tail tiles that follow stay interleaved over the XCDs.
+__device__ __forceinline__ int filter_group(const KnnFilterArgs &a)
+{
+    const int full_groups = a.plan->n_full / kWavesPerGroup;   // n_full is a multiple of the SIMD count
+    return (int)blockIdx.x < full_groups ? xcd_swizzle((int)blockIdx.x, full_groups) : (int)blockIdx.x;
+}
+
+// One wavefront's item of the second form; S is the wavefront's own LDS (no workgroup barrier inside).
 template <int KP>
-__global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter2_kernel(const KnnFilterArgs a)
+__device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, int group, int wv, int lane)
 {
     constexpr int M = filter_list_len(KP);
     constexpr int MS = (M + 1 + 3) & ~3;
-    __shared__ F2Wave sh_all[kWavesPerGroup];
-    // the wavefront number is wave-uniform, but only readfirstlane tells the compiler: without it the tile, the event,
-    // the loop counters and every record address are computed per lane on the vector ALU
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int col = lane & 31, hh = lane >> 5;
     const uint8_t *__restrict__ rec = a.rec;
     const int64_t *__restrict__ ptr = a.ptr;
-    F2Wave &S = sh_all[wv];
 
     const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
-    // whole-sweep tiles: the workgroups of one XCD take one contiguous eighth of the tile list (see xcd_dealt_position);
-    // the split tail tiles that follow stay interleaved over the XCDs
-    const int full_groups = n_full / kWavesPerGroup;   // n_full is a multiple of the SIMD count
-    const int group = (int)blockIdx.x < full_groups ? xcd_swizzle((int)blockIdx.x, full_groups) : (int)blockIdx.x;
     const int item = group * kWavesPerGroup + wv;
     int tile = item, sub = 0, nsub = 1;
     if (item >= n_full) {
@@ -1576,6 +1586,25 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter2_kernel(
     for (int p = 0; p < KP; ++p) { ld[p] = kd[p]; lj[p] = kj[p]; }
     ld[M] = tau;
     lj[M] = L.overflow ? 1 : 0;
+}
+
+// Both forms in ONE launch: a wavefront takes the form its item's event calls for.  Batches that mix event sizes
+// (configs[4]: 500-8000 nodes) used to pay a second, nearly empty launch for their events below kF2MinNodes -- a few
+// hundred long serial items on an otherwise idle chip (216 us at 64 events) -- which now run beside the second form's
+// items.  The wavefront number is wave-uniform, but only readfirstlane tells the compiler: without it the tile, the
+// event, the loop counters and every record address are computed per lane on the vector ALU.
+template <int KP>
+__global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter12_kernel(const KnnFilterArgs a)
+{
+    union WaveLds {
+        F2Wave f2;
+        FilterQueue<filter_queue_len(filter_list_len(KP))> f1;
+    };
+    __shared__ WaveLds sh_all[kWavesPerGroup];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int group = filter_group(a);
+    filter2_wave<KP>(a, sh_all[wv].f2, group, wv, lane);   // returns at once unless the item's event is a second-form event
+    filter1_wave<KP>(a, sh_all[wv].f1, group, wv, lane);   // likewise
 }
 
 // Split (tail) tiles of the second form: merge the two exact partial lists of a query by (d, j) and certify against
@@ -2016,11 +2045,12 @@ int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, cons
     DMET_LAUNCH_CHECK("knn_prep_kernel");
     const int64_t ftiles_max = (f.N + kFQ - 1) / kFQ + f.B;
     const int64_t fblocks = (ftiles_max + slots + kWavesPerGroup - 1) / kWavesPerGroup;
-    hipLaunchKernelGGL((knn_filter_kernel<KF>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
-    DMET_LAUNCH_CHECK("knn_filter_kernel");
     if (f.form2) {
-        hipLaunchKernelGGL((knn_filter2_kernel<KF>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
-        DMET_LAUNCH_CHECK("knn_filter2_kernel");
+        hipLaunchKernelGGL((knn_filter12_kernel<KF>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
+        DMET_LAUNCH_CHECK("knn_filter12_kernel");
+    } else {
+        hipLaunchKernelGGL((knn_filter_kernel<KF>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
+        DMET_LAUNCH_CHECK("knn_filter_kernel");
     }
     constexpr int kRerankQpb = 4 * (kWave / filter_list_len(KF));
     constexpr int kRerankParts = (kFQ + kRerankQpb - 1) / kRerankQpb;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/knn_budget2.sh : cycle budget of knn_filter2_kernel by ablation builds + rocprofv3 kernel durations (GPU box).
+# tools/knn_budget2.sh : cycle budget of the second filter form (knn_filter12_kernel) by ablation builds + rocprofv3 kernel durations (GPU box).
 #   DMET_F2_ABL 1 = no exact re-rank; 2 = + no hit masks / entries; 3 = + no tile minima / tau; 4 = + no half-wave swap
 set -e
 cd "$(dirname "$0")/.."
