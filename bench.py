@@ -255,7 +255,7 @@ def gather_roofline(args, ksum, ev_overhead_ms, model, x, batch, ptr, sizes, sta
         except Exception:
             pass
     # untimed legs: the same kernel form standalone, warm and cold
-    if gname == "gather_max" and args.dtype == "f32" and not args.hip_graph:
+    if gname == "gather_max" and args.dtype == "f32":
         try:
             with torch.no_grad():
                 from deepmetv2_amd import conv as conv_mod
@@ -263,7 +263,14 @@ def gather_roofline(args, ksum, ev_overhead_ms, model, x, batch, ptr, sizes, sta
                 P, Q = _native.node_linear_split(emb, lin.weight, lin.bias, sliced=lds)
                 want_arg = args.mode == "train"
 
+                step_kernel = _native.last_gather_kernel
+                rows16 = getattr(table, "rows16", None)
+                winner_ids = table.cnt is not None and lds and want_arg and table.nonempty and rows16 is not None
+
                 def launch():
+                    if winner_ids:      # the form the static flow's training step runs (conv._EdgeConvLinearMax)
+                        return _native.gather_max_local_j16(P, Q, rows16, table.cnt, table.order_by_count(), table.ptr,
+                                                            table.k, lds)
                     return _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=want_arg, cnt=table.cnt, lds=lds,
                                               nbr_local=table.nbr_local, sliced=lds)
 
@@ -281,6 +288,7 @@ def gather_roofline(args, ksum, ev_overhead_ms, model, x, batch, ptr, sizes, sta
                     return ts[len(ts) // 2]
 
                 launch(); torch.cuda.synchronize(dev)
+                roof["legs_kernel_matches_step"] = _native.last_gather_kernel == step_kernel
                 warm_ms, cold_ms = timed(False), timed(True)
                 roof["standalone_warm"] = {"us": round(warm_ms * 1e3, 2), "frac": round(alg_bytes / (warm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                 roof["cold_us"] = round(cold_ms * 1e3, 2)
@@ -359,10 +367,12 @@ def main():
                 b = next(feed)
                 return train_step(model, flat, sync, opt, b.x, b.y, b.batch, b.ptr)
         elif args.hip_graph:
-            if args.graph != "dynamic":
-                raise SystemExit("--hip-graph: the static flow sizes its edge_index on the host (one sync per step)")
+            if args.graph == "static":
+                raise SystemExit("--hip-graph: radius_graph sizes its [2,E] result on the host (one sync per step); "
+                                 "use --graph static-table")
             from deepmetv2_amd.parallel import GraphedTrainStep
-            step = GraphedTrainStep(model, flat, sync, opt, x, y, batch, ptr)
+            step = GraphedTrainStep(model, flat, sync, opt, x, y, batch, ptr,
+                                    graph_fn=(lambda _x: static_graph()) if args.graph == "static-table" else None)
         else:
             def step():
                 return train_step(model, flat, sync, opt, x, y, batch, ptr, edge_index=static_graph())
@@ -396,6 +406,22 @@ def main():
     elapsed = time.perf_counter() - t0
     _native.timer.enabled = False
     ksum = _native.timer.summary()
+    roof_leg = None
+    if args.hip_graph and args.mode == "train":
+        # kernels inside a replayed hipGraph cannot be bracketed with events: the per-kernel figures of a --hip-graph run
+        # come from a few eager steps of the same training step after the timed region (said so in the roofline block)
+        def eager_step():
+            return train_step(model, flat, sync, opt, x, y, batch, ptr, edge_index=static_graph())
+        eager_step(); torch.cuda.synchronize(dev)
+        _native.timer.only = None
+        _native.timer.enabled = True
+        _native.timer.reset()
+        for _ in range(min(5, args.steps)):
+            eager_step()
+        torch.cuda.synchronize(dev)
+        _native.timer.enabled = False
+        ksum = _native.timer.summary()
+        roof_leg = "eager steps after the timed region (the timed steps replay hipGraphs, whose kernels cannot be bracketed)"
     if not args.hip_graph:
         _native.timer.only = None
         _native.timer.enabled = True
@@ -414,6 +440,8 @@ def main():
     if rank == 0:
         events = B * world * args.steps
         roof = gather_roofline(args, ksum, ev_overhead_ms, model, x, batch, ptr, sizes, static_graph if args.mode == "train" else None, dev)
+        if roof is not None and roof_leg is not None:
+            roof["measured_in"] = roof_leg
         kernels = {}
         for name, (cnt, ms) in sorted(ksum.items()):
             kernels[name] = {"launches": cnt, "avg_us": round(ms * 1e3, 2)}

@@ -30,6 +30,7 @@ SIGNATURES = {
     "dmet_radius_counted_f32": (_i, [_vp, _vp, _i, _i64, _i, _f, _i, _i, _vp, _vp, _vp]),
     "dmet_radius_workspace_bytes": (_sz, [_i64]),
     "dmet_radius_windowed_f32": (_i, [_vp, _vp, _i, _i64, _i, _f, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "dmet_radius_windowed_local_f32": (_i, [_vp, _vp, _i, _i64, _i, _f, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "dmet_edgeconv_linear_workspace_bytes": (_sz, [_i64, _i]),
     "dmet_edgeconv_linear_max_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_edgeconv_fused_lds_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -45,6 +46,7 @@ SIGNATURES = {
     "dmet_edge_mlp2_bf16": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "dmet_table_order_by_count": (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
     "dmet_gather_max_counted_lds_j16_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    "dmet_gather_max_local_j16_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "dmet_gather_max_bwd_j16_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp]),
     "dmet_gather_max_mixed_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "dmet_node_linear_split_bf16": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -156,9 +156,12 @@ def knn_local(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict] 
 
 
 def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int, skip_self: bool = False,
-           pad: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+           pad: bool = True, local: bool = False):
     """(nbr[N,max_nbr] int32, cnt[N] int32).  pad=False leaves the slots >= cnt[i] unwritten instead of filling them
-    with -1 (the fill is most of a 255-wide table's bytes); only for consumers that go by cnt."""
+    with -1 (the fill is most of a 255-wide table's bytes); only for consumers that go by cnt.
+    local=True: a third result, the rows again as event-local uint16 ids (int16-typed [N, roundup8(max_nbr)], slots
+    cnt[i] .. roundup8(cnt[i]) - 1 = 0xFFFF, the rest unwritten) for gather_max_local_j16; None when the all-pairs
+    form is selected."""
     dev = _require_device(x, ptr)
     L = _lib.load()
     x = _f32c(x.detach(), "x")
@@ -166,6 +169,20 @@ def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int, skip_self
     B = ptr.numel() - 1
     nbr = torch.empty((N, max_nbr), dtype=torch.int32, device=dev)
     cnt = torch.empty((N,), dtype=torch.int32, device=dev)
+    if local:
+        rows16 = None
+        if RADIUS_FORM != "sweep":
+            stride16 = (max_nbr + 7) // 8 * 8
+            rows16 = torch.empty((N, stride16), dtype=torch.int16, device=dev)
+            ws = _ws(L.dmet_radius_workspace_bytes(N), dev)
+            with torch.cuda.device(dev):
+                _lib.check(L.dmet_radius_windowed_local_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, float(r), max_nbr,
+                                                            1 if skip_self else 0, 1 if pad else 0, nbr.data_ptr(),
+                                                            cnt.data_ptr(), rows16.data_ptr(), stride16, ws.data_ptr(),
+                                                            ws.numel(), _stream(dev)), "dmet_radius_windowed_local_f32")
+            return nbr, cnt, rows16
+        nbr, cnt = radius(x, ptr, r, max_nbr, skip_self, pad)
+        return nbr, cnt, None
     with torch.cuda.device(dev):
         if RADIUS_FORM == "sweep":      # all pairs of an event (A/B and fallback)
             fn = L.dmet_radius_f32 if pad else L.dmet_radius_counted_f32
@@ -333,6 +350,31 @@ def gather_max_counted_j16(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, 
                                                          order.data_ptr() if order is not None else None, ptr.data_ptr(),
                                                          ptr.numel() - 1, N, k, H, 1 if sliced else 0, out.data_ptr(),
                                                          argj.data_ptr(), _stream(dev)), "dmet_gather_max_counted_lds_j16_f32")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
+    return out, argj
+
+
+def gather_max_local_j16(P: torch.Tensor, Q: torch.Tensor, rows16: torch.Tensor, cnt: torch.Tensor,
+                         order: Optional[torch.Tensor], ptr: torch.Tensor, kmax: int, sliced: bool):
+    """gather_max_counted_j16 reading the ids from the uint16 rows of radius(..., local=True): identical (out, argj)."""
+    dev = _require_device(P, Q, rows16, cnt, ptr)
+    L = _lib.load()
+    if sliced:
+        N, H = P.shape[1], P.shape[0] * 8
+    else:
+        N, H = P.shape
+    out = torch.empty((N, H), dtype=torch.float32, device=dev)
+    argj = torch.empty((N, H), dtype=torch.int16, device=dev)
+    _t = timer.record('gather_max', dev)
+    _note_gather("gather_max_lds_kernel, counted rows (radius table as event-local uint16 rows; Q slice resident in LDS, "
+                 "winner ids, rows ordered by depth" + (", slice-major P/Q)" if sliced else ")"))
+    with torch.cuda.device(dev):
+        _lib.check(L.dmet_gather_max_local_j16_f32(P.data_ptr(), Q.data_ptr(), rows16.data_ptr(), rows16.shape[1],
+                                                   cnt.data_ptr(), order.data_ptr() if order is not None else None,
+                                                   ptr.data_ptr(), ptr.numel() - 1, N, kmax, H, 1 if sliced else 0,
+                                                   out.data_ptr(), argj.data_ptr(), _stream(dev)),
+                   "dmet_gather_max_local_j16_f32")
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))
     return out, argj

@@ -86,9 +86,10 @@ def radius_table(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None
     m = max_num_neighbors if loop else max_num_neighbors + 1
     info = batch_info(batch, x.shape[0], x.device, num_events)
     # no -1 fill of the unused slots: every consumer of a table with `cnt` goes by cnt
-    nbr, _cnt = _native.radius(x, info.ptr, r, m, skip_self=not loop, pad=False)
+    nbr, _cnt, rows16 = _native.radius(x, info.ptr, r, m, skip_self=not loop, pad=False, local=True)
     # with self loops every node finds at least itself (the cap counts hits in index order, but a full row is not empty)
-    return NeighborTable(nbr, info.ptr, dense=False, max_nodes=info.max_nodes, cnt=_cnt, nonempty=bool(loop))
+    return NeighborTable(nbr, info.ptr, dense=False, max_nodes=info.max_nodes, cnt=_cnt, nonempty=bool(loop),
+                         rows16=rows16)
 
 
 def radius_graph(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None, loop: bool = False,

@@ -88,7 +88,11 @@ class _EdgeConvLinearMax(torch.autograd.Function):
             # needs no look-up in the 255-wide table, and walk the rows in order of their depth
             ctx.j16 = (lds and need_grad and table.nonempty and _native.GATHER_MAX_FORM == "auto"
                        and os.environ.get("DMET_RADIUS_J16", "1") != "0")
-            if ctx.j16:
+            if ctx.j16 and table.rows16 is not None and os.environ.get("DMET_RADIUS_IDS", "rows16") == "rows16":
+                # ids from the event-local uint16 copy of the rows that the radius kernel wrote
+                out, arg = _native.gather_max_local_j16(P, Q, table.rows16, table.cnt, table.order_by_count(), table.ptr,
+                                                        table.k, sliced)
+            elif ctx.j16:
                 out, arg = _native.gather_max_counted_j16(P, Q, table.nbr, table.cnt, table.order_by_count(), table.ptr,
                                                           sliced)
             else:

@@ -681,11 +681,17 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
 // none) -- the backward scatter then needs no look-up in the 255-wide table (dmet_gather_max_bwd_j16_f32).
 // `order` (optional): the event's nodes are processed in this order (table_order_kernel: by slot count), so that the
 // lane pairs of a wavefront walk rows of similar depth.
-template <bool WITH_ARG, bool SLICED, bool ARGJ = false>
+// LOC16: the ids come from the event-local uint16 copy of the rows that the radius kernel writes
+// (dmet_radius_windowed_local_f32: rows of stride16 ids, 16-byte aligned, every started chunk of 8 padded with 0xFFFF):
+// one aligned 16-byte load per 8 slots.  Out of the 255-wide int32 table every lane pair reads its 1020-byte-strided
+// row with two unaligned 16-byte loads per 8 slots, each touching 32 cache lines per wavefront, re-read once per
+// slice: the texture path, not the vector ALU, bounded that form (103 -> 75 us at 64 x 4500 nodes, 35 ids per row).
+template <bool WITH_ARG, bool SLICED, bool ARGJ = false, bool LOC16 = false>
 __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_counted_kernel(
     const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ nbr,
     const int32_t *__restrict__ cnt, const int64_t *__restrict__ ptr, int B, int kmax, int H,
-    float *__restrict__ out, uint8_t *__restrict__ arg, int64_t N, const int32_t *__restrict__ order = nullptr)
+    float *__restrict__ out, uint8_t *__restrict__ arg, int64_t N, const int32_t *__restrict__ order = nullptr,
+    const uint16_t *__restrict__ nbr16 = nullptr, int stride16 = 0)
 {
     __shared__ __attribute__((aligned(16))) float4 qs[kLdsGatherRows * 2];   // [n_b + 1][2] float4 = 8 channels/node
     constexpr int RPI = kLdsGatherThreads / 2;
@@ -733,6 +739,29 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_counted_kern
         constexpr int kNone = ARGJ ? 0xFFFF : 255;
         int a0 = kNone, a1 = kNone, a2 = kNone, a3 = kNone;
         bool any = false;
+        if (LOC16) {
+            any = m > 0;
+            const uint16_t *r16 = nbr16 + node * stride16;
+            for (int s0 = 0; s0 < m; s0 += 8) {
+                const uint4 w = *reinterpret_cast<const uint4 *>(r16 + s0);
+                const unsigned jl[8] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16,
+                                        w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};   // 0xFFFF = none
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (in_lds) v[u] = qs[min(jl[u], (unsigned)n) * 2 + half];
+                    else v[u] = (jl[u] != 0xFFFFu) ? Q4[pq_at(lo + (int64_t)jl[u])] : make_float4(ninf, ninf, ninf, ninf);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int tag = ARGJ ? (int)jl[u] : (s0 + u);
+                    if (v[u].x > best.x) { best.x = v[u].x; a0 = tag; }
+                    if (v[u].y > best.y) { best.y = v[u].y; a1 = tag; }
+                    if (v[u].z > best.z) { best.z = v[u].z; a2 = tag; }
+                    if (v[u].w > best.w) { best.w = v[u].w; a3 = tag; }
+                }
+            }
+        } else
         for (int s0 = 0; s0 < m; s0 += 8) {
             int32_t j[8];
             float4 v[8];
@@ -1446,6 +1475,38 @@ extern "C" int dmet_table_order_by_count(const int32_t *cnt, const int64_t *ptr,
     DMET_REQUIRE(cnt && ptr && order, "dmet_table_order_by_count: null pointer");
     hipLaunchKernelGGL(table_order_kernel, dim3((unsigned)B), dim3(1024), 0, as_stream(stream), cnt, ptr, B, order);
     DMET_LAUNCH_CHECK("table_order_kernel");
+    return 0;
+}
+
+extern "C" int dmet_gather_max_local_j16_f32(const float *P, const float *Q, const uint16_t *nbr16, int stride16,
+                                             const int32_t *cnt, const int32_t *order, const int64_t *ptr, int B,
+                                             int64_t N, int kmax, int H, int pq_sliced, float *out, uint16_t *argj,
+                                             dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_gather_max_local_j16_f32: N out of range");
+    DMET_REQUIRE(kmax >= 1 && kmax <= 255 && stride16 >= kmax && stride16 % 8 == 0,
+                 "dmet_gather_max_local_j16_f32: kmax=%d stride16=%d", kmax, stride16);
+    DMET_REQUIRE(H >= kSliceC && H % kSliceC == 0 && H <= DMET_MAX_H,
+                 "dmet_gather_max_local_j16_f32: H=%d must be a multiple of %d", H, kSliceC);
+    if (N == 0 || B == 0) return 0;
+    DMET_REQUIRE(P && Q && nbr16 && cnt && ptr && out && argj, "dmet_gather_max_local_j16_f32: null pointer");
+    DMET_REQUIRE(aligned16(P) && aligned16(Q) && aligned16(out) && aligned16(nbr16) &&
+                     (reinterpret_cast<uintptr_t>(argj) & 7u) == 0,
+                 "dmet_gather_max_local_j16_f32: pointers must be 16-B (argj: 8-B) aligned");
+    const int nsl = H / kSliceC;
+    const int64_t groups = (B + kNumXcd - 1) / kNumXcd;
+    const int64_t blocks = groups * kNumXcd * nsl;
+    hipStream_t st = as_stream(stream);
+    uint8_t *a8 = reinterpret_cast<uint8_t *>(argj);
+    if (pq_sliced)
+        hipLaunchKernelGGL((gather_max_lds_counted_kernel<true, true, true, true>), dim3((unsigned)blocks),
+                           dim3(kLdsGatherThreads), 0, st, P, Q, nullptr, cnt, ptr, B, kmax, H, out, a8, N, order, nbr16,
+                           stride16);
+    else
+        hipLaunchKernelGGL((gather_max_lds_counted_kernel<true, false, true, true>), dim3((unsigned)blocks),
+                           dim3(kLdsGatherThreads), 0, st, P, Q, nullptr, cnt, ptr, B, kmax, H, out, a8, N, order, nbr16,
+                           stride16);
+    DMET_LAUNCH_CHECK("gather_max_lds_counted_kernel (uint16 rows)");
     return 0;
 }
 

@@ -2302,13 +2302,20 @@ __global__ __launch_bounds__(kWave * 4) void radius_window_kernel(const float *_
                                                                    int D, float r2, int max_nbr, int skip_self,
                                                                    const int32_t *__restrict__ order,
                                                                    int32_t *__restrict__ nbr,
-                                                                   int32_t *__restrict__ cntout)
+                                                                   int32_t *__restrict__ cntout,
+                                                                   uint16_t *__restrict__ nbr16, int stride16)
 {
     __shared__ f2 tile_all[4][(kRadTile / 2) * DP];
     __shared__ int queue_all[4][kRadQueue];
+    // hits leave the lane through 16-byte staging slots (4 int32 ids / 8 uint16 ids) and reach memory as one 16-byte
+    // store per full slot: a wavefront's 64 scattered 2- or 4-byte stores per hit cost more than the distances
+    __shared__ __attribute__((aligned(16))) int32_t stage32_all[4][kWave][4];
+    __shared__ __attribute__((aligned(16))) uint16_t stage16_all[4][kWave][8];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     f2 *tile = tile_all[wv];
     int *queue = queue_all[wv];
+    int32_t *stage32 = stage32_all[wv][lane];
+    uint16_t *stage16 = stage16_all[wv][lane];
     // wavefronts are aligned to events: event b owns the wavefront ids from (ptr[b] >> 6) + b on (strictly increasing
     // in b and at least ceil(n_b / 64) apart, so no prefix sum over the events is needed); surplus ids idle
     const int64_t w = (int64_t)blockIdx.x * 4 + wv;
@@ -2347,6 +2354,8 @@ __global__ __launch_bounds__(kWave * 4) void radius_window_kernel(const float *_
     }
     int stored = 0, seen = valid ? 0 : max_nbr;        // idle lanes are "full" from the start
     int32_t *row = nbr + qq * max_nbr;
+    // optional second copy of the row as event-local uint16 ids (rows of stride16 ids, 16-byte aligned)
+    uint16_t *row16 = nbr16 ? nbr16 + qq * stride16 : nullptr;
     int pending = 0;                                    // wave-uniform: ids waiting in the queue
 
     // sweep of one tile: the first `cntc` queue entries (ascending node ids)
@@ -2383,7 +2392,18 @@ __global__ __launch_bounds__(kWave * 4) void radius_window_kernel(const float *_
                 mask &= mask - 1ull;
                 const int j = queue[bit];
                 if (seen < max_nbr && j >= lo && j < hi) {   // own event only (wavefronts that straddle two events)
-                    if (!(skip_self && j == (int)qq)) { row[stored] = j; ++stored; }
+                    if (!(skip_self && j == (int)qq)) {
+                        stage32[stored & 3] = j;
+                        if (row16) stage16[stored & 7] = (uint16_t)(j - lo);
+                        ++stored;
+                        if ((stored & 3) == 0) {   // rows are only 4-byte aligned (255-wide tables)
+                            struct __attribute__((packed, aligned(4))) I4 { int32_t a, b, c, d; };
+                            const int4 v = *reinterpret_cast<const int4 *>(stage32);
+                            *reinterpret_cast<I4 *>(row + stored - 4) = I4{v.x, v.y, v.z, v.w};
+                        }
+                        if (row16 && (stored & 7) == 0)
+                            *reinterpret_cast<uint4 *>(row16 + stored - 8) = *reinterpret_cast<const uint4 *>(stage16);
+                    }
                     ++seen;
                 }
             }
@@ -2410,7 +2430,14 @@ __global__ __launch_bounds__(kWave * 4) void radius_window_kernel(const float *_
         }
     }
     if (pending > 0 && __any(seen < max_nbr)) sweep(pending);
-    if (valid) cntout[qq] = stored;
+    if (valid) {
+        cntout[qq] = stored;
+        for (int s = stored & ~3; s < stored; ++s) row[s] = stage32[s & 3];     // the unfinished slots
+        if (row16 && (stored & 7) != 0) {   // the last started chunk of 8 reads as "no neighbour" beyond the row's end
+            for (int s = stored & 7; s < 8; ++s) stage16[s] = 0xFFFFu;
+            *reinterpret_cast<uint4 *>(row16 + (stored & ~7)) = *reinterpret_cast<const uint4 *>(stage16);
+        }
+    }
 }
 
 }  // namespace
@@ -2515,10 +2542,14 @@ extern "C" size_t dmet_radius_workspace_bytes(int64_t N)
     return N > 0 ? sizeof(int32_t) * (size_t)N + 512 : 0;
 }
 
-extern "C" int dmet_radius_windowed_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r,
-                                        int max_nbr, int skip_self, int fill, int32_t *nbr, int32_t *cnt, void *ws,
-                                        size_t ws_bytes, dmet_stream_t stream)
+extern "C" int dmet_radius_windowed_local_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r,
+                                              int max_nbr, int skip_self, int fill, int32_t *nbr, int32_t *cnt,
+                                              uint16_t *nbr16, int stride16, void *ws, size_t ws_bytes,
+                                              dmet_stream_t stream)
 {
+    DMET_REQUIRE(!nbr16 || (stride16 >= max_nbr && stride16 % 8 == 0 && aligned16(nbr16)),
+                 "dmet_radius_windowed_local_f32: nbr16 rows need a 16-byte aligned stride of >= max_nbr ids (stride16=%d)",
+                 stride16);
     DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_radius_windowed_f32: N out of range");
     DMET_REQUIRE(D >= 1 && D <= 8, "dmet_radius_windowed_f32: D=%d not in [1,8]", D);
     DMET_REQUIRE(max_nbr >= 1, "dmet_radius_windowed_f32: max_nbr=%d", max_nbr);
@@ -2537,13 +2568,21 @@ extern "C" int dmet_radius_windowed_f32(const float *x, const int64_t *ptr, int 
     DMET_LAUNCH_CHECK("radius_order_kernel");
     if (D <= 2)
         hipLaunchKernelGGL((radius_window_kernel<2>), dim3((unsigned)blocks), dim3(kWave * 4), 0, st, x, ptr, B, N, D, r2,
-                           max_nbr, skip_self, order, nbr, cnt);
+                           max_nbr, skip_self, order, nbr, cnt, nbr16, stride16);
     else if (D <= 4)
         hipLaunchKernelGGL((radius_window_kernel<4>), dim3((unsigned)blocks), dim3(kWave * 4), 0, st, x, ptr, B, N, D, r2,
-                           max_nbr, skip_self, order, nbr, cnt);
+                           max_nbr, skip_self, order, nbr, cnt, nbr16, stride16);
     else
         hipLaunchKernelGGL((radius_window_kernel<8>), dim3((unsigned)blocks), dim3(kWave * 4), 0, st, x, ptr, B, N, D, r2,
-                           max_nbr, skip_self, order, nbr, cnt);
+                           max_nbr, skip_self, order, nbr, cnt, nbr16, stride16);
     DMET_LAUNCH_CHECK("radius_window_kernel");
     return 0;
+}
+
+extern "C" int dmet_radius_windowed_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r,
+                                        int max_nbr, int skip_self, int fill, int32_t *nbr, int32_t *cnt, void *ws,
+                                        size_t ws_bytes, dmet_stream_t stream)
+{
+    return dmet_radius_windowed_local_f32(x, ptr, B, N, D, r, max_nbr, skip_self, fill, nbr, cnt, nullptr, 0, ws, ws_bytes,
+                                          stream);
 }

@@ -160,8 +160,10 @@ class NeighborTable:
 
     def __init__(self, nbr: torch.Tensor, ptr: Optional[torch.Tensor], dense: bool, dist: Optional[torch.Tensor] = None,
                  max_nodes: Optional[int] = None, cnt: Optional[torch.Tensor] = None,
-                 nbr_local: Optional[torch.Tensor] = None, nonempty: bool = False):
+                 nbr_local: Optional[torch.Tensor] = None, nonempty: bool = False,
+                 rows16: Optional[torch.Tensor] = None):
         self.nbr = nbr
+        self.rows16 = rows16        # counted tables: the rows again as event-local uint16 ids (_native.radius(local=True))
         self.nonempty = nonempty    # True: every row holds at least one entry (tables built with self loops)
         self._order = None
         self.nbr_local = nbr_local  # optional int16-typed [N,k]: the same table as event-local uint16 ids (knn_local)

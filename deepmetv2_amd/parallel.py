@@ -138,7 +138,11 @@ class GraphedTrainStep:
     step is GPU-bound and the two forms time the same.  The inputs are static buffers: refill them with `load`.
     The optimizer must be built with capturable=True; batch metadata must be registered (no host sync in forward)."""
 
-    def __init__(self, model, flat: FlatModule, sync: GradSync, optimizer, x, y, batch, ptr=None, warmup: int = 3):
+    def __init__(self, model, flat: FlatModule, sync: GradSync, optimizer, x, y, batch, ptr=None, warmup: int = 3,
+                 graph_fn=None):
+        """graph_fn(x) -> the static graph of the batch (the reference's active flow, train.py:45-48), built INSIDE the
+        captured step; it must not synchronise with the host, i.e. return a NeighborTable (dm.radius_table), not
+        radius_graph's [2,E] tensor.  None: the model builds its kNN graphs itself (dynamic flow)."""
         from .model import loss_fn, split_features
         self.flat, self.sync, self.opt = flat, sync, optimizer
         self.x, self.y, self.batch, self.ptr = x, y, batch, ptr
@@ -146,7 +150,8 @@ class GraphedTrainStep:
         def fwd_bwd():
             flat.zero_grad()
             x_cont, x_cat = split_features(self.x)
-            loss = loss_fn(model(x_cont, x_cat, None, self.batch), self.x, self.y, self.batch, ptr=self.ptr)
+            graph = graph_fn(self.x) if graph_fn is not None else None
+            loss = loss_fn(model(x_cont, x_cat, graph, self.batch), self.x, self.y, self.batch, ptr=self.ptr)
             loss.backward()
             flat.gather_grads()
             return loss.detach()

@@ -89,6 +89,12 @@ size_t dmet_radius_workspace_bytes(int64_t N);
 int dmet_radius_windowed_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr,
                              int skip_self, int fill, int32_t *nbr, int32_t *cnt, void *ws, size_t ws_bytes,
                              dmet_stream_t stream);
+/* Same, and optionally a second copy of every row as EVENT-LOCAL uint16 ids (nbr16 != NULL: rows of stride16 ids,
+ * stride16 % 8 == 0, stride16 >= max_nbr, 16-byte aligned; slots cnt[i] .. roundup8(cnt[i]) - 1 hold 0xFFFF, the rest
+ * of the row is unwritten; meaningful for events of at most 65534 nodes) for dmet_gather_max_local_j16_f32. */
+int dmet_radius_windowed_local_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr,
+                                   int skip_self, int fill, int32_t *nbr, int32_t *cnt, uint16_t *nbr16, int stride16,
+                                   void *ws, size_t ws_bytes, dmet_stream_t stream);
 
 /* ---- K2+K3 fused: EdgeConv with nn = Linear(2*Hin -> Hout), aggr = 'max', fixed-width table ---------
  * replaces torch_geometric.nn.EdgeConv(nn=Sequential(Linear(2H,H)), aggr='max').forward
@@ -152,6 +158,13 @@ int dmet_table_order_by_count(const int32_t *cnt, const int64_t *ptr, int B, int
 int dmet_gather_max_counted_lds_j16_f32(const float *P, const float *Q, const int32_t *nbr, const int32_t *cnt,
                                         const int32_t *order, const int64_t *ptr, int B, int64_t N, int k, int H,
                                         int pq_sliced, float *out, uint16_t *argj, dmet_stream_t stream);
+/* Second form of the ids for the same gather: rows of event-local uint16 ids written by the radius kernel itself
+ * (dmet_radius_windowed_local_f32: nbr16[N][stride16], stride16 a multiple of 8 and >= max_nbr, 16-byte aligned; the
+ * last started chunk of 8 of every row is padded with 0xFFFF; events of at most 65534 nodes): one aligned 16-byte
+ * load per 8 slots, no packing pass.  Identical out / argj. */
+int dmet_gather_max_local_j16_f32(const float *P, const float *Q, const uint16_t *nbr16, int stride16,
+                                  const int32_t *cnt, const int32_t *order, const int64_t *ptr, int B, int64_t N,
+                                  int kmax, int H, int pq_sliced, float *out, uint16_t *argj, dmet_stream_t stream);
 /* gQ[j,c] = sum of g_out[i,c] over the (i,c) whose winner is j = ptr[event] + argj[i,c]: the per-event LDS scatter
  * with exact integer sums of dmet_gather_max_bwd_lds_f32 (bitwise reproducible), H = 32. */
 int dmet_gather_max_bwd_j16_f32(const float *g_out, const uint16_t *argj, const int64_t *ptr, int B, int64_t N, int H,

@@ -24,8 +24,21 @@ def knn_local(x, ptr, k, stats=None):
     return nbr, dist, loc
 
 
-def radius(x, ptr, r, max_nbr, skip_self=False, pad=True):
+def radius(x, ptr, r, max_nbr, skip_self=False, pad=True, local=False):
     import ctypes  # noqa: F401
+    if local:
+        nbr, cnt = radius(x, ptr, r, max_nbr, skip_self, pad)
+        stride16 = (max_nbr + 7) // 8 * 8
+        counts = (ptr[1:] - ptr[:-1]).long()
+        lo = torch.repeat_interleave(ptr[:-1], counts).view(-1, 1)
+        slot = torch.arange(stride16).view(1, -1)
+        loc = torch.zeros((nbr.shape[0], stride16), dtype=torch.long)
+        loc[:, :max_nbr] = nbr.long() - lo
+        c = cnt.long().view(-1, 1)
+        loc = torch.where(slot < c, loc, torch.full_like(loc, 0xFFFF))       # pad of the last chunk
+        loc = torch.where(slot < (c + 7) // 8 * 8, loc, torch.full_like(loc, 0x1234))   # unwritten: poison
+        loc &= 0xFFFF
+        return nbr, cnt, torch.where(loc >= 0x8000, loc - 0x10000, loc).to(torch.int16)
     x = x.detach().float().contiguous()
     N, D = x.shape
     nbr = torch.empty((N, max_nbr), dtype=torch.int32)
@@ -327,6 +340,17 @@ def gather_max_counted_j16(P, Q, nbr, cnt, order, ptr, sliced):
     return out, torch.where(j >= 0x8000, j - 0x10000, j).to(torch.int16)
 
 
+def gather_max_local_j16(P, Q, rows16, cnt, order, ptr, kmax, sliced):
+    """Rebuilds the int32 table from the uint16 rows (only slots < cnt are read) and runs the counted gather on it."""
+    N = cnt.numel()
+    counts = (ptr[1:] - ptr[:-1]).long()
+    lo = torch.repeat_interleave(ptr[:-1], counts).view(-1, 1)
+    ids = (rows16[:, :kmax].long() & 0xFFFF) + lo
+    slot = torch.arange(kmax).view(1, -1)
+    nbr = torch.where(slot < cnt.long().view(-1, 1), ids, torch.full_like(ids, 2 ** 30)).to(torch.int32)
+    return gather_max_counted_j16(P, Q, nbr, cnt, order, ptr, sliced)
+
+
 def gather_max_bwd_j16(g_out, argj, ptr):
     N, H = g_out.shape
     counts = (ptr[1:] - ptr[:-1]).long()
@@ -340,7 +364,7 @@ def gather_max_bwd_j16(g_out, argj, ptr):
     return gQ
 
 
-_NAMES = ["table_order_by_count", "gather_max_counted_j16", "gather_max_bwd_j16", "table_rowptr", "table_edges", "head_fwd", "head_bwd", "met_loss", "gather_max_bwd_lds", "edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "knn_local", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
+_NAMES = ["table_order_by_count", "gather_max_local_j16", "gather_max_counted_j16", "gather_max_bwd_j16", "table_rowptr", "table_edges", "head_fwd", "head_bwd", "met_loss", "gather_max_bwd_lds", "edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "knn_local", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",
           "edge_features_bwd", "segment_max", "segment_sum", "segment_max_bwd", "segment_sum_bwd", "met_reduce",
           "met_reduce_bwd", "segment_sum_1d", "batch_to_ptr", "xty", "onehot_xty", "edgeconv_fused_lds"]
 

@@ -817,9 +817,11 @@ def test_training_trajectory_matches_oracle(dev):
             torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-4, msg=lambda m, n=name: f"{n}: {m}")
 
 
-def test_graphed_train_step_matches_eager(dev):
+@pytest.mark.parametrize("flow", ["dynamic", "static-table"])
+def test_graphed_train_step_matches_eager(dev, flow):
     """H1: the step replayed as two hipGraphs (parallel.GraphedTrainStep) walks the same parameter trajectory as the
-    eager step (every kernel on the path is deterministic, so the comparison is bitwise)."""
+    eager step (every kernel on the path is deterministic, so the comparison is bitwise) -- for the kNN flow and for
+    the reference's active flow with the radius table built inside the captured step (train.py:45-48)."""
     import deepmetv2_amd as dm
     from deepmetv2_amd import synth
     from deepmetv2_amd.model import Net
@@ -827,16 +829,22 @@ def test_graphed_train_step_matches_eager(dev):
     sizes = [700, 90, 1300]
     x, y, batch, ptr = synth.make_events(sizes, seed=5, device=dev)
     dm.register_batch(batch, ptr, len(sizes), max_nodes=max(sizes))
+
+    def radius(xx):
+        etaphi = torch.stack([xx[:, 3], torch.atan2(xx[:, 1], xx[:, 0])], 1)
+        return dm.radius_table(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255)
+
+    graph_fn = radius if flow == "static-table" else None
     finals = []
     for graphed in (False, True):
         torch.manual_seed(1)
-        model = Net(8, 3, graph="dynamic", k=16).to(dev).train()
+        model = Net(8, 3, graph="dynamic" if flow == "dynamic" else "static", k=16).to(dev).train()
         flat = FlatModule(model); sync = GradSync(flat)
         opt = torch.optim.AdamW([flat.flat_param], lr=1e-3, capturable=True)
         if graphed:
             p0 = flat.flat_param.detach().clone()
             bufs0 = [b.detach().clone() for b in model.buffers()]
-            step = GraphedTrainStep(model, flat, sync, opt, x, y, batch, ptr, warmup=1)
+            step = GraphedTrainStep(model, flat, sync, opt, x, y, batch, ptr, warmup=1, graph_fn=graph_fn)
             # capture ran warm-up steps: rewind parameters, buffers and optimizer state
             with torch.no_grad():
                 flat.flat_param.copy_(p0)
@@ -850,7 +858,8 @@ def test_graphed_train_step_matches_eager(dev):
                 loss = step()
         else:
             for _ in range(3):
-                loss = train_step(model, flat, sync, opt, x, y, batch, ptr)
+                loss = train_step(model, flat, sync, opt, x, y, batch, ptr,
+                                  edge_index=graph_fn(x) if graph_fn is not None else None)
         torch.cuda.synchronize()
         finals.append((flat.flat_param.detach().clone(), float(loss)))
     assert finals[0][1] == finals[1][1]
@@ -984,6 +993,18 @@ def test_counted_gather_winner_ids_and_ordered_rows(dev):
         assert torch.equal(argj.long() & 0xFFFF, win)
         out2, argj2 = _native.gather_max_counted_j16(P, Q, t.nbr, t.cnt, None, t.ptr, sliced)      # without the order
         assert torch.equal(out1, out2) and torch.equal(argj, argj2)
+        # ids from the uint16 rows written by the radius kernel: same bits again
+        assert t.rows16 is not None and t.rows16.shape == (N, 256)
+        out4, argj4 = _native.gather_max_local_j16(P, Q, t.rows16, t.cnt, order, t.ptr, t.k, sliced)
+        assert torch.equal(out1, out4) and torch.equal(argj, argj4)
+    # the uint16 rows themselves: slots < cnt = local ids, the rest of the last started chunk = 0xFFFF
+    slot = torch.arange(256, device=dev).view(1, -1)
+    c = t.cnt.long().view(-1, 1)
+    r16 = t.rows16.long() & 0xFFFF
+    want = torch.zeros_like(r16); want[:, :255] = t.nbr.long() - lo
+    assert torch.equal(torch.where(slot < c, r16, 0 * r16), torch.where(slot < c, want, 0 * want))
+    pad = (slot >= c) & (slot < (c + 7) // 8 * 8)
+    assert bool((r16[pad] == 0xFFFF).all())
     gout = torch.randn(N, H, generator=g).to(dev)
     gq0 = _native.gather_max_bwd_lds(gout, arg8, t.nbr, t.ptr)
     gq1 = _native.gather_max_bwd_j16(gout, argj, t.ptr)
