@@ -474,29 +474,24 @@ __device__ __forceinline__ void load_ids16_pair(unsigned (&w)[K4], const uint16_
 // 4*K4 LDS reads are issued before the compare chain; the next node's ids and P slice are prefetched meanwhile.
 // SLICED: P and Q are the slice-major tables of dmet_node_linear_split_sliced_f32 ([H/8][N][8]); out / arg stay
 // row-major.
-template <bool WITH_ARG, int K4, int GML_MODE = 0, bool IDS16 = false, bool SLICED = false>
-__global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
-    const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ nbr,
-    const uint16_t *__restrict__ nbr16, const int64_t *__restrict__ ptr, int B, int k, int H,
-    float *__restrict__ out, uint8_t *__restrict__ arg, int64_t N, int skip_big)
+// One segment of work: nodes [i0, i1) of event b, slice sl (the whole event's Q slice is staged either way).
+template <bool WITH_ARG, int K4, int GML_MODE, bool IDS16, bool SLICED>
+__device__ __forceinline__ void gather_max_lds_segment(
+    float4 *__restrict__ qs, const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ nbr,
+    const uint16_t *__restrict__ nbr16, const int64_t *__restrict__ ptr, int k, int H,
+    float *__restrict__ out, uint8_t *__restrict__ arg, int64_t N, int skip_big, const int b, const int sl, const int i0,
+    const int i1)
 {
     static_assert(!IDS16 || K4 % 2 == 0, "uint16 tables: k must be a multiple of 8");
-    __shared__ __attribute__((aligned(16))) float4 qs[kLdsGatherRows * 2];   // [n_b + 1][2] float4 = 8 channels/node
     constexpr int RPI = kLdsGatherThreads / 2;                                // rows per iteration (2 lanes per node)
-    const int nsl = H / kSliceC;
-    // block -> (event, slice): slices of one event are 8 blocks apart (same XCD under round-robin placement)
-    const int grp = blockIdx.x / (kNumXcd * nsl), rem = blockIdx.x % (kNumXcd * nsl);
-    const int b = grp * kNumXcd + (rem % kNumXcd);
-    const int sl = rem / kNumXcd;
-    if (b >= B) return;
     const int lo = (int)ptr[b], hi = (int)ptr[b + 1];
     const int n = hi - lo;
-    if (n <= 0) return;
+    if (n <= 0 || i0 >= i1) return;
     const int h4 = H / 4;                       // float4s per full row
     const float4 *Q4 = reinterpret_cast<const float4 *>(Q);
     const float4 *P4 = reinterpret_cast<const float4 *>(P);
     const int half = threadIdx.x & 1;
-    const int r0 = threadIdx.x >> 1;
+    const int r0 = i0 + (threadIdx.x >> 1);
     const int col4 = sl * 2 + half;             // float4 column of this lane inside a full row
     const float ninf = -__builtin_inff();
     // float4 index of this lane's 4 channels of node `i` in P / Q (row-major, or slice-major [H/8][N][8])
@@ -505,7 +500,7 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     if (n + 1 > kLdsGatherRows) {
         if (skip_big) return;   // dmet_gather_max_mixed_f32: the L2-form kernel of the same call takes this event
         // event too large for the LDS image: same arithmetic, rows gathered from global memory (L2)
-        for (int r = r0; r < n; r += RPI) {
+        for (int r = r0; r < i1; r += RPI) {
             const int64_t node = lo + r;
             float4 best = make_float4(ninf, ninf, ninf, ninf);
             int a0 = 255, a1 = 255, a2 = 255, a3 = 255;
@@ -549,7 +544,7 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     int4 ids[K4];
     unsigned idw[K4];
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r0 < n) {
+    if (r0 < i1) {
         if constexpr (IDS16) {
             load_ids16_pair<K4>(idw, nbr16 + (int64_t)(lo + r0) * k, half);
         } else {
@@ -563,7 +558,7 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
     if (threadIdx.x < 2) qs[n * 2 + threadIdx.x] = make_float4(ninf, ninf, ninf, ninf);   // the -inf row
     __syncthreads();
 
-    for (int r = r0; r < n; r += RPI) {
+    for (int r = r0; r < i1; r += RPI) {
         const int64_t node = lo + r;
         unsigned off[4 * K4];
         if constexpr (IDS16) {
@@ -587,7 +582,7 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
             }
         }
         const float4 p = pv;
-        if (r + RPI < n) {
+        if (r + RPI < i1) {
             if constexpr (IDS16) {
                 load_ids16_pair<K4>(idw, nbr16 + (node + RPI) * k, half);
             } else {
@@ -671,6 +666,66 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
             const uchar4 a = make_uchar4((unsigned char)a0, (unsigned char)a1, (unsigned char)a2, (unsigned char)a3);
             reinterpret_cast<uchar4 *>(arg)[node * h4 + col4] = a;
         }
+    }
+}
+
+inline int num_cus()
+{
+    static int cached = 0;
+    if (cached == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            cached = cus;
+        else
+            cached = 256;
+    }
+    return cached;
+}
+
+// balanced == 0: one workgroup per (event, slice); slices of one event are 8 blocks apart (same XCD under round-robin
+// placement).  With B * H/8 = 256 that is exactly one lock-step round of the 256 CUs (the image is the whole LDS of a
+// CU: one workgroup per CU) -- and at any other B a partial or a second round (B = 65: 260 workgroups, twice the time).
+// balanced != 0: the grid is one workgroup per CU; the work axis [event][slice][node] (length H/8 * N) is cut into
+// gridDim.x equal ranges, the workgroups of an XCD taking one contiguous part of it.  A workgroup walks the
+// (event, slice) segments of its range, staging the Q slice of each (a range that cuts an (event, slice) in two makes
+// two workgroups stage it: the price of the balance).  At B * H/8 = 256 equal events both mappings coincide.
+template <bool WITH_ARG, int K4, int GML_MODE = 0, bool IDS16 = false, bool SLICED = false>
+__global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
+    const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ nbr,
+    const uint16_t *__restrict__ nbr16, const int64_t *__restrict__ ptr, int B, int k, int H,
+    float *__restrict__ out, uint8_t *__restrict__ arg, int64_t N, int skip_big, int balanced)
+{
+    __shared__ __attribute__((aligned(16))) float4 qs[kLdsGatherRows * 2];   // [n_b + 1][2] float4 = 8 channels/node
+    const int nsl = H / kSliceC;
+    if (!balanced) {
+        const int grp = blockIdx.x / (kNumXcd * nsl), rem = blockIdx.x % (kNumXcd * nsl);
+        const int b = grp * kNumXcd + (rem % kNumXcd);
+        const int sl = rem / kNumXcd;
+        if (b >= B) return;
+        gather_max_lds_segment<WITH_ARG, K4, GML_MODE, IDS16, SLICED>(qs, P, Q, nbr, nbr16, ptr, k, H, out, arg, N, skip_big,
+                                                                       b, sl, 0, (int)(ptr[b + 1] - ptr[b]));
+        return;
+    }
+    const int64_t L = (int64_t)nsl * N;
+    const int c = xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+    int64_t pos = L * c / gridDim.x;
+    const int64_t end = L * (c + 1) / gridDim.x;
+    while (pos < end) {
+        int b0 = 0, b1 = B;                // event of the position: largest b with nsl * ptr[b] <= pos
+        while (b1 - b0 > 1) {
+            const int mid = (b0 + b1) >> 1;
+            if ((int64_t)nsl * ptr[mid] <= pos) b0 = mid; else b1 = mid;
+        }
+        const int64_t lo = ptr[b0];
+        const int n = (int)(ptr[b0 + 1] - lo);
+        const int64_t rel = pos - (int64_t)nsl * lo;       // < nsl * n
+        const int sl = (int)(rel / n), i0 = (int)(rel - (int64_t)sl * n);
+        const int i1 = (int)((end - pos) < (int64_t)(n - i0) ? i0 + (end - pos) : n);
+        gather_max_lds_segment<WITH_ARG, K4, GML_MODE, IDS16, SLICED>(qs, P, Q, nbr, nbr16, ptr, k, H, out, arg, N, skip_big,
+                                                                       b0, sl, i0, i1);
+        pos += i1 - i0;
+        __syncthreads();                   // the image is restaged by the next segment
     }
 }
 
@@ -1351,16 +1406,30 @@ static int gather_max_lds_impl(const float *P, const float *Q, const int32_t *nb
                  "dmet_gather_max_lds_f32: pointers must be 16-B aligned");
     const int nsl = H / kSliceC;
     const int64_t groups = (B + kNumXcd - 1) / kNumXcd;
-    const int64_t blocks = groups * kNumXcd * nsl;
+    int64_t blocks = groups * kNumXcd * nsl;
+    // Measured at 4500-node events on 256 CUs (tools/gather_sweep.py, us, one workgroup per (event, slice) / balanced):
+    // B = 32: 35.8 / 29.5, 48: 37.2 / 41.0, 64: 39.6 / 40.8, 65: 56.6 / 45.0, 96: 65.2 / 67.2, 128: 69.8 / 94.2 -- a range
+    // that cuts an (event, slice) stages its slice twice, and independent workgroups drift apart so that one CU's staging
+    // hides under its neighbours' gathers, which the lock-step ranges of the balanced form do not.  It wins when the
+    // (event, slice) units fill well under the chip or leave a short tail round.  DMET_GATHER_BALANCED=0/1 forces either.
+    const int cus = num_cus();
+    const int64_t units = (int64_t)B * nsl;
+    int balanced = units * 16 <= (int64_t)cus * 9 || (units > cus && units % cus != 0 && units % cus <= cus / 8);
+    if (const char *e = getenv("DMET_GATHER_BALANCED")) balanced = atoi(e) != 0;
+    if (balanced) {
+        blocks = cus;
+        const int64_t most = ((int64_t)nsl * N + 63) / 64;
+        if (blocks > most) blocks = most;
+    }
     hipStream_t st = as_stream(stream);
 #define DMET_GML_LAUNCH(ARG_, K4_, I16_)                                                                          \
     do {                                                                                                          \
         if (sliced)                                                                                               \
             hipLaunchKernelGGL((gather_max_lds_kernel<ARG_, K4_, 0, I16_, true>), dim3((unsigned)blocks),         \
-                               dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N, skip_big);      \
+                               dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N, skip_big, balanced); \
         else                                                                                                      \
             hipLaunchKernelGGL((gather_max_lds_kernel<ARG_, K4_, 0, I16_, false>), dim3((unsigned)blocks),        \
-                               dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N, skip_big);      \
+                               dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N, skip_big, balanced); \
     } while (0)
 #define DMET_GML(K4_)                                                                                          \
     do {                                                                                                       \
@@ -1372,8 +1441,8 @@ static int gather_max_lds_impl(const float *P, const float *Q, const int32_t *nb
     // slice, =2 the LDS gather + compare chain (results are then meaningless)
     if (const char *e = (arg && nbr16 && k == 16) ? getenv("DMET_GML_MODE") : nullptr) {
         const int m = atoi(e);
-        if (m == 1) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 1, true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N, skip_big);
-        else if (m == 2) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 2, true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N, skip_big);
+        if (m == 1) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 1, true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N, skip_big, balanced);
+        else if (m == 2) hipLaunchKernelGGL((gather_max_lds_kernel<true, 4, 2, true>), dim3((unsigned)blocks), dim3(kLdsGatherThreads), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, out, arg, N, skip_big, balanced);
         else DMET_GML(4);
         DMET_LAUNCH_CHECK("gather_max_lds_kernel");
         return 0;

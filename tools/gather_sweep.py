@@ -46,8 +46,9 @@ def run(label, sizes):
           f"bwd {t_b * 1e3:7.1f} us   [{_native.last_gather_kernel[:60]}]")
 
 
-for B in (32, 48, 64, 65, 96, 128):
+for B in (16, 32, 40, 48, 64, 65, 72, 96, 128):
     run(f"B={B} x 4500", [4500] * B)
+run("ragged 64 x U[500,5000] (every event LDS-resident)", synth.ragged_sizes(64, 500, 5000, seed=7))
 sizes = synth.ragged_sizes(512, 500, 8000, seed=1234)
 for r, shard in enumerate(balanced_shards([s * s for s in sizes], 8)):
     run(f"ragged 512-event batch, shard {r} ({len(shard)} ev)", [sizes[i] for i in shard])
