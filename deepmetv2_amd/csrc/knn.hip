@@ -256,18 +256,28 @@ __device__ __forceinline__ void knn_plan_body(const int64_t *__restrict__ ptr, i
         sum += (int)((nb + tile_queries - 1) / tile_queries);
         nf1 += (nb > 0 && !(nb >= kF2MinNodes && nb <= kF2MaxNodes)) ? 1 : 0;
     }
-    part[tid] = sum;
-    __shared__ int part_f1[256];
-    part_f1[tid] = nf1;
+    // exclusive prefix of the per-thread tile counts and the number of first-form events: wavefront scans + four
+    // wavefront totals (a serial walk of thread 0 over 256 LDS cells was a third of the prep launch: it sits on the
+    // critical path of every build)
+    __shared__ int wave_tot[4], wave_f1[4];
+    const int lane = tid & 63, wv = tid >> 6;
+    int incl = sum, f1 = nf1;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) f1 += __shfl_xor(f1, off, 64);
+    if (lane == 63) wave_tot[wv] = incl;
+    if (lane == 0) wave_f1[wv] = f1;
     __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += wave_tot[w];
+    part[tid] = base + incl - sum;
     if (tid == 0) {
-        int form1_events = 0;
-        for (int i = 0; i < 256; ++i) form1_events += part_f1[i];
-        int run = 0;
-        const int owners = chunk > 0 ? (B + chunk - 1) / chunk : 0;   // threads beyond this own no event
-        for (int i = 0; i < owners; ++i) { const int v = part[i]; part[i] = run; run += v; }
-        for (int i = owners; i < 256; ++i) part[i] = run;
-        const int tiles = run;
+        const int form1_events = wave_f1[0] + wave_f1[1] + wave_f1[2] + wave_f1[3];
+        const int tiles = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
         int n_full = tiles, split = 1;
         // the tiles beyond the last full round of `simds` -- ALL tiles when the batch is small -- are cut into
         // candidate sub-sweeps so that they still fill the chip (unless the events are so small that a sub-sweep
