@@ -706,8 +706,16 @@ def _encode_params(params, dev):
 def _encode_x(x: torch.Tensor, x_cat: torch.Tensor):
     if x.dim() != 2 or x.shape[1] != 8 or x.dtype != torch.float32:
         raise ValueError(f"encode: x_cont must be float32 [N,8], got {tuple(x.shape)} {x.dtype}")
-    if x_cat.dim() != 2 or x_cat.shape != (x.shape[0], 3) or x_cat.dtype != torch.int64:
-        raise ValueError(f"encode: x_cat must be int64 [N,3], got {tuple(x_cat.shape)} {x_cat.dtype}")
+    if x_cat.dim() != 2 or x_cat.shape != (x.shape[0], 3):
+        raise ValueError(f"encode: x_cat must be [N,3], got {tuple(x_cat.shape)}")
+    if x_cat.dtype == torch.float32:
+        # the float columns 8..10 of the same feature matrix (split_features(x, lazy_cat=True)): converted in the kernel
+        if (x.stride(1) == 1 and x_cat.stride(1) == 1 and x_cat.stride(0) == x.stride(0) and x.stride(0) >= 11
+                and x_cat.data_ptr() == x.data_ptr() + 32):
+            return x, None
+        x_cat = x_cat.long()
+    if x_cat.dtype != torch.int64:
+        raise ValueError(f"encode: x_cat must be int64 (or the float columns 8..10 of x), got {x_cat.dtype}")
     return (x if x.stride(1) == 1 else x.contiguous()), x_cat.contiguous()
 
 
@@ -720,7 +728,7 @@ def encode_fwd(x_cont: torch.Tensor, x_cat: torch.Tensor, params) -> torch.Tenso
     N = x.shape[0]
     h = torch.empty((N, 32), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(L.dmet_encode_fwd_f32(x.data_ptr(), x.stride(0), xc.data_ptr(), N, *[t.data_ptr() for t in ps],
+        _lib.check(L.dmet_encode_fwd_f32(x.data_ptr(), x.stride(0), xc.data_ptr() if xc is not None else None, N, *[t.data_ptr() for t in ps],
                                          h.data_ptr(), _stream(dev)), "dmet_encode_fwd_f32")
     return h
 
@@ -738,15 +746,17 @@ def encode_bwd(x_cont: torch.Tensor, x_cat: torch.Tensor, params, h: torch.Tenso
         return [g.zero_() for g in grads]
     with torch.cuda.device(dev):
         ws = _ws(L.dmet_encode_bwd_workspace_bytes(N), dev)
-        _lib.check(L.dmet_encode_bwd_f32(x.data_ptr(), x.stride(0), xc.data_ptr(), N, *[t.data_ptr() for t in ps],
+        _lib.check(L.dmet_encode_bwd_f32(x.data_ptr(), x.stride(0), xc.data_ptr() if xc is not None else None, N, *[t.data_ptr() for t in ps],
                                          h.data_ptr(), g_h.data_ptr(), *[g.data_ptr() for g in grads], ws.data_ptr(),
                                          ws.numel(), _stream(dev)), "dmet_encode_bwd_f32")
     return grads
 
 
 def bn_fwd(x: torch.Tensor, residual: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, eps: float,
-           momentum: float, running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], training: bool):
-    """BatchNorm1d over rows (+ residual): returns (y, save_mean, save_invstd); running stats updated in place."""
+           momentum: float, running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], training: bool,
+           num_batches_tracked: Optional[torch.Tensor] = None):
+    """BatchNorm1d over rows (+ residual): returns (y, save_mean, save_invstd); running stats updated in place, and
+    num_batches_tracked (int64 scalar on the device, training mode only) incremented by the statistics kernel."""
     dev = _require_device(x, gamma, beta)
     L = _lib.load()
     x = _f32c(x, "x")
@@ -763,12 +773,18 @@ def bn_fwd(x: torch.Tensor, residual: Optional[torch.Tensor], gamma: torch.Tenso
     stats = torch.empty((2, H), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         ws = _ws(L.dmet_bn_workspace_bytes(N, H), dev)
-        _lib.check(L.dmet_bn_fwd_f32(x.data_ptr(), residual.data_ptr() if residual is not None else None, N, H,
-                                     gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum),
-                                     running_mean.data_ptr() if running_mean is not None else None,
-                                     running_var.data_ptr() if running_var is not None else None,
-                                     1 if training else 0, y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
-                                     ws.data_ptr(), ws.numel(), _stream(dev)), "dmet_bn_fwd_f32")
+        nbt = None
+        if num_batches_tracked is not None and training:
+            if num_batches_tracked.dtype != torch.int64 or num_batches_tracked.numel() != 1 or num_batches_tracked.device != dev:
+                raise ValueError("bn_fwd: num_batches_tracked must be an int64 scalar on x's device")
+            nbt = num_batches_tracked.data_ptr()
+        _lib.check(L.dmet_bn_fwd_tracked_f32(x.data_ptr(), residual.data_ptr() if residual is not None else None, N, H,
+                                             gamma.data_ptr(), beta.data_ptr(), float(eps), float(momentum),
+                                             running_mean.data_ptr() if running_mean is not None else None,
+                                             running_var.data_ptr() if running_var is not None else None, nbt,
+                                             1 if training else 0, y.data_ptr(), stats[0].data_ptr(),
+                                             stats[1].data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+                   "dmet_bn_fwd_tracked_f32")
     return y, stats[0], stats[1]
 
 

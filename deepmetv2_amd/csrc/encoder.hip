@@ -32,16 +32,21 @@ __device__ __forceinline__ float elu(float z) { return z > 0.0f ? z : (__expf(z)
 // categorical columns (x_cat[N,3] int64 = pdgId, charge, fromPV) -> table rows; the pdg remap is the reference's
 // SEQUENTIAL torch.where chain, kept sequential so unexpected ids behave identically; indices are clamped into
 // their tables (torch would raise on an out-of-range index).
-__device__ __forceinline__ void cat_indices(const int64_t *__restrict__ xcat, int64_t i, int &ichg, int &ipdg, int &ipv)
+// xcat == NULL: the three columns are columns 8..10 of the node's own row of x, still as floats -- the conversion of
+// train.py:43 (`x[:, 8:].long()`, truncation toward zero) then happens here instead of in a kernel of its own.
+__device__ __forceinline__ void cat_indices(const int64_t *__restrict__ xcat, const float *__restrict__ row, int64_t i,
+                                            int &ichg, int &ipdg, int &ipv)
 {
-    long long c = xcat[i * 3 + 0];
+    long long c = xcat ? xcat[i * 3 + 0] : (long long)row[8];
+    const long long chg = xcat ? xcat[i * 3 + 1] : (long long)row[9];
+    const long long pv = xcat ? xcat[i * 3 + 2] : (long long)row[10];
     c = c < 0 ? -c : c;
     const long long table[7] = {1, 2, 11, 13, 22, 130, 211};
 #pragma unroll
     for (int t = 0; t < 7; ++t) c = (c == table[t]) ? (long long)t : c;
     ipdg = (int)min(max(c, 0ll), 6ll);
-    ichg = (int)min(max((long long)xcat[i * 3 + 1] + 1, 0ll), 2ll);
-    ipv = (int)min(max((long long)xcat[i * 3 + 2], 0ll), 7ll);
+    ichg = (int)min(max(chg + 1, 0ll), 2ll);
+    ipv = (int)min(max(pv, 0ll), 7ll);
 }
 
 // forward chain for one node; pre-activations are returned because backward needs ELU'(z)
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void encode_fwd_kernel(const float *__restr
 #pragma unroll
     for (int f = 0; f < 8; ++f) xc[f] = row[f];
     int ichg, ipdg, ipv;
-    cat_indices(xcat, i, ichg, ipdg, ipv);
+    cat_indices(xcat, row, i, ichg, ipdg, ipv);
     float cat24[24], z1[16], z2[16], joint[32], z3[32];
     encode_node(ENC_ARGS, xc, ichg, ipdg, ipv, cat24, z1, z2, joint, z3);
     float4 *o = reinterpret_cast<float4 *>(h + i * 32);
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(64 * kEncBwdWaves, 2) void encode_bwd_kernel(const 
 #pragma unroll
         for (int f = 0; f < 8; ++f) xc[f] = row[f];
         int ichg, ipdg, ipv;
-        cat_indices(xcat, ii, ichg, ipdg, ipv);
+        cat_indices(xcat, row, ii, ichg, ipdg, ipv);
         packed[lane] = ichg | (ipdg << 2) | (ipv << 5);
         float cat24[24], joint[32];
 #pragma unroll
@@ -342,7 +347,8 @@ extern "C" int dmet_encode_fwd_f32(const float *x, int64_t x_stride, const int64
 {
     DMET_REQUIRE(N >= 0 && x_stride >= 8, "dmet_encode_fwd_f32: bad sizes");
     if (N == 0) return 0;
-    DMET_REQUIRE(x && xcat && Wc && bc && Wk && bk && Wa && ba && Echg && Epdg && Epv && h, "dmet_encode_fwd_f32: null pointer");
+    DMET_REQUIRE(x && Wc && bc && Wk && bk && Wa && ba && Echg && Epdg && Epv && h, "dmet_encode_fwd_f32: null pointer");
+    DMET_REQUIRE(xcat || x_stride >= 11, "dmet_encode_fwd_f32: x_cat == NULL needs rows of at least 11 columns (x_stride=%lld)", (long long)x_stride);
     DMET_REQUIRE(aligned16(h), "dmet_encode_fwd_f32: h must be 16-B aligned");
     const int64_t blocks = (N + 255) / 256;
     DMET_REQUIRE(blocks < (1ll << 31), "dmet_encode_fwd_f32: too many nodes");
@@ -367,7 +373,7 @@ extern "C" int dmet_encode_bwd_f32(const float *x, int64_t x_stride, const int64
                                    dmet_stream_t stream)
 {
     DMET_REQUIRE(N > 0 && x_stride >= 8, "dmet_encode_bwd_f32: bad sizes");
-    DMET_REQUIRE(x && xcat && Wc && bc && Wk && bk && Wa && ba && Echg && Epdg && Epv && h && g_h && gWc && gbc && gWk && gbk &&
+    DMET_REQUIRE((xcat || x_stride >= 11) && x && Wc && bc && Wk && bk && Wa && ba && Echg && Epdg && Epv && h && g_h && gWc && gbc && gWk && gbk &&
                      gWa && gba && gEchg && gEpdg && gEpv && ws,
                  "dmet_encode_bwd_f32: null pointer");
     DMET_REQUIRE(ws_bytes >= dmet_encode_bwd_workspace_bytes(N), "dmet_encode_bwd_f32: workspace too small");

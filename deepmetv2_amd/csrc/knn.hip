@@ -1173,7 +1173,10 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
 //   * the first kF2Defer tiles only feed tau; they are swept again at the end against the final tau (their masks
 //     would otherwise be nearly full: tau is still the sentinel there);
 //   * the exact re-rank walks the set bits of the surviving entries.
-constexpr int kF2Defer = 32;        // tiles that only feed tau in the main sweep
+#ifndef DMET_F2_DEFER
+#define DMET_F2_DEFER 32
+#endif
+constexpr int kF2Defer = DMET_F2_DEFER;   // tiles that only feed tau in the main sweep
 constexpr int kF2Slots = 30;        // entries per lane
 constexpr int kF2RowF = 16;         // features staged per re-rank half round
 constexpr unsigned kF2TileBits = 11u, kF2TileMask = (1u << kF2TileBits) - 1u;

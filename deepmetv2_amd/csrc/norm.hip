@@ -92,11 +92,13 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(const float *__re
                                                              float momentum, float *__restrict__ running_mean,
                                                              float *__restrict__ running_var,
                                                              float *__restrict__ save_mean,
-                                                             float *__restrict__ save_invstd)
+                                                             float *__restrict__ save_invstd,
+                                                             int64_t *__restrict__ num_batches_tracked)
 {
     double s0, s1;
     bn_combine(partial, nblocks, H, s0, s1);
     const int c = threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;   // torch bumps it with a kernel of its own
     if (c >= H) return;                                    // threads >= 64 (other groups) leave here too
     const double shift = (double)x[c];
     const double m = s0 / (double)N;                       // mean of (x - shift)
@@ -211,10 +213,11 @@ extern "C" size_t dmet_bn_workspace_bytes(int64_t N, int H)
     return sizeof(float) * ((size_t)kBnBlocks * 2 * H + 2 * (size_t)H) + 512;
 }
 
-extern "C" int dmet_bn_fwd_f32(const float *x, const float *residual, int64_t N, int H, const float *gamma,
-                               const float *beta, float eps, float momentum, float *running_mean, float *running_var,
-                               int training, float *y, float *save_mean, float *save_invstd, void *ws, size_t ws_bytes,
-                               dmet_stream_t stream)
+extern "C" int dmet_bn_fwd_tracked_f32(const float *x, const float *residual, int64_t N, int H, const float *gamma,
+                                       const float *beta, float eps, float momentum, float *running_mean,
+                                       float *running_var, int64_t *num_batches_tracked, int training, float *y,
+                                       float *save_mean, float *save_invstd, void *ws, size_t ws_bytes,
+                                       dmet_stream_t stream)
 {
     DMET_REQUIRE(bn_shape_ok(H), "dmet_bn_fwd_f32: H=%d must be a multiple of 4 in [4,64]", H);
     DMET_REQUIRE(N >= 0, "dmet_bn_fwd_f32: N=%lld", (long long)N);
@@ -235,7 +238,7 @@ extern "C" int dmet_bn_fwd_f32(const float *x, const float *residual, int64_t N,
                            (const float *)nullptr, (const float *)nullptr, rpb, partial);
         DMET_LAUNCH_CHECK("bn_reduce_kernel<0>");
         hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nb, x, N, H, eps, momentum,
-                           running_mean, running_var, save_mean, save_invstd);
+                           running_mean, running_var, save_mean, save_invstd, num_batches_tracked);
         DMET_LAUNCH_CHECK("bn_fwd_finalize_kernel");
     } else {
         hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(1), dim3(64), 0, st, (const float *)running_mean,
@@ -249,6 +252,15 @@ extern "C" int dmet_bn_fwd_f32(const float *x, const float *residual, int64_t N,
                        (const float *)save_mean, (const float *)save_invstd, y);
     DMET_LAUNCH_CHECK("bn_apply_kernel");
     return 0;
+}
+
+extern "C" int dmet_bn_fwd_f32(const float *x, const float *residual, int64_t N, int H, const float *gamma,
+                               const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                               int training, float *y, float *save_mean, float *save_invstd, void *ws, size_t ws_bytes,
+                               dmet_stream_t stream)
+{
+    return dmet_bn_fwd_tracked_f32(x, residual, N, H, gamma, beta, eps, momentum, running_mean, running_var, nullptr,
+                                   training, y, save_mean, save_invstd, ws, ws_bytes, stream);
 }
 
 extern "C" int dmet_bn_bwd_f32(const float *x, const float *g_y, int64_t N, int H, const float *gamma,

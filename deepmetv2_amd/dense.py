@@ -85,9 +85,9 @@ class _BatchNorm(torch.autograd.Function):
     """BatchNorm1d over the rows of x[N,H] (+ residual) on the HIP kernels of csrc/norm.hip."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, tracked=None):
         y, mean, invstd = _native.bn_fwd(x, residual, weight.detach(), bias.detach(), eps, momentum,
-                                         running_mean, running_var, training)
+                                         running_mean, running_var, training, num_batches_tracked=tracked)
         ctx.save_for_backward(x, weight, mean, invstd)
         ctx.training = training
         ctx.has_residual = residual is not None
@@ -104,7 +104,7 @@ class _BatchNorm(torch.autograd.Function):
             g_x = g_y * scale
             g_w = (g_y * (x - mean) * invstd).sum(0)
             g_b = g_y.sum(0)
-        return g_x, (g_y if ctx.has_residual else None), g_w, g_b, None, None, None, None, None
+        return g_x, (g_y if ctx.has_residual else None), g_w, g_b, None, None, None, None, None, None
 
 
 def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -120,9 +120,9 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, residual: Optional[tor
     training = bn.training or not bn.track_running_stats
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    return _BatchNorm.apply(x, residual, bn.weight, bn.bias, rm, rv, training, float(bn.momentum), float(bn.eps))
+    # the statistics kernel bumps num_batches_tracked (torch's own `add_(1)` is one more launch per layer and step)
+    tracked = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None
+    return _BatchNorm.apply(x, residual, bn.weight, bn.bias, rm, rv, training, float(bn.momentum), float(bn.eps), tracked)
 
 
 class _Head(torch.autograd.Function):

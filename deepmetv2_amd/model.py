@@ -69,6 +69,8 @@ class GraphMETNetwork(nn.Module):
             h = dense.encode(x_cont, x_cat, lc.weight, lc.bias, lk.weight, lk.bias, la.weight, la.bias,
                              self.embed_charge.weight, self.embed_pdgid.weight, self.embed_pv.weight)
             return dense.batch_norm(h, self.bn_all)
+        if x_cat.is_floating_point():      # split_features(x, lazy_cat=True) on the layer-by-layer route
+            x_cat = x_cat.long()
         e_cont = _run(self.embed_continuous, x_cont)
         e_chrg = dense.embedding(x_cat[:, 1] + 1, self.embed_charge.weight)
         e_pv = dense.embedding(x_cat[:, 2], self.embed_pv.weight)
@@ -119,6 +121,9 @@ def loss_fn(weights: torch.Tensor, prediction: torch.Tensor, truth: torch.Tensor
     return met_loss(met, truth)
 
 
-def split_features(x: torch.Tensor):
-    """train.py:42-46: continuous columns 0..7 (puppi included), categorical columns 8..10 as int64."""
-    return x[:, :8], x[:, 8:].long()
+def split_features(x: torch.Tensor, lazy_cat: bool = False):
+    """train.py:42-46: continuous columns 0..7 (puppi included), categorical columns 8..10 as int64.
+    lazy_cat=True hands the categorical columns over as the float view x[:, 8:]: the fused encoder kernel converts them
+    itself (same truncation as `.long()`), which saves the conversion kernel and its [N,3] int64 tensor per step; any
+    other consumer inside this package converts on demand."""
+    return x[:, :8], (x[:, 8:] if lazy_cat else x[:, 8:].long())

@@ -121,7 +121,7 @@ def train_step(model: torch.nn.Module, flat: FlatModule, sync: GradSync, optimiz
     from .model import loss_fn, split_features
 
     flat.zero_grad()
-    x_cont, x_cat = split_features(x)
+    x_cont, x_cat = split_features(x, lazy_cat=True)
     weights = model(x_cont, x_cat, edge_index, batch)
     loss = loss_fn(weights, x, y, batch, ptr=ptr)
     loss.backward()
@@ -149,7 +149,7 @@ class GraphedTrainStep:
 
         def fwd_bwd():
             flat.zero_grad()
-            x_cont, x_cat = split_features(self.x)
+            x_cont, x_cat = split_features(self.x, lazy_cat=True)
             graph = graph_fn(self.x) if graph_fn is not None else None
             loss = loss_fn(model(x_cont, x_cat, graph, self.batch), self.x, self.y, self.batch, ptr=self.ptr)
             loss.backward()

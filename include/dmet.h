@@ -296,7 +296,9 @@ int dmet_onehot_xty_f32(const int64_t *index, const float *B, int64_t N, int R, 
  * model/graph_met_network.py:48-58 up to (not including) bn_all:
  *   h = ELU(Wa [ELU(Wk [Echg[chg+1] | Epdg[remap(|pdg|)] | Epv[pv]] + bk) | ELU(Wc x[:, :8] + bc)] + ba)
  * x[N,8] fp32 continuous columns with row stride x_stride floats (a view into the 11-column feature matrix is
- * fine); x_cat[N,3] int64 = (pdgId, charge, fromPV), the arguments of GraphMETNetwork.forward.  Torch layouts
+ * fine); x_cat[N,3] int64 = (pdgId, charge, fromPV), the arguments of GraphMETNetwork.forward -- or x_cat == NULL:
+ * the three columns are columns 8..10 of the same rows of x (x_stride >= 11), still as floats, and the `.long()` of
+ * train.py:43 (truncation toward zero) happens inside the kernel.  Torch layouts
  * for the weights (Linear.weight [out,in], Embedding.weight [rows,8]).  Backward takes the forward output h and g_h = dL/dh and
  * writes (not accumulates) all nine parameter gradients, reduced over the nodes deterministically. */
 int dmet_encode_fwd_f32(const float *x, int64_t x_stride, const int64_t *x_cat, int64_t N, const float *Wc, const float *bc,
@@ -337,6 +339,12 @@ size_t dmet_bn_workspace_bytes(int64_t N, int H);
 int dmet_bn_fwd_f32(const float *x, const float *residual, int64_t N, int H, const float *gamma, const float *beta,
                     float eps, float momentum, float *running_mean, float *running_var, int training, float *y,
                     float *save_mean, float *save_invstd, void *ws, size_t ws_bytes, dmet_stream_t stream);
+/* Same; in training mode *num_batches_tracked (optional, int64 on the device: nn.BatchNorm1d's buffer) is incremented by
+ * the statistics kernel instead of by a kernel launch of its own. */
+int dmet_bn_fwd_tracked_f32(const float *x, const float *residual, int64_t N, int H, const float *gamma,
+                            const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                            int64_t *num_batches_tracked, int training, float *y, float *save_mean, float *save_invstd,
+                            void *ws, size_t ws_bytes, dmet_stream_t stream);
 int dmet_bn_bwd_f32(const float *x, const float *g_y, int64_t N, int H, const float *gamma, const float *save_mean,
                     const float *save_invstd, float *g_x, float *g_gamma, float *g_beta, void *ws, size_t ws_bytes,
                     dmet_stream_t stream);

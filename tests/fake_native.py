@@ -196,6 +196,8 @@ def onehot_xty(index, Bm, num_rows):
 
 
 def _encode_chain(x_cont, x_cat, params):
+    if x_cat.is_floating_point():   # lazy categorical columns: the kernel truncates like .long()
+        x_cat = x_cat.long()
     Wc, bc, Wk, bk, Wa, ba, Echg, Epdg, Epv = params
     F = torch.nn.functional
     pdg = x_cat[:, 0].abs()
@@ -219,7 +221,9 @@ def encode_bwd(x_cont, x_cat, params, h, g_h):
     return list(torch.autograd.grad(out, ps, g_h))
 
 
-def bn_fwd(x, residual, gamma, beta, eps, momentum, running_mean, running_var, training):
+def bn_fwd(x, residual, gamma, beta, eps, momentum, running_mean, running_var, training, num_batches_tracked=None):
+    if training and num_batches_tracked is not None:
+        num_batches_tracked.add_(1)
     if training:
         mean = x.mean(0)
         var = x.var(0, unbiased=False)

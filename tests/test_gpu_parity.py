@@ -684,6 +684,14 @@ def test_fused_encoder_fwd_bwd(dev, N):
     dense.encode(big[:, :8], x_cat.to(dev), *params2).backward(g_h.to(dev))
     for p, q in zip(params, params2):
         assert torch.equal(p.grad, q.grad)
+    # categorical columns handed over as the float view of the same rows (split_features(x, lazy_cat=True)): the
+    # kernel does the `.long()` of train.py:43 itself -- same bits
+    params3 = [p.detach().clone().requires_grad_(True) for p in params]
+    h3 = dense.encode(big[:, :8], big[:, 8:], *params3)
+    h3.backward(g_h.to(dev))
+    assert torch.equal(h3, h)
+    for p, q in zip(params, params3):
+        assert torch.equal(p.grad, q.grad)
 
 
 @pytest.mark.parametrize("N,H,residual,training", [(5000, 32, True, True), (70001, 32, False, True), (3, 8, True, True),
