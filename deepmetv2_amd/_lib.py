@@ -63,6 +63,8 @@ SIGNATURES = {
     "dmet_met_reduce_f32": (_i, [_vp, _vp, _i64, _vp, _i, _vp, _vp]),
     "dmet_met_reduce_bwd_f32": (_i, [_vp, _vp, _i64, _vp, _i, _i64, _vp, _vp]),
     "dmet_met_loss_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "dmet_met_loss_strided_f32": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    "dmet_met_reduce_bwd_scaled_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i64, _vp, _vp]),
     "dmet_segment_sum_1d_f32": (_i, [_vp, _vp, _i, _vp, _vp]),
     "dmet_table_degree": (_i, [_vp, _vp, _i64, _i, _vp, _vp]),
     "dmet_table_edges": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -616,16 +616,23 @@ def met_reduce(w: torch.Tensor, x: torch.Tensor, ptr: torch.Tensor) -> torch.Ten
     return met
 
 
-def met_reduce_bwd(g_met: torch.Tensor, x: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:
+def met_reduce_bwd(g_met: torch.Tensor, x: torch.Tensor, ptr: torch.Tensor,
+                   scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """g_w[i] = g_met[b,0] * px_i + g_met[b,1] * py_i; scale (optional, one float32 on the device) multiplies g_met first."""
     dev = _require_device(g_met, x, ptr)
     L = _lib.load()
     g_met = _f32c(g_met, "g_met")
     N = x.shape[0]
     B = ptr.numel() - 1
     g_w = torch.empty((N,), dtype=torch.float32, device=dev)
+    sp = None
+    if scale is not None:
+        if scale.dtype != torch.float32 or scale.numel() != 1 or scale.device != dev:
+            raise ValueError("met_reduce_bwd: scale must be one float32 on the device")
+        sp = scale.data_ptr()
     with torch.cuda.device(dev):
-        _lib.check(L.dmet_met_reduce_bwd_f32(g_met.data_ptr(), x.data_ptr(), x.stride(0), ptr.data_ptr(), B, N,
-                                             g_w.data_ptr(), _stream(dev)), "dmet_met_reduce_bwd_f32")
+        _lib.check(L.dmet_met_reduce_bwd_scaled_f32(g_met.data_ptr(), sp, x.data_ptr(), x.stride(0), ptr.data_ptr(), B, N,
+                                                    g_w.data_ptr(), _stream(dev)), "dmet_met_reduce_bwd_scaled_f32")
     return g_w
 
 
@@ -867,14 +874,12 @@ def met_loss(met: torch.Tensor, truth: torch.Tensor):
     met = _f32c(met, "met"); truth = _f32c(truth, "truth")
     if met.dim() != 2 or met.shape[1] != 2 or truth.shape[0] != met.shape[0] or truth.shape[1] < 2:
         raise ValueError("met_loss: met must be [B,2], truth [B,>=2]")
-    if truth.shape[1] != 2:
-        truth = truth[:, :2].contiguous()
     B = met.shape[0]
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
     g = torch.empty_like(met)
-    with torch.cuda.device(dev):
-        _lib.check(L.dmet_met_loss_f32(met.data_ptr(), truth.data_ptr(), B, loss.data_ptr(), g.data_ptr(), _stream(dev)),
-                   "dmet_met_loss_f32")
+    with torch.cuda.device(dev):    # px, py are columns 0, 1 of the rows: no [B,2] copy of the [B,11] target
+        _lib.check(L.dmet_met_loss_strided_f32(met.data_ptr(), truth.data_ptr(), truth.stride(0), B, loss.data_ptr(),
+                                               g.data_ptr(), _stream(dev)), "dmet_met_loss_strided_f32")
     return loss, g
 
 

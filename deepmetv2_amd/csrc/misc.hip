@@ -71,14 +71,19 @@ __global__ __launch_bounds__(kMetThreads) void event_sum_kernel(const float *__r
     }
 }
 
-__global__ __launch_bounds__(256) void met_bwd_kernel(const float *__restrict__ g_met, const float *__restrict__ x,
-                                                       int64_t x_stride, const int64_t *__restrict__ ptr, int B,
-                                                       int64_t N, float *__restrict__ g_w)
+// scale (optional, one float on the device): g_met is multiplied by it first, rounded to fp32 like the separate
+// `g_met * g_loss` of the autograd chain it replaces
+__global__ __launch_bounds__(256) void met_bwd_kernel(const float *__restrict__ g_met, const float *__restrict__ scale,
+                                                       const float *__restrict__ x, int64_t x_stride,
+                                                       const int64_t *__restrict__ ptr, int B, int64_t N,
+                                                       float *__restrict__ g_w)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int b = find_event(ptr, B, i);
-    g_w[i] = g_met[2 * b] * x[i * x_stride] + g_met[2 * b + 1] * x[i * x_stride + 1];
+    float gx = g_met[2 * b], gy = g_met[2 * b + 1];
+    if (scale) { const float sc = scale[0]; gx = gx * sc; gy = gy * sc; }
+    g_w[i] = gx * x[i * x_stride] + gy * x[i * x_stride + 1];
 }
 
 __global__ __launch_bounds__(256) void batch_to_ptr_kernel(const int64_t *__restrict__ batch, int64_t N, int B,
@@ -154,14 +159,15 @@ extern "C" int dmet_segment_sum_1d_f32(const float *src, const int64_t *ptr, int
 // loss = 0.5 * mean_b((met_x + true_x)^2 + (met_y + true_y)^2)  (model/net.py:58-61) and d loss / d met in one launch;
 // one workgroup, fixed summation order.
 __global__ __launch_bounds__(256) void met_loss_kernel(const float *__restrict__ met, const float *__restrict__ truth,
-                                                        int B, float *__restrict__ loss, float *__restrict__ g_met)
+                                                        int64_t truth_stride, int B, float *__restrict__ loss,
+                                                        float *__restrict__ g_met)
 {
     __shared__ float red[256];
     const int tid = threadIdx.x;
     const float invB = 1.0f / (float)B;
     float s = 0.0f;
     for (int b = tid; b < B; b += 256) {
-        const float rx = met[2 * b] + truth[2 * b], ry = met[2 * b + 1] + truth[2 * b + 1];
+        const float rx = met[2 * b] + truth[b * truth_stride], ry = met[2 * b + 1] + truth[b * truth_stride + 1];
         s += rx * rx + ry * ry;
         g_met[2 * b] = rx * invB;
         g_met[2 * b + 1] = ry * invB;
@@ -175,26 +181,38 @@ __global__ __launch_bounds__(256) void met_loss_kernel(const float *__restrict__
     if (tid == 0) loss[0] = 0.5f * red[0] * invB;
 }
 
+extern "C" int dmet_met_loss_strided_f32(const float *met, const float *truth, int64_t truth_stride, int B, float *loss,
+                                         float *g_met, dmet_stream_t stream)
+{
+    DMET_REQUIRE(B > 0 && truth_stride >= 2, "dmet_met_loss_f32: B=%d truth_stride=%lld", B, (long long)truth_stride);
+    DMET_REQUIRE(met && truth && loss && g_met, "dmet_met_loss_f32: null pointer");
+    hipLaunchKernelGGL(met_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), met, truth, truth_stride, B, loss, g_met);
+    DMET_LAUNCH_CHECK("met_loss_kernel");
+    return 0;
+}
+
 extern "C" int dmet_met_loss_f32(const float *met, const float *truth, int B, float *loss, float *g_met,
                                  dmet_stream_t stream)
 {
-    DMET_REQUIRE(B > 0, "dmet_met_loss_f32: B=%d", B);
-    DMET_REQUIRE(met && truth && loss && g_met, "dmet_met_loss_f32: null pointer");
-    hipLaunchKernelGGL(met_loss_kernel, dim3(1), dim3(256), 0, as_stream(stream), met, truth, B, loss, g_met);
-    DMET_LAUNCH_CHECK("met_loss_kernel");
+    return dmet_met_loss_strided_f32(met, truth, 2, B, loss, g_met, stream);
+}
+
+extern "C" int dmet_met_reduce_bwd_scaled_f32(const float *g_met, const float *scale, const float *x, int64_t x_stride,
+                                              const int64_t *ptr, int B, int64_t N, float *g_w, dmet_stream_t stream)
+{
+    DMET_REQUIRE(B >= 0 && N >= 0 && x_stride >= 2, "dmet_met_reduce_bwd_f32: bad sizes");
+    if (N == 0 || B == 0) return 0;
+    DMET_REQUIRE(g_met && x && ptr && g_w, "dmet_met_reduce_bwd_f32: null pointer");
+    hipLaunchKernelGGL(met_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), g_met, scale, x,
+                       x_stride, ptr, B, N, g_w);
+    DMET_LAUNCH_CHECK("met_bwd_kernel");
     return 0;
 }
 
 extern "C" int dmet_met_reduce_bwd_f32(const float *g_met, const float *x, int64_t x_stride, const int64_t *ptr,
                                        int B, int64_t N, float *g_w, dmet_stream_t stream)
 {
-    DMET_REQUIRE(B >= 0 && N >= 0 && x_stride >= 2, "dmet_met_reduce_bwd_f32: bad sizes");
-    if (N == 0 || B == 0) return 0;
-    DMET_REQUIRE(g_met && x && ptr && g_w, "dmet_met_reduce_bwd_f32: null pointer");
-    hipLaunchKernelGGL(met_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), g_met, x,
-                       x_stride, ptr, B, N, g_w);
-    DMET_LAUNCH_CHECK("met_bwd_kernel");
-    return 0;
+    return dmet_met_reduce_bwd_scaled_f32(g_met, nullptr, x, x_stride, ptr, B, N, g_w, stream);
 }
 
 extern "C" int dmet_batch_to_ptr(const int64_t *batch, int64_t N, int B, int64_t *ptr, dmet_stream_t stream)

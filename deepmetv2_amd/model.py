@@ -18,7 +18,7 @@ from torch import nn
 
 from . import dense
 from .conv import DynamicEdgeConv, EdgeConv
-from .scatter import met_loss, met_reduce
+from .scatter import met_loss, met_loss_from_weights, met_reduce
 
 PDG_CLASSES = (1, 2, 11, 13, 22, 130, 211)  # graph_met_network.py:45
 
@@ -117,6 +117,8 @@ def loss_fn(weights: torch.Tensor, prediction: torch.Tensor, truth: torch.Tensor
             ptr: Optional[torch.Tensor] = None) -> torch.Tensor:
     """net.py:49-62 with the two scatter_add calls fused into one MET reduction:
     0.5 * mean_b((METx + true_px)^2 + (METy + true_py)^2)."""
+    if weights.dtype == torch.float32 and prediction.dtype == torch.float32 and truth.dtype == torch.float32:
+        return met_loss_from_weights(weights, prediction, truth, batch, ptr=ptr)
     met = met_reduce(weights, prediction, batch, ptr=ptr, num_events=truth.shape[0])
     return met_loss(met, truth)
 

@@ -113,6 +113,18 @@ class GradSync:
             self.flat.flat_grad.div_(self.world)
 
 
+_ONES = {}
+
+
+def _one_like(loss: torch.Tensor) -> torch.Tensor:
+    """A cached 1.0 of the loss's device and dtype: `loss.backward()` would fill a fresh one with a kernel every step."""
+    key = (loss.device, loss.dtype)
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones((), device=loss.device, dtype=loss.dtype)
+    return t
+
+
 def train_step(model: torch.nn.Module, flat: FlatModule, sync: GradSync, optimizer: torch.optim.Optimizer,
                x: torch.Tensor, y: torch.Tensor, batch: torch.Tensor, ptr: Optional[torch.Tensor] = None,
                edge_index: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -124,7 +136,7 @@ def train_step(model: torch.nn.Module, flat: FlatModule, sync: GradSync, optimiz
     x_cont, x_cat = split_features(x, lazy_cat=True)
     weights = model(x_cont, x_cat, edge_index, batch)
     loss = loss_fn(weights, x, y, batch, ptr=ptr)
-    loss.backward()
+    loss.backward(_one_like(loss))
     flat.gather_grads()
     sync.average_gradients()
     optimizer.step()
@@ -152,7 +164,7 @@ class GraphedTrainStep:
             x_cont, x_cat = split_features(self.x, lazy_cat=True)
             graph = graph_fn(self.x) if graph_fn is not None else None
             loss = loss_fn(model(x_cont, x_cat, graph, self.batch), self.x, self.y, self.batch, ptr=self.ptr)
-            loss.backward()
+            loss.backward(_one_like(loss))
             flat.gather_grads()
             return loss.detach()
 

@@ -151,6 +151,31 @@ class _MetLoss(torch.autograd.Function):
         return g * g_loss, None
 
 
+class _MetLossFromWeights(torch.autograd.Function):
+    """loss_fn of model/net.py:49-62 as ONE autograd node: MET reduction + loss forward (two kernels), one backward kernel
+    that applies the upstream gradient of the scalar loss itself (the chain of two nodes needs a [B,2] multiply)."""
+
+    @staticmethod
+    def forward(ctx, w, x, ptr, truth):
+        met = _native.met_reduce(w, x, ptr)
+        loss, g = _native.met_loss(met, truth)
+        ctx.save_for_backward(g, x, ptr)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        g, x, ptr = ctx.saved_tensors
+        return _native.met_reduce_bwd(g, x, ptr, scale=g_loss.reshape(1).float()), None, None, None
+
+
+def met_loss_from_weights(weights: torch.Tensor, x: torch.Tensor, truth: torch.Tensor, batch: Optional[torch.Tensor] = None,
+                          ptr: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """met_loss(met_reduce(weights, x), truth) with the same bits, as one autograd node."""
+    if ptr is None:
+        ptr = batch_info(batch, weights.numel(), weights.device, truth.shape[0]).ptr
+    return _MetLossFromWeights.apply(weights, x, ptr, truth)
+
+
 def met_loss(met: torch.Tensor, truth: torch.Tensor) -> torch.Tensor:
     """0.5 * mean_b((met[b,0] + truth[b,0])^2 + (met[b,1] + truth[b,1])^2) (model/net.py:58-61) in one kernel."""
     return _MetLoss.apply(met, truth)

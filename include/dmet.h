@@ -267,6 +267,13 @@ int dmet_met_reduce_bwd_f32(const float *g_met, const float *x, int64_t x_stride
 /* loss[0] = 0.5 * mean_b((met[b,0] + truth[b,0])^2 + (met[b,1] + truth[b,1])^2)  (model/net.py:58-61) and
  * g_met[B,2] = d loss / d met, one launch, fixed summation order. */
 int dmet_met_loss_f32(const float *met, const float *truth, int B, float *loss, float *g_met, dmet_stream_t stream);
+/* The same two entries for the fused loss of model/net.py:49-62 (deepmetv2_amd.scatter.met_loss_from_weights): truth rows
+ * of truth_stride floats (px, py in columns 0, 1 of the [B,11] target: no [B,2] copy), and the backward with g_met
+ * multiplied by one device float first (the upstream gradient of the scalar loss: no separate multiply). */
+int dmet_met_loss_strided_f32(const float *met, const float *truth, int64_t truth_stride, int B, float *loss,
+                              float *g_met, dmet_stream_t stream);
+int dmet_met_reduce_bwd_scaled_f32(const float *g_met, const float *scale, const float *x, int64_t x_stride,
+                                   const int64_t *ptr, int B, int64_t N, float *g_w, dmet_stream_t stream);
 /* Generic sorted-index form used by the scatter_add(src, batch) drop-in: out[b] = sum_{i in b} src[i]. */
 int dmet_segment_sum_1d_f32(const float *src, const int64_t *ptr, int B, float *out,
                             dmet_stream_t stream);

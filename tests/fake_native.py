@@ -171,9 +171,11 @@ def met_reduce(w, x, ptr):
     return met
 
 
-def met_reduce_bwd(g_met, x, ptr):
+def met_reduce_bwd(g_met, x, ptr, scale=None):
     B = ptr.numel() - 1
     batch = torch.repeat_interleave(torch.arange(B), ptr.diff())
+    if scale is not None:
+        g_met = g_met * scale
     return g_met[batch, 0] * x[:, 0] + g_met[batch, 1] * x[:, 1]
 
 
