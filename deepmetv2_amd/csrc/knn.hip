@@ -641,6 +641,7 @@ struct KnnFilterArgs {
     const int32_t *xtile_ptr;   // tile prefix of the exact kernel's plan (same event order)
     int xtile_queries;
     int form2;                  // 1: events of kF2MinNodes..kF2MaxNodes nodes are swept by the second form
+    float slack_scale;          // certificate slack relative to the 32-feature bound (1.5 at 64 features)
 };
 
 __device__ __forceinline__ unsigned bf16_rne_bits(float f)   // finite inputs
@@ -657,14 +658,19 @@ __device__ __forceinline__ unsigned bf16_rne_bits(float f)   // finite inputs
 // pieces of 32 different rows -- followed by the 32 squared norms.  Rows past the end of an event are zero with
 // norm = +inf (key = +inf: never admitted), so the sweep needs no range checks.  Event b owns the records
 // [(ptr[b] >> 5) + b, ... + ceil(n_b / 32)): monotone and disjoint without a prefix sum over the events.
-constexpr int kRecFragBytes = 4 * kWave * 16;           // 4096
-constexpr int kRecBytes = kRecFragBytes + 32 * 4;       // + norms = 4224 (33 cache lines)
+constexpr int kRecFragBytes = 4 * kWave * 16;           // 4096: the four operand fragments of 32 features
+// NH = number of 32-feature halves per row (1: D = 32, 2: D = 64, the hidden width of the reference's DRN,
+// model/dynamic_reduction_network.py:40,86): a record holds NH x 4 fragments, then the 32 squared norms
+constexpr int rec_bytes(int NH) { return kRecFragBytes * NH + 32 * 4; }
+constexpr int kRecBytes = rec_bytes(1);                 // 4224 (33 cache lines)
+constexpr int kRecBytesMax = rec_bytes(2);              // the workspace is carved for either width
 
 __device__ __forceinline__ int64_t rec_base_tile(const int64_t *__restrict__ ptr, int b) { return (ptr[b] >> 5) + b; }
 
 // One wavefront per record: lane (col, hh) converts the 16 features of row col it will later feed to the MFMAs.
 // Also writes the flat norm array (certificates) and clears the uncertified-query counters / flags (zero_bytes bytes
 // at `zero`, 4-byte aligned) for the launches that follow, which saves a memset launch per call.
+template <int NH>
 __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__ x, const int64_t *__restrict__ ptr,
                                                         int B, int64_t N, float *__restrict__ nrm,
                                                         uint8_t *__restrict__ rec, int64_t nrec,
@@ -697,35 +703,39 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__
     if (li0 >= n) return;                   // a slot between two events: never read
     const bool live = li0 + col < n;
     const int64_t r = ev_lo + (live ? li0 + col : 0);
-    float f[16];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const float4 *g = reinterpret_cast<const float4 *>(x + r * 32 + 16 * kb + 8 * hh);
-        const float4 v0 = g[0], v1 = g[1];
-        f[8 * kb + 0] = v0.x; f[8 * kb + 1] = v0.y; f[8 * kb + 2] = v0.z; f[8 * kb + 3] = v0.w;
-        f[8 * kb + 4] = v1.x; f[8 * kb + 5] = v1.y; f[8 * kb + 6] = v1.z; f[8 * kb + 7] = v1.w;
-    }
     float s = 0.0f;
-    unsigned h[16], m[16];
+    uint8_t *recp = rec + tile * rec_bytes(NH);
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const float v = live ? f[u] : 0.0f;
-        s = __builtin_fmaf(v, v, s);
-        h[u] = bf16_rne_bits(v);
-        m[u] = bf16_rne_bits(v - __uint_as_float(h[u] << 16));   // the subtraction is exact
+    for (int half = 0; half < NH; ++half) {
+        float f[16];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const float4 *g = reinterpret_cast<const float4 *>(x + r * (32 * NH) + 32 * half + 16 * kb + 8 * hh);
+            const float4 v0 = g[0], v1 = g[1];
+            f[8 * kb + 0] = v0.x; f[8 * kb + 1] = v0.y; f[8 * kb + 2] = v0.z; f[8 * kb + 3] = v0.w;
+            f[8 * kb + 4] = v1.x; f[8 * kb + 5] = v1.y; f[8 * kb + 6] = v1.z; f[8 * kb + 7] = v1.w;
+        }
+        unsigned h[16], m[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float v = live ? f[u] : 0.0f;
+            s = __builtin_fmaf(v, v, s);
+            h[u] = bf16_rne_bits(v);
+            m[u] = bf16_rne_bits(v - __uint_as_float(h[u] << 16));   // the subtraction is exact
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(recp + half * kRecFragBytes);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            dst[kb * 64 + lane] = make_uint4(h[8 * kb] | (h[8 * kb + 1] << 16), h[8 * kb + 2] | (h[8 * kb + 3] << 16),
+                                             h[8 * kb + 4] | (h[8 * kb + 5] << 16), h[8 * kb + 6] | (h[8 * kb + 7] << 16));
+            dst[(2 + kb) * 64 + lane] = make_uint4(m[8 * kb] | (m[8 * kb + 1] << 16), m[8 * kb + 2] | (m[8 * kb + 3] << 16),
+                                                   m[8 * kb + 4] | (m[8 * kb + 5] << 16), m[8 * kb + 6] | (m[8 * kb + 7] << 16));
+        }
     }
-    s += __shfl_xor(s, 32, 64);             // the row's other 16 features: fixed order, deterministic
+    s += __shfl_xor(s, 32, 64);             // the row's other features: fixed order, deterministic
     if (!live) s = __builtin_inff();
-    uint4 *dst = reinterpret_cast<uint4 *>(rec + tile * kRecBytes);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        dst[kb * 64 + lane] = make_uint4(h[8 * kb] | (h[8 * kb + 1] << 16), h[8 * kb + 2] | (h[8 * kb + 3] << 16),
-                                         h[8 * kb + 4] | (h[8 * kb + 5] << 16), h[8 * kb + 6] | (h[8 * kb + 7] << 16));
-        dst[(2 + kb) * 64 + lane] = make_uint4(m[8 * kb] | (m[8 * kb + 1] << 16), m[8 * kb + 2] | (m[8 * kb + 3] << 16),
-                                               m[8 * kb + 4] | (m[8 * kb + 5] << 16), m[8 * kb + 6] | (m[8 * kb + 7] << 16));
-    }
     if (hh == 0) {
-        reinterpret_cast<float *>(rec + tile * kRecBytes + kRecFragBytes)[col] = s;
+        reinterpret_cast<float *>(recp + kRecFragBytes * NH)[col] = s;
         if (live) nrm[r] = s;
     }
 }
@@ -733,27 +743,33 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__
 // One 32(candidates) x 32(queries) block: acc = cinit + sum over both 16-feature k-blocks of  h.h' + h.m' + m.h'.
 // Operand map of v_mfma_f32_32x32x16_bf16: lane (r = lane & 31, hh = lane >> 5) holds A[row r][k = 8 hh + 0..7].
 // av / bv = {high k-block 0, high k-block 1, middle k-block 0, middle k-block 1}.
-__device__ __forceinline__ f32x16 filter_block(const bf16x8 (&av)[4], const bf16x8 (&bv)[4], const f32x16 &cinit)
+template <int NH = 1>
+__device__ __forceinline__ f32x16 filter_block(const bf16x8 (&av)[4 * NH], const bf16x8 (&bv)[4 * NH], const f32x16 &cinit)
 {
-    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], cinit, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[3], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[2], bv[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[3], bv[1], acc, 0, 0, 0);
+    f32x16 acc = cinit;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[4 * h + 0], bv[4 * h + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[4 * h + 1], bv[4 * h + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[4 * h + 0], bv[4 * h + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[4 * h + 1], bv[4 * h + 3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[4 * h + 2], bv[4 * h + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[4 * h + 3], bv[4 * h + 1], acc, 0, 0, 0);
+    }
     return acc;
 }
 
-// one candidate tile record: the lane's four A operands and the squared norms of the 16 candidate rows it receives
+// one candidate tile record: the lane's 4 NH A operands and the squared norms of the 16 candidate rows it receives
 // results for (accumulator seed; rows (e & 3) + 8 (e >> 2) + 4 hh)
-__device__ __forceinline__ void filter_load(bf16x8 (&av)[4], f32x16 &cinit, const uint8_t *__restrict__ rec, int64_t tidx,
-                                            int lane, int hh)
+template <int NH = 1>
+__device__ __forceinline__ void filter_load(bf16x8 (&av)[4 * NH], f32x16 &cinit, const uint8_t *__restrict__ rec,
+                                            int64_t tidx, int lane, int hh)
 {
-    const uint8_t *base = rec + tidx * kRecBytes;
+    const uint8_t *base = rec + tidx * rec_bytes(NH);
     const bf16x8 *g = reinterpret_cast<const bf16x8 *>(base);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) av[m] = g[m * 64 + lane];
-    const float4 *nr = reinterpret_cast<const float4 *>(base + kRecFragBytes);
+    for (int m = 0; m < 4 * NH; ++m) av[m] = g[m * 64 + lane];
+    const float4 *nr = reinterpret_cast<const float4 *>(base + kRecFragBytes * NH);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float4 v = nr[2 * q + hh];
@@ -1220,8 +1236,9 @@ __device__ __forceinline__ void f2_compact(F2Lane<M> &L, F2Wave &S, int lane)
 }
 
 // Operands of one candidate tile (A fragments + accumulator seed).
+template <int NH = 1>
 struct F2Ops {
-    bf16x8 a[4];
+    bf16x8 a[4 * NH];
     f32x16 c;
 };
 
@@ -1233,10 +1250,13 @@ struct F2Ops {
 // 1 MFMA + 11 VALU groups.  UPD: the tile minima feed tk / tau;  REC: hit masks are recorded.
 // INS: this call inserts min(carry, its tile minimum) into the threshold list (every second tile: the list then holds the
 // M smallest minima of tile PAIRS -- still M groups that each contain a key <= tau); otherwise it only updates `carry`.
-template <int M, bool UPD, bool REC, bool INS>
+// NH = 2 (64 features): `use` and `ld` are the SAME operand set (two sets of eight fragments next to the sixteen of
+// the queries do not fit the register file at two wavefronts per SIMD), reloaded right after its MFMAs were issued.
+template <int M, bool UPD, bool REC, bool INS, int NH = 1>
 __device__ __forceinline__ void f2_tile(F2Lane<M> &L, F2Wave &S, const uint8_t *__restrict__ rec, int64_t rbase, int t,
-                                        int t_hi, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1, const F2Ops &use,
-                                        F2Ops &ld, const bf16x8 (&bq)[2][4], int lane, int hh, bool alive, float &carry)
+                                        int t_hi, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1, const F2Ops<NH> &use,
+                                        F2Ops<NH> &ld, const bf16x8 (&bq)[2][4 * NH], int lane, int hh, bool alive,
+                                        float &carry)
 {
 #if defined(DMET_F2_ABL) && DMET_F2_ABL >= 2
     constexpr bool kRec = false;     // cycle-budget experiment (tools/knn_budget2.sh)
@@ -1251,13 +1271,16 @@ __device__ __forceinline__ void f2_tile(F2Lane<M> &L, F2Wave &S, const uint8_t *
     if (kRec) {
         if (__any(L.cnt >= kF2Slots - 1)) f2_compact<M>(L, S, lane);
     }
+    if (NH == 1) {
 #if defined(DMET_F2_SAMEREC)
-    filter_load(ld.a, ld.c, rec, rbase + (t & 1), lane, hh);   // experiment: operands always cache-resident
+        filter_load<NH>(ld.a, ld.c, rec, rbase + (t & 1), lane, hh);   // experiment: operands always cache-resident
 #else
-    filter_load(ld.a, ld.c, rec, rbase + min(t + 2, t_hi - 1), lane, hh);   // clamped: the last two calls re-read the last tile
+        filter_load<NH>(ld.a, ld.c, rec, rbase + min(t + 2, t_hi - 1), lane, hh);   // clamped: the last two calls re-read the last tile
 #endif
-    n0 = filter_block(use.a, bq[0], use.c);     // (s_setprio 1 around these was measured: 10 % slower)
-    n1 = filter_block(use.a, bq[1], use.c);
+    }
+    n0 = filter_block<NH>(use.a, bq[0], use.c);     // (s_setprio 1 around these was measured: 10 % slower)
+    n1 = filter_block<NH>(use.a, bq[1], use.c);
+    if (NH != 1) filter_load<NH>(ld.a, ld.c, rec, rbase + min(t + 2, t_hi - 1), lane, hh);
     // lanes 32..63 of block 0 <-> lanes 0..31 of block 1: afterwards c0 = rows {0-3, 8-11, ..} and c1 = rows
     // {4-7, 12-15, ..} of THIS lane's query
 #if !(defined(DMET_F2_ABL) && DMET_F2_ABL >= 4)
@@ -1329,25 +1352,34 @@ __device__ __forceinline__ void f2_tile(F2Lane<M> &L, F2Wave &S, const uint8_t *
 }
 
 // One pass over the tiles [t_lo, t_hi) of the event whose first record is rbase.
-template <int M, bool UPD, bool REC>
+template <int M, bool UPD, bool REC, int NH = 1>
 __device__ __forceinline__ void f2_sweep(F2Lane<M> &L, F2Wave &S, const uint8_t *__restrict__ rec, int64_t rbase,
-                                         int t_lo, int t_hi, const bf16x8 (&bq)[2][4], int lane, int hh, bool alive)
+                                         int t_lo, int t_hi, const bf16x8 (&bq)[2][4 * NH], int lane, int hh, bool alive)
 {
     if (t_lo >= t_hi) return;
-    F2Ops A, B;
-    filter_load(A.a, A.c, rec, rbase + t_lo, lane, hh);
-    f32x16 c0 = filter_block(A.a, bq[0], A.c);      // prologue: the first tile's keys
-    f32x16 c1 = filter_block(A.a, bq[1], A.c);
+    F2Ops<NH> A;
+    filter_load<NH>(A.a, A.c, rec, rbase + t_lo, lane, hh);
+    f32x16 c0 = filter_block<NH>(A.a, bq[0], A.c);      // prologue: the first tile's keys
+    f32x16 c1 = filter_block<NH>(A.a, bq[1], A.c);
     f32x16 n0, n1;
-    filter_load(A.a, A.c, rec, rbase + min(t_lo + 1, t_hi - 1), lane, hh);
+    filter_load<NH>(A.a, A.c, rec, rbase + min(t_lo + 1, t_hi - 1), lane, hh);
     float carry = kKnnSentinel;
+    if constexpr (NH != 1) {
+        for (int t = t_lo; t < t_hi; t += 2) {
+            f2_tile<M, UPD, REC, true, NH>(L, S, rec, rbase, t, t_hi, c0, c1, n0, n1, A, A, bq, lane, hh, alive, carry);
+            if (t + 1 < t_hi)
+                f2_tile<M, UPD, REC, true, NH>(L, S, rec, rbase, t + 1, t_hi, n0, n1, c0, c1, A, A, bq, lane, hh, alive, carry);
+        }
+        return;
+    }
+    F2Ops<NH> B;
     for (int t = t_lo; t < t_hi; t += 2) {
         // every tile inserts its own minimum (INS = true).  Inserting the minimum of tile PAIRS instead (half the
         // v_med3 chains) was tried: the threshold then admits up to 2M tiles, more than the 26 entries a lane can keep
         // -> 3 761 overflowed queries per launch and twice the kernel time
-        f2_tile<M, UPD, REC, true>(L, S, rec, rbase, t, t_hi, c0, c1, n0, n1, A, B, bq, lane, hh, alive, carry);
+        f2_tile<M, UPD, REC, true, NH>(L, S, rec, rbase, t, t_hi, c0, c1, n0, n1, A, B, bq, lane, hh, alive, carry);
         if (t + 1 < t_hi)
-            f2_tile<M, UPD, REC, true>(L, S, rec, rbase, t + 1, t_hi, n0, n1, c0, c1, B, A, bq, lane, hh, alive, carry);
+            f2_tile<M, UPD, REC, true, NH>(L, S, rec, rbase, t + 1, t_hi, n0, n1, c0, c1, B, A, bq, lane, hh, alive, carry);
     }
 }
 
@@ -1360,10 +1392,11 @@ __device__ __forceinline__ int filter_group(const KnnFilterArgs &a)
 }
 
 // One wavefront's item of the second form; S is the wavefront's own LDS (no workgroup barrier inside).
-template <int KP>
+template <int KP, int NH = 1>
 __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, int group, int wv, int lane)
 {
     constexpr int M = filter_list_len(KP);
+    constexpr int D = 32 * NH;
     constexpr int MS = (M + 1 + 3) & ~3;
     const int col = lane & 31, hh = lane >> 5;
     const uint8_t *__restrict__ rec = a.rec;
@@ -1382,8 +1415,20 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
     const int pos = find_tile_event(a.tile_ptr, a.B, tile);
     const int ev = a.order[pos];
     const int ev_lo = (int)ptr[ev], ev_hi = (int)ptr[ev + 1];
-    if (!f2_in_domain(ev_hi - ev_lo)) return;      // the first form's events
     const int q_first = ev_lo + (tile - a.tile_ptr[pos]) * kFQ;
+    if (!f2_in_domain(ev_hi - ev_lo)) {
+        // the first form's events.  D = 64 has no first form: every query of such an event is handed to the exact
+        // kernel (once per tile: a split tile comes by `split` times)
+        if (NH != 1 && sub == 0) {
+            const int q = q_first + lane;
+            if (q < ev_hi) {
+                a.qflag[q] = 1;
+                atomicAdd(a.flags + a.xtile_ptr[pos] + (q - ev_lo) / a.xtile_queries, 1);
+                atomicAdd(a.any, 1);
+            }
+        }
+        return;
+    }
     int clo = ev_lo, chi = ev_hi;
     if (nsub > 1) {
         const int chunk = (((chi - clo) + nsub - 1) / nsub + 31) & ~31;
@@ -1394,21 +1439,6 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
     const int64_t rlast = rbase + (ev_hi - ev_lo - 1) / 32;
     const int t_lo = (clo - ev_lo) / 32, t_hi = (chi - ev_lo + 31) / 32;
 
-    bf16x8 bq[2][4];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const int64_t qrec = min(rbase + (q_first - ev_lo) / 32 + b, rlast);
-        const bf16x8 *g = reinterpret_cast<const bf16x8 *>(rec + qrec * kRecBytes);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const bf16x8 v = g[m * 64 + lane];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float f = -2.0f * __uint_as_float(((unsigned)(unsigned short)v[u]) << 16);
-                bq[b][m][u] = (short)(__float_as_uint(f) >> 16);
-            }
-        }
-    }
     const int myq = q_first + hh * 32 + col;
     const bool valid = myq < ev_hi;
     F2Lane<M> L;
@@ -1417,11 +1447,28 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
     L.tau = -__builtin_inff();     // nothing is recorded before tk is full
     L.cnt = 0;
     L.overflow = false;
-
-    const int t_def = min(t_hi, t_lo + kF2Defer);
-    f2_sweep<M, true, false>(L, S, rec, rbase, t_lo, t_def, bq, lane, hh, valid);     // tau only
-    f2_sweep<M, true, true>(L, S, rec, rbase, t_def, t_hi, bq, lane, hh, valid);
-    f2_sweep<M, false, true>(L, S, rec, rbase, t_lo, t_def, bq, lane, hh, valid);     // against the final tau
+    {
+        // the query operands live only as long as the sweeps (the re-rank needs the registers for the rows)
+        bf16x8 bq[2][4 * NH];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int64_t qrec = min(rbase + (q_first - ev_lo) / 32 + b, rlast);
+            const bf16x8 *g = reinterpret_cast<const bf16x8 *>(rec + qrec * rec_bytes(NH));
+#pragma unroll
+            for (int m = 0; m < 4 * NH; ++m) {
+                const bf16x8 v = g[m * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float f = -2.0f * __uint_as_float(((unsigned)(unsigned short)v[u]) << 16);
+                    bq[b][m][u] = (short)(__float_as_uint(f) >> 16);
+                }
+            }
+        }
+        const int t_def = min(t_hi, t_lo + kF2Defer);
+        f2_sweep<M, true, false, NH>(L, S, rec, rbase, t_lo, t_def, bq, lane, hh, valid);     // tau only
+        f2_sweep<M, true, true, NH>(L, S, rec, rbase, t_def, t_hi, bq, lane, hh, valid);
+        f2_sweep<M, false, true, NH>(L, S, rec, rbase, t_lo, t_def, bq, lane, hh, valid);     // against the final tau
+    }
     f2_compact<M>(L, S, lane);
 #if defined(DMET_F2_ABL) && DMET_F2_ABL >= 1
     return;
@@ -1429,11 +1476,11 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
 
     // ---- exact re-rank of the set bits (R1 chain, top-k by (d, j)), candidates fetched cooperatively ----------------
     const int64_t qrow_id = valid ? myq : ev_lo;
-    float qrow[32];
+    float qrow[D];
     {
-        const float4 *g = reinterpret_cast<const float4 *>(a.x + qrow_id * 32);
+        const float4 *g = reinterpret_cast<const float4 *>(a.x + qrow_id * D);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < D / 4; ++c) {
             const float4 v = g[c];
             qrow[4 * c] = v.x; qrow[4 * c + 1] = v.y; qrow[4 * c + 2] = v.z; qrow[4 * c + 3] = v.w;
         }
@@ -1464,9 +1511,39 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
         }
         return j;
     };
+    const float4 *x4 = reinterpret_cast<const float4 *>(a.x);
+    if constexpr (NH != 1) {
+        // D = 64: every lane fetches the row of its own candidate (sixteen 16-byte loads in flight) and runs the chain
+        // on it -- none of the cooperative staging of the 32-wide form below, whose register budget (three rounds of
+        // half rows in flight) does not carry over; the sweep, not this loop, is the larger part at this width
+        for (;;) {
+            const int32_t j = pop();
+            if (!__any(j >= 0)) break;
+            const float4 *row = x4 + (int64_t)(j >= 0 ? j : ev_lo) * (D / 4);
+            float4 v[D / 4];
+#pragma unroll
+            for (int c = 0; c < D / 4; ++c) v[c] = row[c];
+            float dc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < D / 4; ++c) {
+                float df;
+                df = v[c].x - qrow[4 * c + 0]; dc = __builtin_fmaf(df, df, dc);
+                df = v[c].y - qrow[4 * c + 1]; dc = __builtin_fmaf(df, df, dc);
+                df = v[c].z - qrow[4 * c + 2]; dc = __builtin_fmaf(df, df, dc);
+                df = v[c].w - qrow[4 * c + 3]; dc = __builtin_fmaf(df, df, dc);
+            }
+            const unsigned long long nk =
+                j >= 0 ? (((unsigned long long)__float_as_uint(dc) << 32) | (unsigned)j) : ~0ull;
+            bool g[KP];
+#pragma unroll
+            for (int p = 0; p < KP; ++p) g[p] = kk[p] > nk;
+#pragma unroll
+            for (int p = KP - 1; p >= 1; --p) kk[p] = g[p - 1] ? kk[p - 1] : (g[p] ? nk : kk[p]);
+            kk[0] = g[0] ? nk : kk[0];
+        }
+    } else {
     // rows are fetched half a row at a time (16 features = 64 bytes): load instruction 4 h + r brings half h of rows
     // 16 r + (lane >> 2), 16 bytes per lane; exhausted lanes re-read the event's first row (no branches, result unused)
-    const float4 *x4 = reinterpret_cast<const float4 *>(a.x);
     struct HalfRows { float4 v0, v1, v2, v3, v4, v5, v6, v7; };   // named members: stays in registers
     auto fetch = [&](int32_t j) __attribute__((always_inline)) -> HalfRows {
         const int32_t jc = j >= 0 ? j : ev_lo;
@@ -1543,6 +1620,7 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
             round(pb, jb);
         }
     }
+    }
     float kd[KP];
     int32_t kj[KP];
 #pragma unroll
@@ -1581,7 +1659,8 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
         const float nx = a.nrm[myq];
         const float an = __builtin_sqrtf(nx) * 1.000001f;
         const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
-        const float slack = 2.0f * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1e-30f;
+        // (64 features: twice the products per key in the fp32 accumulation -- 1.5 x the bound keeps its 2 x margin)
+        const float slack = (NH == 1 ? 2.0f : 3.0f) * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1e-30f;
         const bool full = tau < kKnnSentinel;
         if (L.overflow || (full && !(tau + nx - slack > kth))) {
             const int xt = a.xtile_ptr[pos] + (myq - ev_lo) / a.xtile_queries;
@@ -1606,7 +1685,7 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
 // hundred long serial items on an otherwise idle chip (216 us at 64 events) -- which now run beside the second form's
 // items.  The wavefront number is wave-uniform, but only readfirstlane tells the compiler: without it the tile, the
 // event, the loop counters and every record address are computed per lane on the vector ALU.
-template <int KP>
+template <int KP, int NH = 1>
 __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter12_kernel(const KnnFilterArgs a)
 {
     union WaveLds {
@@ -1616,8 +1695,8 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter12_kernel
     __shared__ WaveLds sh_all[kWavesPerGroup];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int group = filter_group(a);
-    filter2_wave<KP>(a, sh_all[wv].f2, group, wv, lane);   // returns at once unless the item's event is a second-form event
-    filter1_wave<KP>(a, sh_all[wv].f1, group, wv, lane);   // likewise
+    filter2_wave<KP, NH>(a, sh_all[wv].f2, group, wv, lane);   // returns at once unless the item's event is a second-form event
+    if constexpr (NH == 1) filter1_wave<KP>(a, sh_all[wv].f1, group, wv, lane);   // likewise (32 features only)
 }
 
 // Split (tail) tiles of the second form: merge the two exact partial lists of a query by (d, j) and certify against
@@ -1698,7 +1777,7 @@ __global__ __launch_bounds__(256) void knn_filter2_merge_kernel(const KnnFilterA
     if (act && p < 2) {
         const float an = __builtin_sqrtf(nx) * 1.000001f;
         const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
-        const float slack = 2.0f * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1e-30f;
+        const float slack = 2.0f * a.slack_scale * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1e-30f;
         fail = of != 0 || (tau < kKnnSentinel && !(tau + nx - slack > kth));
     }
     const bool other = __shfl_xor(fail ? 1 : 0, 1, 64) != 0;
@@ -2017,7 +2096,7 @@ inline KnnWorkspace carve_workspace(void *ws, int64_t N, int B, int KP)
     w.ftile_ptr = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * ((size_t)B + 1)));
     w.nrm = reinterpret_cast<float *>(take(sizeof(float) * (size_t)N));
     w.nrec = (N >> 5) + B + 1;                               // event b owns records from (ptr[b] >> 5) + b
-    w.rec = reinterpret_cast<uint8_t *>(take((size_t)w.nrec * kRecBytes));
+    w.rec = reinterpret_cast<uint8_t *>(take((size_t)w.nrec * kRecBytesMax));
     w.zero_bytes = sizeof(int32_t) * ((size_t)exact_tiles_max(N, B) + 4) + (size_t)N;
     w.flags = reinterpret_cast<int32_t *>(take(w.zero_bytes));
     w.any = w.flags + exact_tiles_max(N, B);
@@ -2048,29 +2127,31 @@ inline int filter_form2()
 }
 
 // prep + filter (+ in-place re-rank) + re-rank of the split tail tiles, for result capacity KF >= k
-template <int KF>
+template <int KF, int NH = 1>
 int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, const KnnPlanOut &px, const KnnPlanOut &pf,
                   hipStream_t st)
 {
     const int slots = simds * 2;   // two filter wavefronts per SIMD
-    hipLaunchKernelGGL(knn_prep_kernel, dim3((unsigned)((w.nrec * kWave + 255) / 256 + 2)), dim3(256), 0, st, f.x, f.ptr,
-                       f.B, f.N, w.nrm, w.rec, w.nrec, reinterpret_cast<uint32_t *>(w.flags), w.zero_bytes, px, pf);
+    hipLaunchKernelGGL((knn_prep_kernel<NH>), dim3((unsigned)((w.nrec * kWave + 255) / 256 + 2)), dim3(256), 0, st, f.x,
+                       f.ptr, f.B, f.N, w.nrm, w.rec, w.nrec, reinterpret_cast<uint32_t *>(w.flags), w.zero_bytes, px, pf);
     DMET_LAUNCH_CHECK("knn_prep_kernel");
     const int64_t ftiles_max = (f.N + kFQ - 1) / kFQ + f.B;
     const int64_t fblocks = (ftiles_max + slots + kWavesPerGroup - 1) / kWavesPerGroup;
     if (f.form2) {
-        hipLaunchKernelGGL((knn_filter12_kernel<KF>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
+        hipLaunchKernelGGL((knn_filter12_kernel<KF, NH>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
         DMET_LAUNCH_CHECK("knn_filter12_kernel");
     } else {
-        hipLaunchKernelGGL((knn_filter_kernel<KF>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
+        if constexpr (NH == 1) hipLaunchKernelGGL((knn_filter_kernel<KF>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
         DMET_LAUNCH_CHECK("knn_filter_kernel");
     }
     constexpr int kRerankQpb = 4 * (kWave / filter_list_len(KF));
     constexpr int kRerankParts = (kFQ + kRerankQpb - 1) / kRerankQpb;
     // only the split tail tiles (fewer than `slots`) need the separate re-rank: whole sweeps re-rank in place
     const int64_t tail_max = ftiles_max < slots ? ftiles_max : slots;
-    hipLaunchKernelGGL((knn_rerank_kernel<KF>), dim3((unsigned)(tail_max * kRerankParts)), dim3(256), 0, st, f);
-    DMET_LAUNCH_CHECK("knn_rerank_kernel");
+    if constexpr (NH == 1) {    // tail tiles of the first form (32 features only)
+        hipLaunchKernelGGL((knn_rerank_kernel<KF>), dim3((unsigned)(tail_max * kRerankParts)), dim3(256), 0, st, f);
+        DMET_LAUNCH_CHECK("knn_rerank_kernel");
+    }
     if (f.form2) {
         hipLaunchKernelGGL((knn_filter2_merge_kernel<KF>), dim3((unsigned)tail_max), dim3(256), 0, st, f);
         DMET_LAUNCH_CHECK("knn_filter2_merge_kernel");
@@ -2087,7 +2168,9 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     int simds = num_simds();
     if (simds > kMaxSimds) simds = kMaxSimds;
     bool use_filter = false;
-    if constexpr (DP == 32 && KP <= 32) use_filter = D == 32 && k <= 20 && aligned16(x) && filter_mode() != 0;
+    if constexpr ((DP == 32 || DP == 64) && KP <= 32)
+        use_filter = D == DP && k <= 20 && aligned16(x) && filter_mode() != 0 && (DP == 32 || filter_form2());
+    constexpr int NH = DP == 64 ? 2 : 1;   // 64 features (the DRN's hidden width): second filter form only
     const int slots = simds * 2;   // two filter wavefronts per SIMD
     const KnnPlanOut px{QT, simds, kMaxSplit, w.order, w.pos_of, w.tile_ptr, w.plan};
     const KnnPlanOut pf{kFQ, slots, kFilterMaxSplit, w.forder, w.fpos_of, w.ftile_ptr, w.fplan};
@@ -2105,21 +2188,28 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     // the tiles the re-rank could not certify
     if (use_filter) {
         KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.rec, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
-                        w.psd, w.psj, nbr, dist, nbr16, w.flags, w.any, w.qflag, w.tile_ptr, QT, filter_form2()};
+                        w.psd, w.psj, nbr, dist, nbr16, w.flags, w.any, w.qflag, w.tile_ptr, QT, filter_form2(),
+                        NH == 1 ? 1.0f : 1.5f};
         int rc = 0;
-        if constexpr (KP == 8) rc = launch_filter<8>(f, w, simds, px, pf, st);
-        else if constexpr (KP == 16) rc = launch_filter<16>(f, w, simds, px, pf, st);
-        else if constexpr (KP == 32) rc = launch_filter<20>(f, w, simds, px, pf, st);   // 16 < k <= 20 (checked above)
+        if constexpr (DP == 32 || DP == 64) {
+            if constexpr (KP == 8) rc = launch_filter<8, NH>(f, w, simds, px, pf, st);
+            else if constexpr (KP == 16) rc = launch_filter<16, NH>(f, w, simds, px, pf, st);
+            else if constexpr (KP == 32) rc = launch_filter<20, NH>(f, w, simds, px, pf, st);   // 16 < k <= 20 (checked above)
+        }
         if (rc) return rc;
         if (filter_mode() == 2) return 0;
-        const int64_t xtiles_max = (N + QT - 1) / QT + B;
-        // counters exist (and are cleared) for at least xtiles_max tiles; the kernel reads none beyond that
-        hipLaunchKernelGGL(knn_requery_kernel, dim3((unsigned)((xtiles_max + kRequeryTiles - 1) / kRequeryTiles)), dim3(256),
-                           0, st, f, (int)xtiles_max);
-        DMET_LAUNCH_CHECK("knn_requery_kernel");
         a.flags = w.flags;
-        a.flag_min = kRequeryMax + 1;
         a.any = w.any;
+        if constexpr (NH == 1) {
+            const int64_t xtiles_max = (N + QT - 1) / QT + B;
+            // counters exist (and are cleared) for at least xtiles_max tiles; the kernel reads none beyond that
+            hipLaunchKernelGGL(knn_requery_kernel, dim3((unsigned)((xtiles_max + kRequeryTiles - 1) / kRequeryTiles)),
+                               dim3(256), 0, st, f, (int)xtiles_max);
+            DMET_LAUNCH_CHECK("knn_requery_kernel");
+            a.flag_min = kRequeryMax + 1;
+        } else {
+            a.flag_min = 1;    // no per-query fallback at 64 features: the exact kernel takes every flagged tile
+        }
     }
 
     // worst-case grid (the plan is on the device): every event adds at most one partial tile, and splitting the

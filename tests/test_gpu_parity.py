@@ -225,6 +225,41 @@ def test_knn_paths_agree_fuzz(dev, monkeypatch):
         assert torch.equal(n0, n1) and torch.equal(d0, d1), (it, sizes[:5], k, mode, st)
 
 
+def test_knn_64_features_matrix_core_path(dev, monkeypatch):
+    """K1 at the DRN's hidden width (model/dynamic_reduction_network.py:40,86: kNN in 64 features): events of 2048+
+    nodes go through the second filter form with 64-feature records, smaller ones and uncertified tiles through the
+    exact kernel.  Bit-exact against the C oracle on one event, against the exact kernel on ragged / adversarial data."""
+    from oracle import ref_ops
+    g = torch.Generator().manual_seed(64)
+    # (a) oracle: one 2300-node event + a small one (exact path inside the same call), k = 16 and the reference's k = 20
+    sizes = [2300, 150]
+    x = torch.randn(sum(sizes), 64, generator=g)
+    x[700] = x[3]; x[701] = x[3]                                     # exact ties
+    ptr = torch.tensor([0, 2300, 2450])
+    for k in (16, 20):
+        nbr_ref, dist_ref = ref_ops.knn_table(x, ptr, k)
+        n1, d1, st = _knn_with_stats(x.to(dev), ptr.to(dev), k)
+        assert torch.equal(n1, nbr_ref) and torch.equal(d1, dist_ref), (k, st)
+    # (b) against the exact kernel: ragged sizes around the form's lower limit, clustered / heavy-tailed / offset data
+    for it in range(6):
+        sizes = [int(v) for v in torch.randint(1800, 5200, (5,), generator=g)] + [0, 70]
+        N = sum(sizes)
+        x = torch.randn(N, 64, generator=g)
+        if it % 3 == 1:
+            c = torch.randn(5, 64, generator=g) * 3
+            x = c[torch.randint(0, 5, (N,), generator=g)] + 1e-2 * torch.randn(N, 64, generator=g)
+            x[N // 2:N // 2 + 200] = x[:200]
+        elif it % 3 == 2:
+            x = x * torch.exp(1.5 * torch.randn(N, 1, generator=g)) + (50.0 if it == 5 else 0.0)
+        ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.tensor(sizes).cumsum(0)]).to(dev)
+        k = [16, 8, 20][it % 3]
+        monkeypatch.setenv("DMET_KNN_PATH", "exact")
+        n0, d0, _ = _knn_with_stats(x.to(dev), ptr, k)
+        monkeypatch.delenv("DMET_KNN_PATH")
+        n1, d1, st = _knn_with_stats(x.to(dev), ptr, k)
+        assert torch.equal(n0, n1) and torch.equal(d0, d1), (it, sizes, k, st)
+
+
 def test_radius_graph(dev):
     import deepmetv2_amd as dm
     from oracle import ref_ops

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from deepmetv2_amd import _native
 
-n, D, k = 4500, 32, 16
+n, D, k = 4500, int(os.environ.get('KNN_AB_D', '32')), 16
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 out = sys.argv[3] if len(sys.argv) > 3 else None

@@ -7,6 +7,7 @@ from deepmetv2_amd import _native
 
 dev = torch.device("cuda:0")
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 32      # 32, or 64 (the DRN width: second filter form only)
 g = torch.Generator().manual_seed(2024)
 bad = 0
 for it in range(rounds):
@@ -18,16 +19,16 @@ for it in range(rounds):
     if N == 0:
         continue
     k = int([16, 8, 20, 13, 1][it % 5])
-    x = torch.randn(N, 32, generator=g)
+    x = torch.randn(N, D, generator=g)
     mode = it % 4
     if mode == 1:      # clusters + exact duplicates
-        c = torch.randn(7, 32, generator=g) * 3
-        x = c[torch.randint(0, 7, (N,), generator=g)] + 1e-2 * torch.randn(N, 32, generator=g)
+        c = torch.randn(7, D, generator=g) * 3
+        x = c[torch.randint(0, 7, (N,), generator=g)] + 1e-2 * torch.randn(N, D, generator=g)
         x[N // 2:N // 2 + N // 10] = x[:N // 10]
     elif mode == 2:    # heavy tails
         x = x * torch.exp(2.0 * torch.randn(N, 1, generator=g))
     elif mode == 3:    # low-dimensional manifold (many near ties)
-        x = torch.randn(N, 2, generator=g) @ torch.randn(2, 32, generator=g)
+        x = torch.randn(N, 2, generator=g) @ torch.randn(2, D, generator=g)
     ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.tensor(sizes).cumsum(0)]).to(dev)
     xd = x.to(dev)
     os.environ["DMET_KNN_PATH"] = "exact"
