@@ -5,7 +5,7 @@
 //   R1  d(i,j) = chain of fmaf(diff, diff, acc) over the feature index, fp32, diff = x[j,c]-x[i,c]
 //   R2  top-k by (d, j) lexicographic order == upstream's strict-'>' insertion in ascending j
 // R1 / R2 define the RESULT, not the work done on pairs that cannot win.  Three paths, one stream, no host sync:
-//   * D = 32, k <= 20 (the model's shape): a matrix-core FILTER ranks all pairs approximately
+//   * D = 32 (the model's shape) or 64 (the DRN's), k <= 20: a matrix-core FILTER ranks all pairs approximately
 //     (key = |x_j|^2 - 2 x_i.x_j from a bf16 split on v_mfma_f32_32x32x16_bf16), keeps a certified superset of every
 //     query's neighbours, and only those go through the exact R1 chain and the (d, j) order.  Second form
 //     (filter2_wave, events of 2048..65536 nodes): per-tile hit masks, threshold from tile minima; first form
@@ -2184,7 +2184,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     if (!use_filter && hipMemsetAsync(w.flags, 0, w.zero_bytes, st) != hipSuccess)
         return hip_fail(hipGetLastError(), "hipMemsetAsync");
 
-    // matrix-core filter + exact re-rank for the hot shape (D = 32, k <= 20); the exact kernel then only recomputes
+    // matrix-core filter + exact re-rank for the hot shapes (D = 32 or 64, k <= 20); the exact kernel then only recomputes
     // the tiles the re-rank could not certify
     if (use_filter) {
         KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.rec, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
