@@ -589,6 +589,29 @@ def test_gather_max_local_ids_kernel_matches(dev, k):
             assert torch.equal(o0, o1) and (not want_arg or torch.equal(a0, a1))
 
 
+def test_gather_max_work_mappings_agree(dev, monkeypatch):
+    """K3: the LDS gather kernel's two block -> work mappings (one workgroup per (event, slice); one workgroup per CU
+    walking equal ranges of the [event][slice][node] axis, whose boundaries cut events and slices) must give the
+    same bits on a ragged batch with empty, tiny and oversized events, for both table forms and P / Q layouts."""
+    from deepmetv2_amd import _native
+    sizes = [1900, 0, 3, 4800, 64, 5150, 1, 2500, 700]
+    x, batch, ptr = _ragged(sizes, 32, seed=21)
+    xd, ptrd = x.to(dev), ptr.to(dev)
+    nbr, _, loc = _native.knn_local(xd, ptrd, 16)
+    g = torch.Generator().manual_seed(5)
+    W = (torch.randn(32, 64, generator=g) * 0.2).to(dev)
+    b = torch.randn(32, generator=g).to(dev)
+    for sliced in (False, True):
+        P, Q = _native.node_linear_split(xd, W, b, sliced=sliced)
+        for nl in (loc, None):
+            res = {}
+            for mode in ("0", "1"):
+                monkeypatch.setenv("DMET_GATHER_BALANCED", mode)
+                res[mode] = _native.gather_max(P, Q, nbr, ptrd, True, lds=True, nbr_local=nl, sliced=sliced)
+            monkeypatch.delenv("DMET_GATHER_BALANCED")
+            assert torch.equal(res["0"][0], res["1"][0]) and torch.equal(res["0"][1], res["1"][1])
+
+
 def test_max_ties_and_empty_rows(dev):
     """R3: empty target -> 0.  R4: gradient to the lowest edge position among exact ties."""
     import deepmetv2_amd as dm
