@@ -288,3 +288,31 @@ def test_knn_second_filter_form_paths_agree_fuzz(dev, monkeypatch):
         n2, d2 = _native.knn(xd, ptr, k)
         monkeypatch.delenv("DMET_KNN_FILTER")
         assert torch.equal(n0, n2) and torch.equal(d0, d2), (it, sizes, k, mode, "first form")
+
+
+@pytest.mark.parametrize("D", [32, 64])
+def test_knn_filter_form_boundaries(dev, monkeypatch, D):
+    """Event sizes on both sides of every switch of the matrix-core path -- 2047 / 2048 / 2049 nodes (first vs second
+    filter form; exact kernel vs second form at 64 features) and 65535 / 65536 / 65537 nodes (16-bit candidate ids, the
+    second form's upper limit) -- against the exact kernel."""
+    from deepmetv2_amd import _native
+    g = torch.Generator().manual_seed(700 + D)
+    for sizes in ([2047, 2048, 2049, 31], [65535], [65536, 5], [65537]):
+        N = sum(sizes)
+        x = torch.randn(N, D, generator=g).to(dev)
+        ptr = _ptr(sizes).to(dev)
+        monkeypatch.setenv("DMET_KNN_PATH", "exact")
+        n0, d0 = _native.knn(x, ptr, 16)
+        monkeypatch.delenv("DMET_KNN_PATH")
+        st = {}
+        n1, d1 = _native.knn(x, ptr, 16, stats=st)
+        assert torch.equal(n0, n1) and torch.equal(d0, d1), (sizes, st)
+
+
+def test_knn_many_tiny_events(dev):
+    """More events than the launch plans rank by size (4096): 5000 events of 0..40 nodes, every row against the C oracle
+    (events shorter than k yield short rows padded with -1 / 1e10)."""
+    g = torch.Generator().manual_seed(9)
+    sizes = [int(v) for v in torch.randint(0, 41, (5000,), generator=g)]
+    x = torch.randn(sum(sizes), 32, generator=g)
+    _knn_vs_oracle(dev, x, sizes, 16)
