@@ -18,7 +18,7 @@ constexpr int kHin = 32, kHid = 16;
 constexpr int kXPad = 36;                      // emb tile row stride (floats)
 constexpr int kAPad = 20;                      // [g_z1 (16) | g_z | 0 0 0] and [h1 (16) | 1 | 0 0 0] tiles
 constexpr int kHeadWaves = 4;
-constexpr int kHeadPartial = 2 * 1024;         // per wavefront: A^T.emb tile, A^T.[h1|1] tile
+constexpr int kHeadPartial = 1024 + 64;        // per wavefront: the A^T.emb tile, then [gW2 (16) | gb2 | .. | gb1 (16) | ..]
 
 __device__ __forceinline__ void head_wave_sync()
 {
@@ -96,14 +96,18 @@ __global__ __launch_bounds__(64 * kHeadWaves, 2) void head_bwd_kernel(const floa
 {
     __shared__ float sX[kHeadWaves][64 * kXPad];
     __shared__ float sA[kHeadWaves][64 * kAPad];
-    __shared__ float sB[kHeadWaves][64 * kAPad];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    float *X = sX[wv], *A = sA[wv], *Bt = sB[wv];
+    float *X = sX[wv], *A = sA[wv];
     const int64_t wave = (int64_t)blockIdx.x * kHeadWaves + wv;
     const int64_t lo = wave * nodes_per_wave, hi = min(N, lo + nodes_per_wave);
-    f32x16 acc0, acc1;
+    f32x16 acc0;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
+    for (int e = 0; e < 16; ++e) acc0[e] = 0.0f;
+    // gW2 = sum g_z h1, gb1 = sum g_z1, gb2 = sum g_z: 33 numbers -- per-lane sums over the lane's nodes, one butterfly
+    // per wavefront at the end (a second 32x32 MFMA tile for them cost as much as the gW1 tile)
+    float aW2[kHid], ab1[kHid], ab2 = 0.0f;
+#pragma unroll
+    for (int o = 0; o < kHid; ++o) { aW2[o] = 0.0f; ab1[o] = 0.0f; }
     for (int64_t base = lo; base < hi; base += 64) {
         // opaque zero offset: keeps the (loop-invariant) scalar weight loads inside the loop (see encoder.hip)
         int zero = 0;
@@ -131,10 +135,11 @@ __global__ __launch_bounds__(64 * kHeadWaves, 2) void head_bwd_kernel(const floa
             const float h = head_elu(a);
             gz1[o] = gz * w2[o] * (a > 0.0f ? 1.0f : h + 1.0f);          // through Linear 2 and the ELU
             A[lane * kAPad + o] = gz1[o];
-            Bt[lane * kAPad + o] = h;
+            aW2[o] = __builtin_fmaf(gz, h, aW2[o]);
+            ab1[o] += gz1[o];
         }
-        A[lane * kAPad + 16] = gz; A[lane * kAPad + 17] = 0.0f; A[lane * kAPad + 18] = 0.0f; A[lane * kAPad + 19] = 0.0f;
-        Bt[lane * kAPad + 16] = 1.0f; Bt[lane * kAPad + 17] = 0.0f; Bt[lane * kAPad + 18] = 0.0f; Bt[lane * kAPad + 19] = 0.0f;
+        ab2 += gz;
+        A[lane * kAPad + 16] = 0.0f; A[lane * kAPad + 17] = 0.0f; A[lane * kAPad + 18] = 0.0f; A[lane * kAPad + 19] = 0.0f;
         // g_emb row = W1^T g_z1 (rows of W1 read sequentially).  W1 is re-loaded through a second opaque offset: kept
         // live from the recompute above, its 512 scalars overflow the SGPR file (546 SGPR spills before this)
         int zero2 = 0;
@@ -149,7 +154,6 @@ __global__ __launch_bounds__(64 * kHeadWaves, 2) void head_bwd_kernel(const floa
             for (int f = 0; f < kHin; ++f) gx[f] = __builtin_fmaf(w1b[o * kHin + f], gz1[o], gx[f]);
         head_wave_sync();
         head_mma<kXPad>(acc0, A, X, lane);            // rows 0..15: gW1 = g_z1^T emb
-        head_mma<kAPad>(acc1, A, Bt, lane);           // row 16: [gW2 | gb2];  column 16 of rows 0..15: gb1
         head_wave_sync();
         // g_emb through the (now free) emb tile for coalesced stores
 #pragma unroll
@@ -172,8 +176,19 @@ __global__ __launch_bounds__(64 * kHeadWaves, 2) void head_bwd_kernel(const floa
     for (int e = 0; e < 16; ++e) {
         const int r = (e & 3) + 8 * (e >> 2) + 4 * hh;
         out[r * 32 + c] = acc0[e];
-        out[1024 + r * 32 + c] = acc1[e];
     }
+    float mine = 0.0f;      // lane l of the tail: l < 16 gW2[l], l == 16 gb2, 32 <= l < 48 gb1[l - 32]
+#pragma unroll
+    for (int o = 0; o < kHid; ++o) {
+        const float sw = wave_sum(aW2[o]), sb = wave_sum(ab1[o]);
+        if (lane == o) mine = sw;
+        if (lane == 32 + o) mine = sb;
+    }
+    {
+        const float s2 = wave_sum(ab2);
+        if (lane == 16) mine = s2;
+    }
+    out[1024 + lane] = mine;
 }
 
 // ordered sum of the wavefront partials (32 thread groups, then 32 group sums) and routing to the four gradients
@@ -183,7 +198,7 @@ __global__ __launch_bounds__(1024) void head_bwd_finalize_kernel(const float *__
 {
     __shared__ float red[32][33];
     const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + e;            // element of the 2 x [32][32] partial; a block owns one tile row
+    const int idx = blockIdx.x * 32 + e;            // element of the [32][32] tile + 64-float tail; a block owns 32 of them
     float s = 0.0f;
 #pragma unroll 8   // independent loads: keep eight in flight (the sum order is unchanged)
     for (int64_t w = grp; w < nwaves; w += 32) s += partial[w * kHeadPartial + idx];
@@ -193,13 +208,14 @@ __global__ __launch_bounds__(1024) void head_bwd_finalize_kernel(const float *__
     s = 0.0f;
 #pragma unroll
     for (int q = 0; q < 32; ++q) s += red[q][e];
-    const int t = idx >> 10, r = (idx & 1023) >> 5, c = idx & 31;
-    if (t == 0) {
+    if (idx < 1024) {
+        const int r = idx >> 5, c = idx & 31;
         if (r < kHid) gW1[r * kHin + c] = s;
     } else {
-        if (r < kHid && c == 16) gb1[r] = s;
-        else if (r == 16 && c < kHid) gW2[c] = s;
-        else if (r == 16 && c == 16) gb2[0] = s;
+        const int l = idx - 1024;
+        if (l < kHid) gW2[l] = s;
+        else if (l == 16) gb2[0] = s;
+        else if (l >= 32 && l < 32 + kHid) gb1[l - 32] = s;
     }
 }
 
