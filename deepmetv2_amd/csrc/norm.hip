@@ -36,6 +36,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_reduce_kernel(const float *__re
     if (rr < rpb) {
         if (MODE == 0) sa = reinterpret_cast<const float4 *>(x)[c4];                      // shift: row 0
         else { sa = reinterpret_cast<const float4 *>(stat_a)[c4]; sb = reinterpret_cast<const float4 *>(stat_b)[c4]; }
+#pragma unroll 4   // four rows in flight per thread (the adds keep their order: same bits)
         for (int64_t i = lo + rr; i < hi; i += rpb) {
             const float4 v = reinterpret_cast<const float4 *>(x + i * H)[c4];
             if (MODE == 0) {
