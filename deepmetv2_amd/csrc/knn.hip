@@ -1851,7 +1851,7 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
 #pragma unroll 1
     for (int t = 0; t < kFilterMaxSplit; ++t) {
         float ct = kKnnSentinel;
-        const int32_t j = (t == 0) ? myj[0] : myj[kFilterMaxSplit - 1];
+        int32_t j = (t == 0) ? myj[0] : myj[kFilterMaxSplit - 1];
         if (active && t < nsub) {
             const int idx = t * M + l;
             if (j >= 0) {
@@ -1871,6 +1871,13 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
                     df = v.w - qv.w; acc = __builtin_fmaf(df, df, acc);
                 }
                 ct = acc;
+                // a candidate at or beyond the sentinel distance (or NaN) is never a neighbour (dmet_oracle.c:62: strict
+                // '>' against the 1e10 the lists start from) -- it counts as a missing entry from here on
+                if (!(ct < kKnnSentinel)) {
+                    ct = kKnnSentinel;
+                    j = -1;
+                    if (t == 0) myj[0] = -1; else myj[kFilterMaxSplit - 1] = -1;
+                }
             }
             sc[slot][idx] = ct;
             sj[slot][idx] = (j >= 0) ? j : (0x7fffffff - idx);   // missing entries sort last, all distinct

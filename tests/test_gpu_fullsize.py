@@ -10,6 +10,8 @@
   that tie to the last ulp.  The result must still be the C oracle's bits; where the certificate cannot hold, the
   exact fallback must have run (flagged_queries > 0).
 """
+import os
+
 import pytest
 import torch
 
@@ -200,15 +202,22 @@ def _knn_vs_oracle(dev, x, sizes, k):
     return st
 
 
-@pytest.mark.parametrize("D", [32, 64])
+@pytest.mark.parametrize("D", [32, 64, "32-first-form"])
 @pytest.mark.parametrize("sizes", [[2500, 900], [4500]])
 @pytest.mark.parametrize("case", ["nonfinite_rows", "beyond_sentinel", "feature_tails", "common_offset",
                                   "mirrored_ulp_ties", "tight_far_cluster"])
-def test_knn_filter_adversarial(dev, case, sizes, D):
+def test_knn_filter_adversarial(dev, monkeypatch, case, sizes, D):
     """Matrix-core filter + certificate on hostile inputs, events on both sides of the 2048-node switch between the
     two filter forms, at the model's width (32) and the DRN's (64: second form only, exact kernel for the rest).  Bits
     must equal the C oracle's (dmet_oracle.c:62: a candidate at d >= 1e10 or NaN is never a neighbour, short results
     are -1 / 1e10)."""
+    if D == "32-first-form":
+        # every event through the first filter form: with [4500] alone all its tiles are split tail tiles, i.e. the
+        # sub-sweep merge of knn_rerank_kernel decides every row (found there: candidates at >= 1e10 were ranked)
+        monkeypatch.setenv("DMET_KNN_FILTER", "1")
+        D = 32
+    filter_runs = (os.environ.get("DMET_KNN_PATH", "") != "exact"
+                   and not (D == 64 and os.environ.get("DMET_KNN_FILTER", "") == "1"))   # 64 features: second form only
     seeds = {"nonfinite_rows": 11, "beyond_sentinel": 12, "feature_tails": 13, "common_offset": 14,
              "mirrored_ulp_ties": 15, "tight_far_cluster": 16}
     g = torch.Generator().manual_seed(seeds[case] * 10 + len(sizes) + D)
@@ -246,7 +255,7 @@ def test_knn_filter_adversarial(dev, case, sizes, D):
         x = c[torch.randint(0, 6, (N,), generator=g)] + 1e-3 * x
         expect_fallback = True
     st = _knn_vs_oracle(dev, x.contiguous(), sizes, k)
-    if expect_fallback:
+    if expect_fallback and filter_runs:
         assert st["flagged_queries"] > 0, st     # the certificate cannot hold here: the exact fallback must have run
     if case == "feature_tails":
         # (at 64 features the events below the second form's 2048 nodes are handed to the exact kernel wholesale)

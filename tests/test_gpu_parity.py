@@ -510,8 +510,10 @@ def test_counted_radius_table_consumers_go_by_cnt(dev, monkeypatch, reverse_rout
         o0, a0 = _native.gather_max(Pb, Qb, nb, pb, True, cnt=cb, lds=False)
         o1, a1 = _native.gather_max(Pb, Qb, nb, pb, True, cnt=cb, lds=True)
         assert torch.equal(o0, o1) and torch.equal(a0, a1)
-        # slice-major P / Q through the counted LDS kernel (small events, then the oversized one)
-        for Pr, Qr, tb, pp, cc in ((Pm, Qm, nbr_u, ptr, cnt_p), (Pb, Qb, nb, pb, cb)):
+        # slice-major P / Q through the counted LDS kernel (small events, then the oversized one); not under
+        # DMET_GATHER_MAX_FORM=l2-only, which has no reader for that layout
+        for Pr, Qr, tb, pp, cc in (((Pm, Qm, nbr_u, ptr, cnt_p), (Pb, Qb, nb, pb, cb))
+                                   if _native.GATHER_MAX_FORM != "l2-only" else ()):
             Ps = Pr.view(-1, 4, 8).permute(1, 0, 2).contiguous()
             Qs = Qr.view(-1, 4, 8).permute(1, 0, 2).contiguous()
             o0, a0 = _native.gather_max(Pr, Qr, tb, pp, True, cnt=cc, lds=True)
@@ -1060,17 +1062,19 @@ def test_counted_gather_winner_ids_and_ordered_rows(dev):
         out2, argj2 = _native.gather_max_counted_j16(P, Q, t.nbr, t.cnt, None, t.ptr, sliced)      # without the order
         assert torch.equal(out1, out2) and torch.equal(argj, argj2)
         # ids from the uint16 rows written by the radius kernel: same bits again
-        assert t.rows16 is not None and t.rows16.shape == (N, 256)
-        out4, argj4 = _native.gather_max_local_j16(P, Q, t.rows16, t.cnt, order, t.ptr, t.k, sliced)
-        assert torch.equal(out1, out4) and torch.equal(argj, argj4)
+        if _native.RADIUS_FORM != "sweep":     # the all-pairs form (DMET_RADIUS=sweep) writes the int32 table only
+            assert t.rows16 is not None and t.rows16.shape == (N, 256)
+            out4, argj4 = _native.gather_max_local_j16(P, Q, t.rows16, t.cnt, order, t.ptr, t.k, sliced)
+            assert torch.equal(out1, out4) and torch.equal(argj, argj4)
     # the uint16 rows themselves: slots < cnt = local ids, the rest of the last started chunk = 0xFFFF
-    slot = torch.arange(256, device=dev).view(1, -1)
-    c = t.cnt.long().view(-1, 1)
-    r16 = t.rows16.long() & 0xFFFF
-    want = torch.zeros_like(r16); want[:, :255] = t.nbr.long() - lo
-    assert torch.equal(torch.where(slot < c, r16, 0 * r16), torch.where(slot < c, want, 0 * want))
-    pad = (slot >= c) & (slot < (c + 7) // 8 * 8)
-    assert bool((r16[pad] == 0xFFFF).all())
+    if t.rows16 is not None:
+        slot = torch.arange(256, device=dev).view(1, -1)
+        c = t.cnt.long().view(-1, 1)
+        r16 = t.rows16.long() & 0xFFFF
+        want = torch.zeros_like(r16); want[:, :255] = t.nbr.long() - lo
+        assert torch.equal(torch.where(slot < c, r16, 0 * r16), torch.where(slot < c, want, 0 * want))
+        pad = (slot >= c) & (slot < (c + 7) // 8 * 8)
+        assert bool((r16[pad] == 0xFFFF).all())
     gout = torch.randn(N, H, generator=g).to(dev)
     gq0 = _native.gather_max_bwd_lds(gout, arg8, t.nbr, t.ptr)
     gq1 = _native.gather_max_bwd_j16(gout, argj, t.ptr)
