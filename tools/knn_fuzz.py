@@ -29,6 +29,16 @@ for it in range(rounds):
         x = x * torch.exp(2.0 * torch.randn(N, 1, generator=g))
     elif mode == 3:    # low-dimensional manifold (many near ties)
         x = torch.randn(N, 2, generator=g) @ torch.randn(2, D, generator=g)
+    hostile = (it // 4) % 3     # every third block of four rounds: far rows / non-finite rows on top of the mode
+    if hostile == 1 and N >= 8:     # rows 1e5..1e6 from the origin: distances >= 1e10 must come back as -1
+        idx = torch.randperm(N, generator=g)[: max(2, N // 40)]
+        x[idx] = x[idx] * torch.empty(idx.numel(), 1).uniform_(1e5, 1e6, generator=g)
+        x[idx[:2]] = x[idx[0]].clone()
+    elif hostile == 2 and N >= 8:   # NaN / +-inf entries
+        idx = torch.randperm(N, generator=g)[: max(3, N // 60)]
+        x[idx[0::3], it % D] = float("nan")
+        x[idx[1::3], (it + 1) % D] = float("inf")
+        x[idx[2::3]] = float("-inf")
     ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.tensor(sizes).cumsum(0)]).to(dev)
     xd = x.to(dev)
     os.environ["DMET_KNN_PATH"] = "exact"
@@ -38,7 +48,7 @@ for it in range(rounds):
     n1, d1 = _native.knn(xd, ptr, k, stats=st)
     ok = torch.equal(n0, n1) and torch.equal(d0, d1)
     bad += 0 if ok else 1
-    print(f"round {it:2d}: B={B:2d} N={N:6d} k={k:2d} mode={mode} flagged_queries={st['flagged_queries']:6d} "
+    print(f"round {it:2d}: B={B:2d} N={N:6d} k={k:2d} mode={mode} hostile={hostile} flagged_queries={st['flagged_queries']:6d} "
           f"{'ok' if ok else 'MISMATCH rows=' + str(int((n0 != n1).any(1).sum()))}")
 print("mismatching rounds:", bad)
 sys.exit(1 if bad else 0)
