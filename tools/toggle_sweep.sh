@@ -1,0 +1,15 @@
+#!/bin/bash
+# tools/toggle_sweep.sh : the GPU test suite under every diagnostic / A-B environment switch (GPU box; ~35 s per switch).
+# Alternative paths rot quietly: this round the sweep found the first filter form's tail merge ranking candidates at
+# >= 1e10.  Tests that assert the DEFAULT path's own counters or layouts are expected to fail under some switches
+# (DMET_GATHER_MAX_FORM=l2-only: the direct slice-major calls; DMET_KNN_PATH=exact: the flagged-query counters).
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out/toggles
+for t in "DMET_NONE=1" "DMET_GATHER_MAX_FORM=l2-only" "DMET_EDGECONV_FORM=fused" "DMET_RADIUS=sweep" "DMET_RADIUS_IDS=int32" \
+         "DMET_RADIUS_J16=0" "DMET_KNN_FILTER=1" "DMET_KNN_PATH=exact" "DMET_FUSED_ENCODER=0" "DMET_GATHER_BWD=reverse" \
+         "DMET_PQ_SLICED=0" "DMET_GATHER_BALANCED=0" "DMET_GATHER_BALANCED=1" "DMET_GATHER_MIXED=1"; do
+  n=$(echo $t | tr "=" "_")
+  env $t timeout -k 10 300 python -m pytest tests -m gpu -q 2>&1 | tail -8 > gpurun_out/toggles/$n.txt
+  echo "$t: $(tail -1 gpurun_out/toggles/$n.txt)"
+  grep FAILED gpurun_out/toggles/$n.txt | head -6
+done
