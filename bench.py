@@ -29,8 +29,8 @@ FP32_VALU_PEAK_TFLOPS = 157.3
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--events-per-gpu", type=int, default=64)
     ap.add_argument("--nodes", type=int, default=4500)
     ap.add_argument("--k", type=int, default=16)
@@ -53,6 +53,10 @@ def parse_args():
                     help="device: the batch is resident in HBM when the timed region starts (the metric's definition); "
                          "host: every step takes its batch from pinned host memory through deepmetv2_amd.DeviceLoader "
                          "(copied on a side stream two batches ahead), i.e. the PCIe-inclusive rate")
+    ap.add_argument("--prewarm-ms", type=float, default=200.0,
+                    help="untimed run-in before the W warm-up steps: the same step repeated for this long, so that the "
+                         "module loads, the allocator's growth and the GPU's clock ramp are over when warm-up starts "
+                         "(a cold start makes the first ~30 steps 5 %% slower); 0 disables it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-events", type=int, default=0, help="0 = one event per host core (max 16)")
     return ap.parse_args()
@@ -390,6 +394,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    prewarm_steps = 0
+    if args.prewarm_ms > 0:
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize(dev)
+            prewarm_steps += 8
     for _ in range(args.warmup):
         step()
     ev_overhead_ms = _native.timer.calibrate(dev)
@@ -399,14 +411,21 @@ def main():
     _native.timer.enabled = True
     _native.timer.reset()
     import gc
-    gc.collect()
-    gc.disable()          # a collection inside the timed loop stalls the launch thread for a whole step or more
+    # no collection inside the timed loop (it stalls the launch thread for a step or more) -- and none right before it
+    # either: after a gc.collect() the first step takes the launch thread 2.2 ms instead of 1.2 and the GPU waits
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
+    dbg = [] if os.environ.get("DMET_BENCH_STEP_TIMES") == "1" else None
     for _ in range(args.steps):
         step()
+        if dbg is not None:
+            dbg.append(time.perf_counter() - t0)
     barrier()
     elapsed = time.perf_counter() - t0
+    if dbg is not None:
+        print("host enqueue time per step (ms):", [round(1e3 * (b - a), 3) for a, b in zip([0.0] + dbg[:-1], dbg)][:25],
+              "total", round(1e3 * elapsed, 3), file=sys.stderr)
     gc.enable()
     _native.timer.enabled = False
     ksum = _native.timer.summary()
@@ -459,7 +478,7 @@ def main():
                                    "frac_of_floor_sum": round((fl["mfma_floor_us"] + fl["valu_floor_us"]) / (ksum["knn"][1] * 1e3), 3)})
         out = {
             "metric": "events/sec (4.5k PF cands, k=16)", "value": round(events / elapsed, 1), "unit": "events/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": prewarm_steps,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload_label(args, B, n, k), "events_per_gpu": B,
