@@ -48,3 +48,29 @@ def test_collate_and_loader():
     assert sorted(loaders["train"].indices + loaders["test"].indices) == list(range(9))
     seen = sum(bt.num_graphs for bt in loaders["train"])
     assert seen == 8 and len(loaders["train"]) == 4
+
+
+def test_graph_registry_does_not_leak(monkeypatch):
+    """radius_graph / knn_graph hand out a [2,E] tensor and remember its table so that EdgeConv can find it again: once
+    the caller drops the tensor, the table and the registry entry must go too (no garbage collector involved)."""
+    import gc
+    import weakref
+    import torch
+    from tests import fake_native
+    fake_native.install(monkeypatch)
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import graph
+    gc.disable()
+    try:
+        before = len(graph._graph_registry)
+        x = torch.rand(40, 2)
+        batch = torch.zeros(40, dtype=torch.int64)
+        ei = dm.radius_graph(x, 0.3, batch, loop=True, max_num_neighbors=16)
+        table, _flow = graph.lookup_graph(ei)
+        wt = weakref.ref(table)
+        del table
+        assert len(graph._graph_registry) == before + 1 and wt() is not None
+        del ei
+        assert len(graph._graph_registry) == before and wt() is None
+    finally:
+        gc.enable()
