@@ -5,6 +5,7 @@ Every function requires ROCm device tensors and raises otherwise -- there is no 
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import Optional, Tuple
 
@@ -31,6 +32,18 @@ def _require_device(*tensors: torch.Tensor) -> torch.device:
 
 def _stream(dev: torch.device) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
+
+
+_NULL_CTX = contextlib.nullcontext()
+
+
+def _on(dev: torch.device):
+    """Context that makes `dev` the current device for a native call -- a no-op object when it already is (the usual
+    case: one process per GPU): entering torch.cuda.device() costs the launch thread several microseconds per call,
+    ~70 times per training step."""
+    if dev.index is None or torch.cuda.current_device() == dev.index:
+        return _NULL_CTX
+    return torch.cuda.device(dev)
 
 
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -122,14 +135,14 @@ def _knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict], want
     nb = L.dmet_knn_workspace_bytes(N, B, D, k)
     ws = _ws(nb, dev)
     _t = timer.record('knn', dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_knn_local_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, k, nbr.data_ptr(), dist.data_ptr(),
                                         loc.data_ptr() if want_local else None, ws.data_ptr(), ws.numel(),
                                         _stream(dev)), "dmet_knn_local_f32")
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))
     if stats is not None and N > 0 and B > 0:
-        with torch.cuda.device(dev):
+        with _on(dev):
             import ctypes
             out = (ctypes.c_int64 * 2)()
             _lib.check(L.dmet_knn_fallback_stats(ws.data_ptr(), N, B, D, k, ctypes.cast(out, ctypes.c_void_p),
@@ -175,7 +188,7 @@ def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int, skip_self
             stride16 = (max_nbr + 7) // 8 * 8
             rows16 = torch.empty((N, stride16), dtype=torch.int16, device=dev)
             ws = _ws(L.dmet_radius_workspace_bytes(N), dev)
-            with torch.cuda.device(dev):
+            with _on(dev):
                 _lib.check(L.dmet_radius_windowed_local_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, float(r), max_nbr,
                                                             1 if skip_self else 0, 1 if pad else 0, nbr.data_ptr(),
                                                             cnt.data_ptr(), rows16.data_ptr(), stride16, ws.data_ptr(),
@@ -183,7 +196,7 @@ def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int, skip_self
             return nbr, cnt, rows16
         nbr, cnt = radius(x, ptr, r, max_nbr, skip_self, pad)
         return nbr, cnt, None
-    with torch.cuda.device(dev):
+    with _on(dev):
         if RADIUS_FORM == "sweep":      # all pairs of an event (A/B and fallback)
             fn = L.dmet_radius_f32 if pad else L.dmet_radius_counted_f32
             _lib.check(fn(x.data_ptr(), ptr.data_ptr(), B, N, D, float(r), max_nbr, 1 if skip_self else 0,
@@ -214,7 +227,7 @@ def node_linear_split(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor
     PQ = torch.empty((2, Hout // 8, N, 8) if sliced else (2, N, Hout), dtype=torch.float32, device=dev)
     bp = _f32c(b, "b").data_ptr() if b is not None else None
     _t = timer.record('node_linear_split', dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         fn = L.dmet_node_linear_split_sliced_f32 if sliced else L.dmet_node_linear_split_f32
         _lib.check(fn(x.data_ptr(), N, Hin, Hout, W.data_ptr(), bp, PQ[0].data_ptr(), PQ[1].data_ptr(), _stream(dev)),
                    "dmet_node_linear_split_f32")
@@ -243,7 +256,7 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
         _t = timer.record('gather_max', dev)
         _note_gather("gather_max_lds_kernel (events <= 5119 nodes: Q slice resident in LDS) + gather_max_mlp_kernel "
                      "(larger events: row gathers from L2), chosen per event in one call; row-major P/Q")
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(L.dmet_gather_max_mixed_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(),
                                                    nbr_local.data_ptr() if nbr_local is not None else None,
                                                    ptr.data_ptr(), ptr.numel() - 1, N, k, H, out.data_ptr(),
@@ -265,7 +278,7 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
         _t = timer.record('gather_max', dev)
         _note_gather("gather_max_lds_kernel (per-event Q slice resident in LDS; slice-major P/Q, "
                      + ("uint16 event-local ids)" if nbr_local is not None else "int32 ids)"))
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(L.dmet_gather_max_lds_sliced_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(),
                                                         nbr_local.data_ptr() if nbr_local is not None else None,
                                                         ptr.data_ptr(), ptr.numel() - 1, N, k, H, out.data_ptr(),
@@ -276,7 +289,7 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
         return out, arg
     if cnt is not None:
         _t = timer.record('gather_max', dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             if lds and ptr is not None and H % 8 == 0 and GATHER_MAX_FORM != "l2-only":
                 _note_gather("gather_max_lds_kernel, counted rows (radius table; Q slice resident in LDS"
                              + (", slice-major P/Q)" if sliced else ")"))
@@ -297,7 +310,7 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
         return out, arg
     _t = timer.record('gather_max', dev)
     use_lds = (lds or GATHER_MAX_FORM == "lds") and GATHER_MAX_FORM != "l2-only" and ptr is not None and H % 8 == 0
-    with torch.cuda.device(dev):
+    with _on(dev):
         if use_lds and nbr_local is not None and k in (8, 16, 32):
             if nbr_local.shape != nbr.shape or nbr_local.dtype != torch.int16 or not nbr_local.is_contiguous():
                 raise ValueError("nbr_local must be the contiguous int16 [N, k] table of knn_local()")
@@ -324,7 +337,7 @@ def table_order_by_count(cnt: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:
     L = _lib.load()
     N = cnt.numel()
     order = torch.empty((N,), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_table_order_by_count(cnt.data_ptr(), ptr.data_ptr(), ptr.numel() - 1, N, order.data_ptr(),
                                                _stream(dev)), "dmet_table_order_by_count")
     return order
@@ -345,7 +358,7 @@ def gather_max_counted_j16(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, 
     _t = timer.record('gather_max', dev)
     _note_gather("gather_max_lds_kernel, counted rows (radius table; Q slice resident in LDS, winner ids, rows ordered by "
                  "depth" + (", slice-major P/Q)" if sliced else ")"))
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_gather_max_counted_lds_j16_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(), cnt.data_ptr(),
                                                          order.data_ptr() if order is not None else None, ptr.data_ptr(),
                                                          ptr.numel() - 1, N, k, H, 1 if sliced else 0, out.data_ptr(),
@@ -369,7 +382,7 @@ def gather_max_local_j16(P: torch.Tensor, Q: torch.Tensor, rows16: torch.Tensor,
     _t = timer.record('gather_max', dev)
     _note_gather("gather_max_lds_kernel, counted rows (radius table as event-local uint16 rows; Q slice resident in LDS, "
                  "winner ids, rows ordered by depth" + (", slice-major P/Q)" if sliced else ")"))
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_gather_max_local_j16_f32(P.data_ptr(), Q.data_ptr(), rows16.data_ptr(), rows16.shape[1],
                                                    cnt.data_ptr(), order.data_ptr() if order is not None else None,
                                                    ptr.data_ptr(), ptr.numel() - 1, N, kmax, H, 1 if sliced else 0,
@@ -389,7 +402,7 @@ def gather_max_bwd_j16(g_out: torch.Tensor, argj: torch.Tensor, ptr: torch.Tenso
         raise TypeError("gather_max_bwd_j16: argj must be the contiguous int16 [N,H] tensor of gather_max_counted_j16")
     gQ = torch.empty((N, H), dtype=torch.float32, device=dev)
     _t = timer.record('gather_max_bwd', dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_gather_max_bwd_j16_f32(g_out.data_ptr(), argj.data_ptr(), ptr.data_ptr(), ptr.numel() - 1, N, H,
                                                  gQ.data_ptr(), _stream(dev)), "dmet_gather_max_bwd_j16_f32")
     if _t is not None:
@@ -411,7 +424,7 @@ def edgeconv_fused_lds(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tenso
     bp = _f32c(b, "b").data_ptr() if b is not None else None
     _t = timer.record('edgeconv_fused', dev)
     _note_gather("edgeconv_fused_lds_kernel (gather + edge-MLP + max in one launch)")
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_edgeconv_fused_lds_f32(x.data_ptr(), nbr.data_ptr(), ptr.data_ptr(), ptr.numel() - 1, N, k,
                                                  Hin, Hout, W.data_ptr(), bp, out.data_ptr(),
                                                  arg.data_ptr() if want_arg else None, _stream(dev)),
@@ -440,7 +453,7 @@ def edge_mlp2_bf16(x: torch.Tensor, nbr: torch.Tensor, W1: torch.Tensor, b1: Opt
         raise TypeError("edge_mlp2: nbr must be a contiguous int32 [N, k] table")
     out = torch.empty((N, H2), dtype=torch.float32, device=dev)
     _t = timer.record('edge_mlp2', dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_edge_mlp2_bf16(x.data_ptr(), N, Hin, nbr.data_ptr(), k, W1.data_ptr(),
                                          _f32c(b1, "b1").data_ptr() if b1 is not None else None, H1, W2.data_ptr(),
                                          _f32c(b2, "b2").data_ptr() if b2 is not None else None, H2, 1 if act2 else 0,
@@ -461,7 +474,7 @@ def node_linear_split_bf16(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.T
     Qh = torch.empty((N, Hout), dtype=torch.bfloat16, device=dev)
     bp = _f32c(b, "b").data_ptr() if b is not None else None
     _t = timer.record('node_linear_split', dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_node_linear_split_bf16(x.data_ptr(), N, Hin, Hout, W.data_ptr(), bp, P.data_ptr(),
                                                  Qh.data_ptr(), _stream(dev)), "dmet_node_linear_split_bf16")
     if _t is not None:
@@ -478,7 +491,7 @@ def gather_max_bf16q(P: torch.Tensor, Qh: torch.Tensor, nbr: torch.Tensor, want_
     arg = torch.empty((N, H), dtype=torch.uint8, device=dev) if want_arg else None
     _t = timer.record('gather_max', dev)
     _note_gather("gather_max_bf16q_kernel (gather + max over the bf16 Q table, gathers from L2)")
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_gather_max_bf16q(P.data_ptr(), Qh.data_ptr(), nbr.data_ptr(), N, k, H, out.data_ptr(),
                                            arg.data_ptr() if want_arg else None, _stream(dev)), "dmet_gather_max_bf16q")
     if _t is not None:
@@ -494,7 +507,7 @@ def gather_max_bwd(g_out: torch.Tensor, arg: torch.Tensor, rev_ptr: torch.Tensor
     N, H = g_out.shape
     gQ = torch.empty((N, H), dtype=torch.float32, device=dev)
     _t = timer.record('gather_max_bwd', dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_gather_max_bwd_f32(g_out.data_ptr(), arg.data_ptr(), rev_ptr.data_ptr(),
                                              rev_slot.data_ptr(), N, k, H, gQ.data_ptr(), _stream(dev)),
                    "dmet_gather_max_bwd_f32")
@@ -513,7 +526,7 @@ def reverse_index(keys: torch.Tensor, num_keys: int) -> Tuple[torch.Tensor, torc
     rev_ptr = torch.empty((num_keys + 1,), dtype=torch.int32, device=dev)
     rev_pos = torch.empty((max(M, 1),), dtype=torch.int32, device=dev)
     _t = timer.record('reverse_index', dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = _ws(L.dmet_reverse_index_workspace_bytes(M, num_keys), dev)
         _lib.check(L.dmet_reverse_index(keys.data_ptr(), M, num_keys, rev_ptr.data_ptr(), rev_pos.data_ptr(),
                                         ws.data_ptr(), ws.numel(), _stream(dev)), "dmet_reverse_index")
@@ -530,7 +543,7 @@ def edge_features(x: torch.Tensor, src: torch.Tensor, tgt: torch.Tensor) -> torc
     E = src.numel()
     H = x.shape[1]
     feat = torch.empty((E, 2 * H), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_edge_features_f32(x.data_ptr(), src.data_ptr(), tgt.data_ptr(), E, H, feat.data_ptr(),
                                             _stream(dev)), "dmet_edge_features_f32")
     return feat
@@ -542,7 +555,7 @@ def edge_features_bwd(g_feat: torch.Tensor, rowptr: torch.Tensor, srcptr: torch.
     L = _lib.load()
     g_feat = _f32c(g_feat, "g_feat")
     gx = torch.empty((N, H), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_edge_features_bwd_f32(g_feat.data_ptr(), rowptr.data_ptr(), srcptr.data_ptr(),
                                                 srcperm.data_ptr(), N, H, gx.data_ptr(), _stream(dev)),
                    "dmet_edge_features_bwd_f32")
@@ -556,7 +569,7 @@ def segment_max(msg: torch.Tensor, rowptr: torch.Tensor, N: int) -> Tuple[torch.
     H = msg.shape[1]
     out = torch.empty((N, H), dtype=torch.float32, device=dev)
     arg = torch.empty((N, H), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_segment_max_f32(msg.data_ptr(), rowptr.data_ptr(), N, H, out.data_ptr(), arg.data_ptr(),
                                           _stream(dev)), "dmet_segment_max_f32")
     return out, arg
@@ -568,7 +581,7 @@ def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, N: int) -> torch.Tensor
     msg = _f32c(msg, "msg")
     H = msg.shape[1]
     out = torch.empty((N, H), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_segment_sum_f32(msg.data_ptr(), rowptr.data_ptr(), N, H, out.data_ptr(), _stream(dev)),
                    "dmet_segment_sum_f32")
     return out
@@ -580,7 +593,7 @@ def segment_max_bwd(g_out: torch.Tensor, arg: torch.Tensor, rowptr: torch.Tensor
     g_out = _f32c(g_out, "g_out")
     N, H = g_out.shape
     g_msg = torch.empty((E, H), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_segment_max_bwd_f32(g_out.data_ptr(), arg.data_ptr(), rowptr.data_ptr(), N, H,
                                               g_msg.data_ptr(), _stream(dev)), "dmet_segment_max_bwd_f32")
     return g_msg
@@ -592,7 +605,7 @@ def segment_sum_bwd(g_out: torch.Tensor, rowptr: torch.Tensor, E: int) -> torch.
     g_out = _f32c(g_out, "g_out")
     N, H = g_out.shape
     g_msg = torch.empty((E, H), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_segment_sum_bwd_f32(g_out.data_ptr(), rowptr.data_ptr(), N, H, g_msg.data_ptr(),
                                               _stream(dev)), "dmet_segment_sum_bwd_f32")
     return g_msg
@@ -608,7 +621,7 @@ def met_reduce(w: torch.Tensor, x: torch.Tensor, ptr: torch.Tensor) -> torch.Ten
     B = ptr.numel() - 1
     met = torch.empty((B, 2), dtype=torch.float32, device=dev)
     _t = timer.record('met_reduce', dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_met_reduce_f32(w.data_ptr(), x.data_ptr(), x.stride(0), ptr.data_ptr(), B, met.data_ptr(),
                                          _stream(dev)), "dmet_met_reduce_f32")
     if _t is not None:
@@ -630,7 +643,7 @@ def met_reduce_bwd(g_met: torch.Tensor, x: torch.Tensor, ptr: torch.Tensor,
         if scale.dtype != torch.float32 or scale.numel() != 1 or scale.device != dev:
             raise ValueError("met_reduce_bwd: scale must be one float32 on the device")
         sp = scale.data_ptr()
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_met_reduce_bwd_scaled_f32(g_met.data_ptr(), sp, x.data_ptr(), x.stride(0), ptr.data_ptr(), B, N,
                                                     g_w.data_ptr(), _stream(dev)), "dmet_met_reduce_bwd_scaled_f32")
     return g_w
@@ -642,7 +655,7 @@ def segment_sum_1d(src: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:
     src = _f32c(src, "src")
     B = ptr.numel() - 1
     out = torch.empty((B,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_segment_sum_1d_f32(src.data_ptr(), ptr.data_ptr(), B, out.data_ptr(), _stream(dev)),
                    "dmet_segment_sum_1d_f32")
     return out
@@ -655,7 +668,7 @@ def batch_to_ptr(batch: torch.Tensor, B: int) -> torch.Tensor:
         batch = batch.to(torch.int64)
     batch = batch.contiguous()
     ptr = torch.empty((B + 1,), dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_batch_to_ptr(batch.data_ptr(), batch.numel(), B, ptr.data_ptr(), _stream(dev)),
                    "dmet_batch_to_ptr")
     return ptr
@@ -671,7 +684,7 @@ def xty(A: torch.Tensor, Bm: torch.Tensor) -> torch.Tensor:
     Hb = Bm.shape[1]
     C = torch.empty((Ha, Hb), dtype=torch.float32, device=dev)
     _t = timer.record("xty", dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = _ws(L.dmet_xty_workspace_bytes(N, Ha, Hb), dev)
         _lib.check(L.dmet_xty_f32(A.data_ptr(), Bm.data_ptr(), N, Ha, Hb, C.data_ptr(), ws.data_ptr(), ws.numel(),
                                   _stream(dev)), "dmet_xty_f32")
@@ -689,7 +702,7 @@ def onehot_xty(index: torch.Tensor, Bm: torch.Tensor, num_rows: int) -> torch.Te
     index = index.contiguous(); Bm = _f32c(Bm, "B")
     N, Hb = Bm.shape
     C = torch.empty((num_rows, Hb), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = _ws(L.dmet_xty_workspace_bytes(N, num_rows, Hb), dev)
         _lib.check(L.dmet_onehot_xty_f32(index.data_ptr(), Bm.data_ptr(), N, num_rows, Hb, C.data_ptr(), ws.data_ptr(),
                                          ws.numel(), _stream(dev)), "dmet_onehot_xty_f32")
@@ -734,7 +747,7 @@ def encode_fwd(x_cont: torch.Tensor, x_cat: torch.Tensor, params) -> torch.Tenso
     ps = _encode_params(params, dev)
     N = x.shape[0]
     h = torch.empty((N, 32), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_encode_fwd_f32(x.data_ptr(), x.stride(0), xc.data_ptr() if xc is not None else None, N, *[t.data_ptr() for t in ps],
                                          h.data_ptr(), _stream(dev)), "dmet_encode_fwd_f32")
     return h
@@ -751,7 +764,7 @@ def encode_bwd(x_cont: torch.Tensor, x_cat: torch.Tensor, params, h: torch.Tenso
     grads = [torch.empty_like(t) for t in ps]
     if N == 0:
         return [g.zero_() for g in grads]
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = _ws(L.dmet_encode_bwd_workspace_bytes(N), dev)
         _lib.check(L.dmet_encode_bwd_f32(x.data_ptr(), x.stride(0), xc.data_ptr() if xc is not None else None, N, *[t.data_ptr() for t in ps],
                                          h.data_ptr(), g_h.data_ptr(), *[g.data_ptr() for g in grads], ws.data_ptr(),
@@ -778,7 +791,7 @@ def bn_fwd(x: torch.Tensor, residual: Optional[torch.Tensor], gamma: torch.Tenso
     gamma = _f32c(gamma, "gamma"); beta = _f32c(beta, "beta")
     y = torch.empty_like(x)
     stats = torch.empty((2, H), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = _ws(L.dmet_bn_workspace_bytes(N, H), dev)
         nbt = None
         if num_batches_tracked is not None and training:
@@ -803,7 +816,7 @@ def bn_bwd(x: torch.Tensor, g_y: torch.Tensor, gamma: torch.Tensor, save_mean: t
     N, H = x.shape
     g_x = torch.empty_like(x)
     gg = torch.empty((2, H), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = _ws(L.dmet_bn_workspace_bytes(N, H), dev)
         _lib.check(L.dmet_bn_bwd_f32(x.data_ptr(), g_y.data_ptr(), N, H, gamma.data_ptr(), save_mean.data_ptr(),
                                      save_invstd.data_ptr(), g_x.data_ptr(), gg[0].data_ptr(), gg[1].data_ptr(),
@@ -826,7 +839,7 @@ def edgeconv_linear_bwd(x: torch.Tensor, weight: torch.Tensor, g_out: torch.Tens
     gx = torch.empty_like(x)
     gW = torch.empty_like(weight)
     gb = torch.empty((H,), dtype=torch.float32, device=dev) if want_bias else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = _ws(L.dmet_edgeconv_linear_bwd_workspace_bytes(N, H), dev)
         if g_add is not None:
             g_add = _f32c(g_add, "g_add")
@@ -854,7 +867,7 @@ def gather_max_bwd_lds(g_out: torch.Tensor, arg: torch.Tensor, nbr: torch.Tensor
     B = ptr.numel() - 1
     gQ = torch.empty((N, H), dtype=torch.float32, device=dev)
     _t = timer.record('gather_max_bwd', dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         if nbr_local is not None and (nbr_local.shape != nbr.shape or nbr_local.dtype != torch.int16
                                       or not nbr_local.is_contiguous()):
             raise ValueError("nbr_local must be the contiguous int16 [N, k] table of knn_local()")
@@ -877,7 +890,7 @@ def met_loss(met: torch.Tensor, truth: torch.Tensor):
     B = met.shape[0]
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
     g = torch.empty_like(met)
-    with torch.cuda.device(dev):    # px, py are columns 0, 1 of the rows: no [B,2] copy of the [B,11] target
+    with _on(dev):    # px, py are columns 0, 1 of the rows: no [B,2] copy of the [B,11] target
         _lib.check(L.dmet_met_loss_strided_f32(met.data_ptr(), truth.data_ptr(), truth.stride(0), B, loss.data_ptr(),
                                                g.data_ptr(), _stream(dev)), "dmet_met_loss_strided_f32")
     return loss, g
@@ -905,7 +918,7 @@ def head_fwd(emb: torch.Tensor, params) -> torch.Tensor:
     ps = _head_params(params, dev)
     N = emb.shape[0]
     out = torch.empty((N,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.dmet_head_fwd_f32(emb.data_ptr(), N, *[t.data_ptr() for t in ps], out.data_ptr(), _stream(dev)),
                    "dmet_head_fwd_f32")
     return out
@@ -922,7 +935,7 @@ def head_bwd(emb: torch.Tensor, params, out: torch.Tensor, g_out: torch.Tensor):
     grads = [torch.empty_like(t) for t in ps]
     if N == 0:
         return [g_emb] + [g.zero_() for g in grads]
-    with torch.cuda.device(dev):
+    with _on(dev):
         ws = _ws(L.dmet_head_bwd_workspace_bytes(N), dev)
         _lib.check(L.dmet_head_bwd_f32(emb.data_ptr(), N, ps[0].data_ptr(), ps[1].data_ptr(), ps[2].data_ptr(),
                                        out.data_ptr(), g_out.data_ptr(), g_emb.data_ptr(),
@@ -939,7 +952,7 @@ def table_rowptr(nbr: torch.Tensor, cnt: Optional[torch.Tensor]) -> torch.Tensor
     rowptr = torch.zeros((N + 1,), dtype=torch.int32, device=dev)
     if N:
         deg = torch.empty((N,), dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(L.dmet_table_degree(nbr.data_ptr(), cnt.data_ptr() if cnt is not None else None, N, k,
                                            deg.data_ptr(), _stream(dev)), "dmet_table_degree")
         torch.cumsum(deg, 0, dtype=torch.int32, out=rowptr[1:])
@@ -956,7 +969,7 @@ def table_edges(nbr: torch.Tensor, cnt: Optional[torch.Tensor], rowptr: torch.Te
     s32 = torch.empty((num_edges,), dtype=torch.int32, device=dev) if want_int32 else None
     t32 = torch.empty((num_edges,), dtype=torch.int32, device=dev) if want_int32 else None
     if N and num_edges:
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(L.dmet_table_edges(nbr.data_ptr(), cnt.data_ptr() if cnt is not None else None, rowptr.data_ptr(),
                                           N, k, 1 if swap else 0,
                                           ei[0].data_ptr() if ei is not None else None,
