@@ -47,4 +47,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(20):
     step()
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28); st.sort_stats("cumtime").print_stats(30)
