@@ -44,6 +44,9 @@ SIGNATURES = {
     "dmet_gather_max_lds16_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "dmet_edge_mlp2_supported": (_i, [_i, _i, _i, _i]),
     "dmet_edge_mlp2_bf16": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "dmet_edge_mlp2_bn_workspace_bytes": (_sz, [_i64, _i]),
+    "dmet_edge_mlp2_bn_bf16": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp,
+                                    _i, _vp, _vp, _sz, _vp]),
     "dmet_table_order_by_count": (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
     "dmet_gather_max_counted_lds_j16_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "dmet_gather_max_local_j16_f32": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp]),

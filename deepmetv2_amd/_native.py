@@ -463,6 +463,38 @@ def edge_mlp2_bf16(x: torch.Tensor, nbr: torch.Tensor, W1: torch.Tensor, b1: Opt
     return out
 
 
+def edge_mlp2_bn_bf16(x: torch.Tensor, nbr: torch.Tensor, W1: torch.Tensor, b1: Optional[torch.Tensor], W2: torch.Tensor,
+                      b2: Optional[torch.Tensor], act2: bool, add: bool, gamma: Optional[torch.Tensor],
+                      beta: Optional[torch.Tensor], eps: float, momentum: float, running_mean: Optional[torch.Tensor],
+                      running_var: Optional[torch.Tensor], num_batches_tracked: Optional[torch.Tensor],
+                      training: bool) -> torch.Tensor:
+    """edge_mlp2_bf16 followed by BatchNorm1d(H2) over the edge messages, then the aggregation (include/dmet.h:
+    dmet_edge_mlp2_bn_bf16); the running statistics are updated in place in training mode."""
+    dev = _require_device(x, nbr, W1, W2, b1, b2, gamma, beta)
+    L = _lib.load()
+    x = _f32c(x, "x"); W1 = _f32c(W1, "W1"); W2 = _f32c(W2, "W2")
+    N, Hin = x.shape
+    H1, H2, k = W1.shape[0], W2.shape[0], nbr.shape[1]
+    if W1.shape[1] != 2 * Hin or W2.shape[1] != H1:
+        raise ValueError(f"edge_mlp2: W1 must be [H1, {2 * Hin}] and W2 [H2, H1], got {tuple(W1.shape)}, {tuple(W2.shape)}")
+    if nbr.dtype != torch.int32 or not nbr.is_contiguous():
+        raise TypeError("edge_mlp2: nbr must be a contiguous int32 [N, k] table")
+    out = torch.empty((N, H2), dtype=torch.float32, device=dev)
+    ptr = lambda t: _f32c(t, "param").data_ptr() if t is not None else None
+    _t = timer.record('edge_mlp2', dev)
+    with _on(dev):
+        ws = _ws(L.dmet_edge_mlp2_bn_workspace_bytes(N, H2), dev)
+        _lib.check(L.dmet_edge_mlp2_bn_bf16(x.data_ptr(), N, Hin, nbr.data_ptr(), k, W1.data_ptr(), ptr(b1), H1, W2.data_ptr(),
+                                            ptr(b2), H2, 1 if act2 else 0, 1 if add else 0, ptr(gamma), ptr(beta), float(eps),
+                                            float(momentum), ptr(running_mean), ptr(running_var),
+                                            num_batches_tracked.data_ptr() if num_batches_tracked is not None else None,
+                                            1 if training else 0, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+                   "dmet_edge_mlp2_bn_bf16")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
+    return out
+
+
 def node_linear_split_bf16(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
     """bf16-MFMA variant: P fp32 [N,H], Q as bf16 [N,H] (gathered table)."""
     dev = _require_device(x, W, b)

@@ -166,21 +166,31 @@ class _EdgeConvLinearMax(torch.autograd.Function):
 
 
 def _as_mlp2(nn_module):
-    """(lin1, lin2, act2) when `nn` is Sequential(Linear, ELU, Linear[, ELU]) (ELU alpha = 1): the edge MLP of
-    model/dynamic_reduction_network.py:59-63 without its trailing BatchNorm; else None."""
-    if not isinstance(nn_module, torch.nn.Sequential) or len(nn_module) not in (3, 4):
+    """(lin1, lin2, act2, bn) when `nn` is Sequential(Linear, ELU, Linear[, ELU][, BatchNorm1d]) (ELU alpha = 1): the
+    edge MLP of model/dynamic_reduction_network.py:59-70, with or without its trailing BatchNorm (bn = None); else None."""
+    if not isinstance(nn_module, torch.nn.Sequential) or len(nn_module) not in (3, 4, 5):
         return None
-    l1, a1, l2 = nn_module[0], nn_module[1], nn_module[2]
+    mods = list(nn_module)
+    bn = None
+    if isinstance(mods[-1], torch.nn.BatchNorm1d):
+        bn = mods.pop()
+        if bn.momentum is None or (not bn.track_running_stats and not bn.training):
+            return None     # cumulative moving average / eval without statistics: the generic route
+    if len(mods) not in (3, 4):
+        return None
+    l1, a1, l2 = mods[0], mods[1], mods[2]
     if not (isinstance(l1, torch.nn.Linear) and isinstance(l2, torch.nn.Linear) and isinstance(a1, torch.nn.ELU)):
         return None
     if a1.alpha != 1.0 or l1.weight.dtype != torch.float32 or l2.in_features != l1.out_features:
         return None
     act2 = False
-    if len(nn_module) == 4:
-        if not isinstance(nn_module[3], torch.nn.ELU) or nn_module[3].alpha != 1.0:
+    if len(mods) == 4:
+        if not isinstance(mods[3], torch.nn.ELU) or mods[3].alpha != 1.0:
             return None
         act2 = True
-    return l1, l2, act2
+    if bn is not None and bn.num_features != l2.out_features:
+        return None
+    return l1, l2, act2, bn
 
 
 class _EdgeMLP2Bf16(torch.autograd.Function):
@@ -189,22 +199,42 @@ class _EdgeMLP2Bf16(torch.autograd.Function):
     differentiates that: straight-through over the bf16 roundings, no per-edge tensor kept between the passes."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, table, act2, add, recompute):
-        out = _native.edge_mlp2_bf16(x, table.nbr, W1, b1, W2, b2, act2, add)
-        ctx.save_for_backward(x, W1, b1, W2, b2)
+    def forward(ctx, x, W1, b1, W2, b2, table, act2, add, recompute, bn=None, gamma=None, beta=None):
+        if bn is None:
+            out = _native.edge_mlp2_bf16(x, table.nbr, W1, b1, W2, b2, act2, add)
+        else:
+            training = bn.training or not bn.track_running_stats
+            track = bn.track_running_stats
+            out = _native.edge_mlp2_bn_bf16(x, table.nbr, W1, b1, W2, b2, act2, add, gamma, beta, bn.eps, bn.momentum,
+                                            bn.running_mean if track else None, bn.running_var if track else None,
+                                            bn.num_batches_tracked if (track and training) else None, training)
+        ctx.save_for_backward(x, W1, b1, W2, b2, gamma, beta)
         ctx.recompute = recompute
+        ctx.bn = bn
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        x, W1, b1, W2, b2 = ctx.saved_tensors
-        with torch.enable_grad():
-            xx = x.detach().requires_grad_(True)
-            out = ctx.recompute(xx)
-        wanted = [(0, xx), (1, W1), (2, b1), (3, W2), (4, b2)]
-        wanted = [(i, t) for i, t in wanted if t is not None and ctx.needs_input_grad[i]]
-        grads = torch.autograd.grad(out, [t for _, t in wanted], g_out.contiguous(), allow_unused=True)
-        res = [None] * 9
+        x, W1, b1, W2, b2, gamma, beta = ctx.saved_tensors
+        bn = ctx.bn
+        # the recomputation runs the user's nn, BatchNorm module included: its running statistics were already updated by
+        # the forward kernel, so the module must not move them a second time
+        frozen = bn is not None and bn.training and bn.track_running_stats
+        if frozen:
+            momentum, tracked = bn.momentum, bn.num_batches_tracked.clone()
+            bn.momentum = 0.0
+        try:
+            with torch.enable_grad():
+                xx = x.detach().requires_grad_(True)
+                out = ctx.recompute(xx)
+            wanted = [(0, xx), (1, W1), (2, b1), (3, W2), (4, b2), (10, gamma), (11, beta)]
+            wanted = [(i, t) for i, t in wanted if t is not None and ctx.needs_input_grad[i]]
+            grads = torch.autograd.grad(out, [t for _, t in wanted], g_out.contiguous(), allow_unused=True)
+        finally:
+            if frozen:
+                bn.momentum = momentum
+                bn.num_batches_tracked.copy_(tracked)
+        res = [None] * 12
         for (i, _), g in zip(wanted, grads):
             res[i] = g
         return tuple(res)
@@ -274,9 +304,10 @@ class EdgeConv(torch.nn.Module):
                 and _native.edge_mlp2_supported(x.shape[1], mlp[0].out_features, mlp[1].out_features, table.k)):
             # generic two-layer nn, bf16 compute requested: both dense layers on the matrix cores, fused with the
             # aggregation (no [E, 2H] tensor); the fp32 route below stays the default and the backward's reference
-            l1, l2, act2 = mlp
+            l1, l2, act2, bn = mlp
             out = _EdgeMLP2Bf16.apply(x, l1.weight, l1.bias, l2.weight, l2.bias, table, act2, self.aggr != "max",
-                                      lambda xx: self._forward_edges(xx, table.edge_list()))
+                                      lambda xx: self._forward_edges(xx, table.edge_list()), bn,
+                                      bn.weight if bn is not None else None, bn.bias if bn is not None else None)
             return (out, x) if passthrough else out
         out = self._forward_edges(x, table.edge_list())
         return (out, x) if passthrough else out

@@ -68,12 +68,20 @@ struct EdgeMlpLds {
     float b2[H2];
 };
 
-template <int HIN, int H1P, int H2, bool ADD>
+// BN (the trailing BatchNorm1d of the DRN's edge MLP, model/dynamic_reduction_network.py:59-70: it normalises the
+// MESSAGES, before the aggregation): a per-channel affine map m -> a m + b commutes with the aggregation --
+// sum_s (a m_s + b) = a sum_s m_s + cnt b, and max_s (a m_s + b) = a max_s m_s + b for a >= 0, a min_s m_s + b for
+// a < 0 -- so ONE pass over the edges suffices: it writes the un-normalised aggregates (sum + edge count, or max and
+// min), and, for batch statistics, per-wavefront partial sums of m and m^2 over the valid edges; a one-workgroup kernel
+// turns those into (a, b) and a node-level kernel applies them (edge_mlp2_bn_*_kernel below).
+template <int HIN, int H1P, int H2, bool ADD, bool BN = false>
 __global__ __launch_bounds__(256, 2) void edge_mlp2_kernel(const float *__restrict__ x, const int32_t *__restrict__ nbr,
                                                             int64_t N, int k, const float *__restrict__ W1,
                                                             const float *__restrict__ b1, int H1,
                                                             const float *__restrict__ W2, const float *__restrict__ b2,
-                                                            int act2, float *__restrict__ out)
+                                                            int act2, float *__restrict__ out,
+                                                            float *__restrict__ out2 = nullptr,
+                                                            float *__restrict__ partial = nullptr)
 {
     using L = EdgeMlpLds<HIN, H1P, H2>;
     constexpr int MB1 = L::MB1, KS1 = L::KS1, MB2 = L::MB2, KS2 = L::KS2, KH = HIN / 16;
@@ -109,6 +117,14 @@ __global__ __launch_bounds__(256, 2) void edge_mlp2_kernel(const float *__restri
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
     const float ninf = -__builtin_inff();
+    // BN: this lane's sums of m and m^2 over its valid edges, for its 16 channels of each 32-channel block, + edge count
+    float st1[BN ? MB2 : 1][16], st2[BN ? MB2 : 1][16], stc = 0.0f;
+    if (BN) {
+#pragma unroll
+        for (int mb2 = 0; mb2 < MB2; ++mb2)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st1[mb2][e] = 0.0f; st2[mb2][e] = 0.0f; }
+    }
 
     for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
         const int64_t node = tile * npt + r / k;
@@ -162,21 +178,136 @@ __global__ __launch_bounds__(256, 2) void edge_mlp2_kernel(const float *__restri
             for (int ks = 0; ks < KS2; ++ks)
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S.w2[mb2][ks][lane], h1f[ks >> 1][ks & 1], acc, 0, 0, 0);
             // messages of this lane's edge for channels 32 mb2 + (e & 3) + 8 (e >> 2) + 4 hh; reduce over the node's k edges
-            float res[16];
+            float res[16], res2[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float m = act2 ? elu1(acc[e]) : acc[e];
-                m = valid ? m : (ADD ? 0.0f : ninf);
+                const float m0 = act2 ? elu1(acc[e]) : acc[e];
+                if (BN && partial) {
+                    const float mv = valid ? m0 : 0.0f;
+                    st1[mb2][e] += mv;
+                    st2[mb2][e] = __builtin_fmaf(mv, mv, st2[mb2][e]);
+                }
+                float m = valid ? m0 : (ADD ? 0.0f : ninf);
                 m = group_reduce<ADD>(m, k);
-                res[e] = (!ADD && m == ninf) ? 0.0f : m;      // a node without any neighbour aggregates to 0 (R3)
+                if (BN) {
+                    res[e] = m;                                // sum, or max with -inf for "no neighbour"
+                    if (!ADD) res2[e] = group_reduce<false>(valid ? -m0 : ninf, k);   // -min
+                } else {
+                    res[e] = (!ADD && m == ninf) ? 0.0f : m;   // a node without any neighbour aggregates to 0 (R3)
+                }
             }
             if (live && slot == 0) {
                 float4 *dst = reinterpret_cast<float4 *>(out + node * H2 + 32 * mb2 + 4 * hh);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dst[2 * q] = make_float4(res[4 * q], res[4 * q + 1], res[4 * q + 2], res[4 * q + 3]);
+                if (BN && !ADD) {
+                    float4 *dst2 = reinterpret_cast<float4 *>(out2 + node * H2 + 32 * mb2 + 4 * hh);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        dst2[2 * q] = make_float4(-res2[4 * q], -res2[4 * q + 1], -res2[4 * q + 2], -res2[4 * q + 3]);
+                }
             }
         }
+        if (BN) {
+            const float c = group_reduce<true>(valid ? 1.0f : 0.0f, k);     // valid edges of the node
+            if (ADD && live && slot == 0 && hh == 0) out2[node] = c;
+            if (hh == 0) stc += valid ? 1.0f : 0.0f;
+        }
     }
+    if (BN && partial) {
+        // per-WORKGROUP partials [2][H2] + count: sums over the 32 lanes of a half (same channels) by a fixed butterfly,
+        // then the four wavefronts in order through LDS (one partial per wavefront made the one-workgroup finalize
+        // kernel walk 8192 of them: 1 ms)
+        __shared__ float pst[4][2 * H2 + 4];
+        const int wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int mb2 = 0; mb2 < MB2; ++mb2)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float a = group_reduce<true>(st1[mb2][e], 32), b = group_reduce<true>(st2[mb2][e], 32);
+                if (r == 0) {
+                    const int c = 32 * mb2 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    pst[wv][c] = a;
+                    pst[wv][H2 + c] = b;
+                }
+            }
+        const float cc = group_reduce<true>(stc, 32);
+        if (lane == 0) pst[wv][2 * H2] = cc;
+        __syncthreads();
+        float *pb = partial + (int64_t)blockIdx.x * (2 * H2 + 4);
+        for (int t = threadIdx.x; t <= 2 * H2; t += blockDim.x) pb[t] = ((pst[0][t] + pst[1][t]) + pst[2][t]) + pst[3][t];
+    }
+}
+
+// (a, b) of the trailing BatchNorm from the wavefront partials (training: batch statistics over the valid edges, biased
+// variance; running statistics updated like torch.nn.BatchNorm1d) or from the running statistics (eval).  One workgroup,
+// sums in double in a fixed order.
+__global__ __launch_bounds__(1024) void edge_mlp2_bn_finalize_kernel(const float *__restrict__ partial, int64_t nwaves, int H2,
+                                                                    const float *__restrict__ gamma,
+                                                                    const float *__restrict__ beta, float eps,
+                                                                    float momentum, float *__restrict__ running_mean,
+                                                                    float *__restrict__ running_var,
+                                                                    int64_t *__restrict__ num_batches_tracked,
+                                                                    int training, float *__restrict__ ab)
+{
+    __shared__ double red[3][16][64];
+    const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;     // 16 groups, each every 16th partial
+    double mean = 0.0, var = 1.0;
+    if (training) {
+        double s1 = 0.0, s2 = 0.0, cn = 0.0;
+        const int cc = c < H2 ? c : 0;
+#pragma unroll 8   // independent loads: keep eight in flight (the sum order is unchanged)
+        for (int64_t w = grp; w < nwaves; w += 16) {
+            const float *pw = partial + w * (int64_t)(2 * H2 + 4);
+            s1 += (double)pw[cc]; s2 += (double)pw[H2 + cc];
+            cn += (double)pw[2 * H2];
+        }
+        red[0][grp][c] = s1; red[1][grp][c] = s2; red[2][grp][c] = cn;
+        __syncthreads();
+        if (grp != 0 || c >= H2) return;
+        s1 = 0.0; s2 = 0.0; cn = 0.0;
+        for (int q = 0; q < 16; ++q) { s1 += red[0][q][c]; s2 += red[1][q][c]; cn += red[2][q][c]; }
+        const double n = cn > 0.0 ? cn : 1.0;
+        mean = s1 / n;
+        var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        if (running_mean) {
+            const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
+        }
+        if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    } else {
+        if (grp != 0 || c >= H2) return;
+        mean = (double)running_mean[c];
+        var = (double)running_var[c];
+    }
+    const double a = (double)(gamma ? gamma[c] : 1.0f) / sqrt(var + (double)eps);
+    ab[c] = (float)a;
+    ab[H2 + c] = (float)((double)(beta ? beta[c] : 0.0f) - mean * a);
+}
+
+// out = a * aggregate + b per channel: sums take cnt * b, maxima become minima under a negative scale, nodes without
+// any neighbour stay 0 (R3)
+template <bool ADD>
+__global__ __launch_bounds__(256) void edge_mlp2_bn_apply_kernel(const float *__restrict__ agg0, const float *__restrict__ agg1,
+                                                                 const float *__restrict__ ab, int64_t N, int H2,
+                                                                 float *__restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * H2) return;
+    const int64_t i = t / H2;
+    const int c = (int)(t - i * H2);
+    const float a = ab[c], b = ab[H2 + c];
+    float v;
+    if (ADD) {
+        const float cnt = agg1[i];
+        v = cnt > 0.0f ? __builtin_fmaf(a, agg0[t], cnt * b) : 0.0f;
+    } else {
+        const float mx = agg0[t];
+        v = mx == -__builtin_inff() ? 0.0f : __builtin_fmaf(a, a >= 0.0f ? mx : agg1[t], b);
+    }
+    out[t] = v;
 }
 
 template <int HIN, int H1P, int H2>
@@ -197,10 +328,85 @@ int launch_edge_mlp2(const float *x, const int32_t *nbr, int64_t N, int k, const
     return 0;
 }
 
+inline int64_t edge_mlp2_blocks(int64_t N, int k)
+{
+    const int npt = 32 / k;
+    const int64_t ntiles = (N + npt - 1) / npt;
+    int64_t blocks = (ntiles + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    return blocks;
+}
+
+template <int HIN, int H1P, int H2>
+int launch_edge_mlp2_bn(const float *x, const int32_t *nbr, int64_t N, int k, const float *W1, const float *b1, int H1,
+                        const float *W2, const float *b2, int act2, int aggr, float *agg0, float *agg1, float *partial,
+                        hipStream_t st)
+{
+    const int64_t blocks = edge_mlp2_blocks(N, k);
+    if (aggr == 0)
+        hipLaunchKernelGGL((edge_mlp2_kernel<HIN, H1P, H2, false, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, nbr, N, k,
+                           W1, b1, H1, W2, b2, act2, agg0, agg1, partial);
+    else
+        hipLaunchKernelGGL((edge_mlp2_kernel<HIN, H1P, H2, true, true>), dim3((unsigned)blocks), dim3(256), 0, st, x, nbr, N, k,
+                           W1, b1, H1, W2, b2, act2, agg0, agg1, partial);
+    DMET_LAUNCH_CHECK("edge_mlp2_kernel (BatchNorm form)");
+    return 0;
+}
+
 }  // namespace
 }  // namespace dmet
 
 using namespace dmet;
+
+extern "C" size_t dmet_edge_mlp2_bn_workspace_bytes(int64_t N, int H2)
+{
+    if (N <= 0 || H2 <= 0) return 0;
+    // two aggregates [N][H2] (the second one: minima, or the per-node edge counts), wavefront partials, (a, b)
+    return sizeof(float) * (2 * (size_t)N * H2 + (size_t)2048 * (2 * H2 + 4) + 2 * (size_t)H2) + 1024;
+}
+
+extern "C" int dmet_edge_mlp2_bn_bf16(const float *x, int64_t N, int Hin, const int32_t *nbr, int k, const float *W1,
+                                      const float *b1, int H1, const float *W2, const float *b2, int H2, int act2, int aggr,
+                                      const float *gamma, const float *beta, float eps, float momentum,
+                                      float *running_mean, float *running_var, int64_t *num_batches_tracked, int training,
+                                      float *out, void *ws, size_t ws_bytes, dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647 / 64, "dmet_edge_mlp2_bn_bf16: N out of range");
+    DMET_REQUIRE(dmet_edge_mlp2_supported(Hin, H1, H2, k), "dmet_edge_mlp2_bn_bf16: unsupported shape Hin=%d H1=%d H2=%d k=%d",
+                 Hin, H1, H2, k);
+    DMET_REQUIRE(aggr == 0 || aggr == 1, "dmet_edge_mlp2_bn_bf16: aggr must be 0 (max) or 1 (add)");
+    DMET_REQUIRE(training || (running_mean && running_var), "dmet_edge_mlp2_bn_bf16: eval mode needs running statistics");
+    DMET_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "dmet_edge_mlp2_bn_bf16: running_mean/var go together");
+    if (N == 0) return 0;
+    DMET_REQUIRE(x && nbr && W1 && W2 && out && ws, "dmet_edge_mlp2_bn_bf16: null pointer");
+    DMET_REQUIRE(aligned16(x) && aligned16(out), "dmet_edge_mlp2_bn_bf16: x and out must be 16-B aligned");
+    DMET_REQUIRE(ws_bytes >= dmet_edge_mlp2_bn_workspace_bytes(N, H2), "dmet_edge_mlp2_bn_bf16: workspace too small");
+    hipStream_t st = as_stream(stream);
+    float *agg0 = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u);
+    float *agg1 = agg0 + (size_t)N * H2;
+    float *partial = agg1 + (size_t)N * H2;
+    const int64_t nwaves = edge_mlp2_blocks(N, k);      // one partial per workgroup
+    float *ab = partial + (size_t)2048 * (2 * H2 + 4);
+    float *pp = training ? partial : nullptr;
+    int rc;
+    if (Hin == 32 && H2 == 32) rc = launch_edge_mlp2_bn<32, 64, 32>(x, nbr, N, k, W1, b1, H1, W2, b2, act2, aggr, agg0, agg1, pp, st);
+    else if (Hin == 32 && H2 == 64) rc = launch_edge_mlp2_bn<32, 64, 64>(x, nbr, N, k, W1, b1, H1, W2, b2, act2, aggr, agg0, agg1, pp, st);
+    else if (H1 <= 96) rc = launch_edge_mlp2_bn<64, 96, 64>(x, nbr, N, k, W1, b1, H1, W2, b2, act2, aggr, agg0, agg1, pp, st);
+    else rc = launch_edge_mlp2_bn<64, 128, 64>(x, nbr, N, k, W1, b1, H1, W2, b2, act2, aggr, agg0, agg1, pp, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(edge_mlp2_bn_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float *)partial, nwaves, H2, gamma, beta,
+                       eps, momentum, running_mean, running_var, num_batches_tracked, training, ab);
+    DMET_LAUNCH_CHECK("edge_mlp2_bn_finalize_kernel");
+    const int64_t total = N * H2;
+    if (aggr == 0)
+        hipLaunchKernelGGL((edge_mlp2_bn_apply_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           (const float *)agg0, (const float *)agg1, (const float *)ab, N, H2, out);
+    else
+        hipLaunchKernelGGL((edge_mlp2_bn_apply_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                           (const float *)agg0, (const float *)agg1, (const float *)ab, N, H2, out);
+    DMET_LAUNCH_CHECK("edge_mlp2_bn_apply_kernel");
+    return 0;
+}
 
 extern "C" int dmet_edge_mlp2_supported(int Hin, int H1, int H2, int k)
 {

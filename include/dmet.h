@@ -198,6 +198,20 @@ int dmet_edge_mlp2_supported(int Hin, int H1, int H2, int k);
 int dmet_edge_mlp2_bf16(const float *x, int64_t N, int Hin, const int32_t *nbr, int k, const float *W1, const float *b1,
                         int H1, const float *W2, const float *b2, int H2, int act2, int aggr, float *out,
                         dmet_stream_t stream);
+/* The same edge MLP followed by the BatchNorm1d(H2) that ends the DRN's `nn` (model/dynamic_reduction_network.py:59-70;
+ * it normalises the per-edge MESSAGES, before the aggregation).  One pass over the edges: the affine map of the norm
+ * commutes with the aggregation (sum: a S + cnt b; max: a max + b for a >= 0, a min + b otherwise), so the kernel writes
+ * un-normalised aggregates plus per-wavefront partial sums of m and m^2 over the valid edges, a one-workgroup kernel turns
+ * them into the per-channel (a, b) -- training != 0: batch statistics over the E valid edges (biased variance;
+ * running_mean / running_var / num_batches_tracked, all optional, updated like torch.nn.BatchNorm1d); training == 0:
+ * running statistics -- and a node-level kernel applies them.  Nodes without any neighbour give 0 (R3).
+ * ws: dmet_edge_mlp2_bn_workspace_bytes(N, H2). */
+size_t dmet_edge_mlp2_bn_workspace_bytes(int64_t N, int H2);
+int dmet_edge_mlp2_bn_bf16(const float *x, int64_t N, int Hin, const int32_t *nbr, int k, const float *W1, const float *b1,
+                           int H1, const float *W2, const float *b2, int H2, int act2, int aggr, const float *gamma,
+                           const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                           int64_t *num_batches_tracked, int training, float *out, void *ws, size_t ws_bytes,
+                           dmet_stream_t stream);
 /* bf16 variant (BASELINE configs[2]): x and the split weights rounded to bf16 (RNE), multiplied on the bf16 matrix
  * cores with fp32 accumulation; P stays fp32, Q is stored as bf16 (raw bits) and gathered as 64-B rows.
  * Built for Hin = Hout = 32, k in {8,16,32}.  Backward is shared with the fp32 path (arg-based, fp32). */

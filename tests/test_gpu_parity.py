@@ -1026,6 +1026,56 @@ def test_edge_mlp2_bf16_mfma(dev, H, H1, H2, k, aggr, act2):
         torch.testing.assert_close(g, gr, rtol=2e-3, atol=2e-4 * max(float(gr.abs().max()), 1e-6))
 
 
+@pytest.mark.parametrize("H,H1,H2,k,aggr,negative_gamma", [(32, 48, 32, 16, "add", False), (32, 64, 64, 8, "max", True),
+                                                           (64, 96, 64, 16, "add", True), (64, 96, 64, 16, "max", False)])
+def test_edge_mlp2_bf16_with_trailing_batch_norm(dev, H, H1, H2, k, aggr, negative_gamma):
+    """The DRN's edge MLP as written (model/dynamic_reduction_network.py:59-70: Linear - ELU - Linear - ELU - BatchNorm1d
+    over the MESSAGES, aggr add by default): fused on the bf16 matrix cores, the norm applied after the aggregation by
+    the affine-commutes argument (max: the minimum where gamma < 0).  Training mode against the fp32 PyG-shaped oracle
+    with the same module: output at the bf16 bar, running statistics and num_batches_tracked moved exactly once per
+    forward + backward, gradients (the backward differentiates the fp32 operators) against the oracle's; then eval mode
+    (running statistics) against the oracle in eval mode."""
+    import copy
+    import deepmetv2_amd as dm
+    from oracle import ref_ops
+    sizes = [300, 5, 0, 131, 64]
+    x, batch, ptr = _ragged(sizes, H, seed=500 + H1 + k)
+    bn = torch.nn.BatchNorm1d(H2)
+    nn_ = torch.nn.Sequential(torch.nn.Linear(2 * H, H1), torch.nn.ELU(), torch.nn.Linear(H1, H2), torch.nn.ELU(), bn)
+    conv = dm.DynamicEdgeConv(nn=nn_, k=k, aggr=aggr)      # (the constructor re-initialises nn, like upstream's)
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(-1.5, 1.5, H2) if negative_gamma else torch.linspace(0.5, 1.5, H2))
+        bn.bias.copy_(torch.linspace(-0.3, 0.3, H2))
+    ref_nn = copy.deepcopy(nn_)
+    xr = x.clone().requires_grad_(True)
+    out_ref = ref_ops.dynamic_edge_conv(xr, batch, ref_nn, k, aggr)
+    gup = torch.randn(out_ref.shape, generator=torch.Generator().manual_seed(3))
+    out_ref.backward(gup)
+    g_ref = [xr.grad.clone()] + [p.grad.clone() for p in ref_nn.parameters()]
+    conv = conv.to(dev)
+    conv.compute_dtype = torch.bfloat16
+    xd = x.to(dev).requires_grad_(True)
+    out = conv(xd, batch.to(dev))
+    out.backward(gup.to(dev))
+    scale = float(out_ref.detach().abs().max())
+    torch.testing.assert_close(out.detach().cpu(), out_ref.detach(), rtol=3e-2, atol=3e-2 * scale)
+    assert int(bn.num_batches_tracked) == int(ref_nn[4].num_batches_tracked) == 1
+    torch.testing.assert_close(bn.running_mean.cpu(), ref_nn[4].running_mean, rtol=2e-2, atol=2e-3)
+    torch.testing.assert_close(bn.running_var.cpu(), ref_nn[4].running_var, rtol=3e-2, atol=2e-3)
+    got = [xd.grad.cpu()] + [p.grad.cpu() for p in nn_.parameters()]
+    for g, gr in zip(got, g_ref):
+        torch.testing.assert_close(g, gr, rtol=2e-3, atol=3e-4 * max(float(gr.abs().max()), 1e-6))
+    # eval mode: running statistics (make both sides use the oracle's so that only the kernel differs)
+    with torch.no_grad():
+        bn.running_mean.copy_(ref_nn[4].running_mean.to(dev)); bn.running_var.copy_(ref_nn[4].running_var.to(dev))
+    conv.eval(); ref_nn.eval()
+    with torch.no_grad():
+        o_eval = conv(x.to(dev), batch.to(dev)).cpu()
+        o_eval_ref = ref_ops.dynamic_edge_conv(x, batch, ref_nn, k, aggr)
+    torch.testing.assert_close(o_eval, o_eval_ref, rtol=3e-2, atol=3e-2 * float(o_eval_ref.abs().max()))
+    assert int(bn.num_batches_tracked) == 1
+
+
 def test_counted_gather_winner_ids_and_ordered_rows(dev):
     """N1 / the reference's active flow (train.py:48: one 255-wide radius table per batch): the winner-id form of the
     counted LDS gather (rows walked in order of their depth) must give the slot form's output bit for bit, its ids must

@@ -40,6 +40,17 @@ for H, H1, H2 in shapes:
         t_mfma = med(lambda: _native.edge_mlp2_bf16(x, table.nbr, l1.weight, l1.bias, l2.weight, l2.bias, True, False))
         conv = dm.EdgeConv(nn=nn_)            # re-initialises nn; only timing matters below
         t_f32 = med(lambda: conv(x, table), reps=3)
+        # the DRN's nn as written: + BatchNorm1d over the messages (aggr add), one pass + (a, b) + node-level apply
+        bn = torch.nn.BatchNorm1d(H2).to(dev)
+        t_bn = med(lambda: _native.edge_mlp2_bn_bf16(x, table.nbr, l1.weight, l1.bias, l2.weight, l2.bias, True, True, bn.weight,
+                                                     bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                                                     bn.num_batches_tracked, True))
+        t_add = med(lambda: _native.edge_mlp2_bf16(x, table.nbr, l1.weight, l1.bias, l2.weight, l2.bias, True, True))
+        conv_bn = dm.EdgeConv(nn=torch.nn.Sequential(torch.nn.Linear(2 * H, H1), torch.nn.ELU(), torch.nn.Linear(H1, H2),
+                                                     torch.nn.ELU(), torch.nn.BatchNorm1d(H2)).to(dev), aggr="add")
+        t_f32_bn = med(lambda: conv_bn(x, table), reps=3)
+    print(f"H={H} H1={H1} H2={H2}: with trailing BatchNorm1d, aggr add: fused {t_bn * 1e3:8.1f} us (without the norm {t_add * 1e3:8.1f} us); "
+          f"fp32 route {t_f32_bn * 1e3:8.1f} us ({t_f32_bn / t_bn:4.1f}x)")
     E = N * k
     useful = 2.0 * E * (2 * H * H1 + H1 * H2)
     H1P = 64 if H == 32 else (96 if H1 <= 96 else 128)
