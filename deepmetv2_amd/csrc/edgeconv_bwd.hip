@@ -147,15 +147,26 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd
                     make_float4(t.x + ga[g].x, t.y + ga[g].y, t.z + ga[g].z, t.w + ga[g].w);
         }
     }
-    float *out = partial + wave * (int64_t)kPartial;
+    // one partial per WORKGROUP: the four wavefronts' tiles meet in LDS (their own P / Q / X tiles, consumed by now) and
+    // are added in wavefront order -- a quarter of the partial traffic and of the finalize kernel's reads
+    __syncthreads();
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int r = (e & 3) + 8 * (e >> 2) + 4 * hh;
-        out[r * 32 + c] = accP[e];
-        out[1024 + r * 32 + c] = accQ[e];
+        P[r * 32 + c] = accP[e];
+        Q[r * 32 + c] = accQ[e];
     }
     const float b = bsum + __shfl_xor(bsum, 32, 64);
-    if (hh == 0) out[2048 + c] = b;
+    if (hh == 0) X[c] = b;
+    __syncthreads();
+    float *out = partial + (int64_t)blockIdx.x * kPartial;
+    for (int i = threadIdx.x; i < kPartial; i += kWave * kWavesPerBlock) {
+        const float *src = i < 1024 ? &sP[0][i] : i < 2048 ? &sQ[0][i - 1024] : &sX[0][i - 2048];
+        float t = src[0];
+#pragma unroll
+        for (int w = 1; w < kWavesPerBlock; ++w) t += src[w * kChunk * kPad];
+        out[i] = t;
+    }
 }
 
 // gW[o][0:32] = sum gP^T x,  gW[o][32:64] = sum gQ^T x - sum gP^T x,  gb[o] = sum gP.  Partials are added in a fixed
@@ -403,8 +414,8 @@ extern "C" int dmet_edgeconv_linear_bwd_add_f32(const float *x, const float *W, 
     hipLaunchKernelGGL(edgeconv_linear_bwd_kernel, dim3((unsigned)(nw / kWavesPerBlock)), dim3(kWave * kWavesPerBlock), 0, st,
                        x, W, g_out, arg, gQ, N, npw, g_add, gx, partial, fin_counters);
     DMET_LAUNCH_CHECK("edgeconv_linear_bwd_kernel");
-    hipLaunchKernelGGL(edgeconv_linear_bwd_finalize_kernel, dim3(kFinGroups * kFinChunks), dim3(1024), 0, st, partial, nw,
-                       chunk_sums, fin_counters, gW, gb);
+    hipLaunchKernelGGL(edgeconv_linear_bwd_finalize_kernel, dim3(kFinGroups * kFinChunks), dim3(1024), 0, st, partial,
+                       nw / kWavesPerBlock, chunk_sums, fin_counters, gW, gb);
     DMET_LAUNCH_CHECK("edgeconv_linear_bwd_finalize_kernel");
     return 0;
 }

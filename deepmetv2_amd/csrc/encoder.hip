@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256, 2) void encode_fwd_kernel(const float *__restr
 // packed table rows; bias gradients are column sums of the staged A tiles (lane (c, half) sums 32 nodes of column c).
 // ELU'(z) is taken from the activation itself (1 if a > 0 else a + 1), so z3 = Wa.joint is never recomputed.
 constexpr int kEncTiles = 3;
-constexpr int kEncBwdWaves = 2;
-constexpr int kEncPartial = kEncTiles * 1024 + 64;   // floats per wavefront partial: 3 tiles + [dba | dbk | dbc]
+constexpr int kEncBwdWaves = 4;
+constexpr int kEncPartial = kEncTiles * 1024 + 64;   // floats per workgroup partial: 3 tiles + [dba | dbk | dbc]
 
 __device__ __forceinline__ void enc_wave_sync()
 {
@@ -274,18 +274,30 @@ __global__ __launch_bounds__(64 * kEncBwdWaves, 2) void encode_bwd_kernel(const 
         tile_mma_onehot(acc[2], packed, Bm, lane);   // S^T [g_cat24|0]
         enc_wave_sync();
     }
-    // per-wave partial: 3 tiles [32][32] then [dba(32) | dbk(16) dbc(16)]
-    float *out = partial + wave * (int64_t)kEncPartial;
+    // one partial per WORKGROUP (3 tiles [32][32] then [dba(32) | dbk(16) dbc(16)]): the wavefronts' tiles meet in their
+    // own LDS buffers (consumed by now) and are added in wavefront order
     const int c = lane & 31, hh = lane >> 5;
+    __syncthreads();
 #pragma unroll
-    for (int t = 0; t < kEncTiles; ++t)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int r = (e & 3) + 8 * (e >> 2) + 4 * hh;
-            out[t * 1024 + r * 32 + c] = acc[t][e];
-        }
+    for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        A[r * 32 + c] = acc[0][e];
+        A[1024 + r * 32 + c] = acc[2][e];
+        Bm[r * 32 + c] = acc[1][e];
+    }
     const float b3 = bias3 + __shfl_xor(bias3, 32), b21 = bias21 + __shfl_xor(bias21, 32);
-    if (hh == 0) { out[kEncTiles * 1024 + c] = b3; out[kEncTiles * 1024 + 32 + c] = b21; }
+    if (hh == 0) { Bm[1024 + c] = b3; Bm[1024 + 32 + c] = b21; }
+    __syncthreads();
+    float *out = partial + (int64_t)blockIdx.x * kEncPartial;
+    for (int i = threadIdx.x; i < kEncPartial; i += 64 * kEncBwdWaves) {
+        // element i of the partial: tile 0 -> A[0..], tile 1 -> Bm[0..], tile 2 -> A[1024..], tail -> Bm[1024..]
+        const float *src = i < 1024 ? &bufA[0][i] : i < 2048 ? &bufB[0][i - 1024] : i < 3072 ? &bufA[0][i - 1024]
+                                                                                              : &bufB[0][i - 2048];
+        float t = src[0];
+#pragma unroll
+        for (int w = 1; w < kEncBwdWaves; ++w) t += src[w * 64 * 33];
+        out[i] = t;
+    }
 }
 
 struct EncGrads {
@@ -387,7 +399,7 @@ extern "C" int dmet_encode_bwd_f32(const float *x, int64_t x_stride, const int64
     DMET_LAUNCH_CHECK("encode_bwd_kernel");
     EncGrads gr{gWc, gbc, gWk, gbk, gWa, gba, gEchg, gEpdg, gEpv};
     static_assert(kEncPartial % 32 == 0, "finalize blocks own 32 elements");
-    hipLaunchKernelGGL(encode_bwd_finalize_kernel, dim3(kEncPartial / 32), dim3(1024), 0, st, partial, nw, gr);
+    hipLaunchKernelGGL(encode_bwd_finalize_kernel, dim3(kEncPartial / 32), dim3(1024), 0, st, partial, nw / kEncBwdWaves, gr);
     DMET_LAUNCH_CHECK("encode_bwd_finalize_kernel");
     return 0;
 }

@@ -18,7 +18,7 @@ constexpr int kHin = 32, kHid = 16;
 constexpr int kXPad = 36;                      // emb tile row stride (floats)
 constexpr int kAPad = 20;                      // [g_z1 (16) | g_z | 0 0 0] and [h1 (16) | 1 | 0 0 0] tiles
 constexpr int kHeadWaves = 4;
-constexpr int kHeadPartial = 1024 + 64;        // per wavefront: the A^T.emb tile, then [gW2 (16) | gb2 | .. | gb1 (16) | ..]
+constexpr int kHeadPartial = 1024 + 64;        // per workgroup: the A^T.emb tile, then [gW2 (16) | gb2 | .. | gb1 (16) | ..]
 
 __device__ __forceinline__ void head_wave_sync()
 {
@@ -170,12 +170,14 @@ __global__ __launch_bounds__(64 * kHeadWaves, 2) void head_bwd_kernel(const floa
             }
         }
     }
-    float *out = partial + wave * (int64_t)kHeadPartial;
+    // one partial per WORKGROUP: tile + tail of each wavefront go through its own emb tile in LDS (64 x 36 floats,
+    // consumed by now) and are added in wavefront order
     const int c = lane & 31, hh = lane >> 5;
+    __syncthreads();
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int r = (e & 3) + 8 * (e >> 2) + 4 * hh;
-        out[r * 32 + c] = acc0[e];
+        X[r * 32 + c] = acc0[e];
     }
     float mine = 0.0f;      // lane l of the tail: l < 16 gW2[l], l == 16 gb2, 32 <= l < 48 gb1[l - 32]
 #pragma unroll
@@ -188,7 +190,15 @@ __global__ __launch_bounds__(64 * kHeadWaves, 2) void head_bwd_kernel(const floa
         const float s2 = wave_sum(ab2);
         if (lane == 16) mine = s2;
     }
-    out[1024 + lane] = mine;
+    X[1024 + lane] = mine;
+    __syncthreads();
+    float *out = partial + (int64_t)blockIdx.x * kHeadPartial;
+    for (int i = threadIdx.x; i < kHeadPartial; i += 64 * kHeadWaves) {
+        float t = sX[0][i];
+#pragma unroll
+        for (int w = 1; w < kHeadWaves; ++w) t += sX[w][i];
+        out[i] = t;
+    }
 }
 
 // ordered sum of the wavefront partials (32 thread groups, then 32 group sums) and routing to the four gradients
@@ -273,7 +283,7 @@ extern "C" int dmet_head_bwd_f32(const float *emb, int64_t N, const float *W1, c
     hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)(nw / kHeadWaves)), dim3(64 * kHeadWaves), 0, st, emb, N, W1, b1, W2,
                        out, g_out, npw, g_emb, partial);
     DMET_LAUNCH_CHECK("head_bwd_kernel");
-    hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(kHeadPartial / 32), dim3(1024), 0, st, partial, nw, gW1, gb1, gW2, gb2);
+    hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(kHeadPartial / 32), dim3(1024), 0, st, partial, nw / kHeadWaves, gW1, gb1, gW2, gb2);
     DMET_LAUNCH_CHECK("head_bwd_finalize_kernel");
     return 0;
 }

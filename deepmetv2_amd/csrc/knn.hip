@@ -1705,13 +1705,14 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter12_kernel
 // lane, every load issued at once, no dependent chain (a head-pointer merge with one lane per query took 22 us, a
 // register-resident rank merge with one lane per query 37 us).  (d, j) pairs are distinct; empty slots are
 // (sentinel, -1) and are never written.
+constexpr int kF2MergeThreads = 1024;   // all kFQ queries of a tile at once at 16 lanes per query (no dependent rounds)
 template <int KP>
-__global__ __launch_bounds__(256) void knn_filter2_merge_kernel(const KnnFilterArgs a)
+__global__ __launch_bounds__(kF2MergeThreads) void knn_filter2_merge_kernel(const KnnFilterArgs a)
 {
     constexpr int M = filter_list_len(KP);
     constexpr int MS = (M + 1 + 3) & ~3;
     constexpr int LPQ = KP <= 16 ? 16 : 32;          // lanes per query
-    constexpr int QPB = 256 / LPQ;                   // queries per workgroup
+    constexpr int QPB = kF2MergeThreads / LPQ;       // queries per workgroup and round
     static_assert(kFilterMaxSplit == 2, "two sub-sweeps");
     const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
     if (split <= 1) return;
@@ -2160,7 +2161,7 @@ int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, cons
         DMET_LAUNCH_CHECK("knn_rerank_kernel");
     }
     if (f.form2) {
-        hipLaunchKernelGGL((knn_filter2_merge_kernel<KF>), dim3((unsigned)tail_max), dim3(256), 0, st, f);
+        hipLaunchKernelGGL((knn_filter2_merge_kernel<KF>), dim3((unsigned)tail_max), dim3(kF2MergeThreads), 0, st, f);
         DMET_LAUNCH_CHECK("knn_filter2_merge_kernel");
     }
     return 0;
