@@ -186,19 +186,19 @@ def workload_label(args, B, n, k) -> str:
 
 
 def knn_floor(sizes):
-    """Stated bound for the matrix-core kNN build (D = 32): per 64-query x 32-candidate tile a wavefront issues 12
-    v_mfma_f32_32x32x16_bf16 (32 cycles of its SIMD's matrix pipe each) and ~130 vector instructions for the selection
-    (half-wave swap, hit mask, tile minimum, threshold list; 2 cycles each at two wavefronts per SIMD, issue-bound);
-    the first 32 tiles of a sweep are visited twice.  Floors at 1024 SIMDs x 2.4 GHz if either pipe were the only
-    limit; the two do not overlap across wavefronts of a SIMD on gfx950 (tools/mfma_overlap_micro.hip), so the sum is
-    the realistic floor of this design."""
+    """Stated bound for the matrix-core kNN build (D = 32): per 64-query x 32-candidate tile a wavefront issues 4
+    v_mfma_f32_32x32x16_f16 (single-term fp16 operands since round 2's second session; 32 cycles of its SIMD's matrix
+    pipe each) and ~130 vector instructions for the selection (half-wave swap, hit mask, tile minimum, threshold
+    list) at 4 cycles each (a 64-lane instruction on a 16-lane SIMD: SQ_ACTIVE_INST_VALU x 4 is what the counters
+    charge; earlier lines of this file priced them at 2); the first 32 tiles of a sweep are visited twice.  Floors at
+    1024 SIMDs x 2.4 GHz if either pipe were the only limit; the vector floor is the one that binds."""
     tiles = 0
     for nn_ in sizes:
         ct = (nn_ + 31) // 32
         tiles += ((nn_ + 63) // 64) * (ct + min(ct, 32))
     clk, simds = 2.4e9, 1024
-    return {"tiles": tiles, "mfma_floor_us": round(tiles * 12 * 32 / simds / clk * 1e6, 1),
-            "valu_floor_us": round(tiles * 130 * 2 / simds / clk * 1e6, 1)}
+    return {"tiles": tiles, "mfma_floor_us": round(tiles * 4 * 32 / simds / clk * 1e6, 1),
+            "valu_floor_us": round(tiles * 130 * 4 / simds / clk * 1e6, 1)}
 
 
 def gather_roofline(args, ksum, ev_overhead_ms, model, x, batch, ptr, sizes, static_graph, dev):

@@ -616,6 +616,7 @@ constexpr int kFilterMaxSplit = 2;  // tail balancing of the filter: at most 2 c
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct KnnFilterArgs {
     const float *x;
@@ -638,11 +639,22 @@ struct KnnFilterArgs {
     int32_t *flags;             // [exact tiles] number of uncertified queries of the tile
     int32_t *any;               // total number of uncertified queries: the fallback kernels exit at once while it is 0
     uint8_t *qflag;             // [N] 1 = uncertified query
+    int32_t *qlist;             // [N] the uncertified queries in the order they were flagged (any = their number)
     const int32_t *xtile_ptr;   // tile prefix of the exact kernel's plan (same event order)
     int xtile_queries;
     int form2;                  // 1: events of kF2MinNodes..kF2MaxNodes nodes are swept by the second form
     float slack_scale;          // certificate slack relative to the 32-feature bound (1.5 at 64 features)
 };
+
+// A query whose result is not certified: counted per exact-kernel tile (dense tiles go to the exact tile kernel) and
+// appended to the list the per-query fallback walks.  Every query is flagged at most once per call.
+__device__ __forceinline__ void flag_query(const KnnFilterArgs &a, int q, int xtile)
+{
+    a.qflag[q] = 1;
+    atomicAdd(a.flags + xtile, 1);   // a count: order-independent
+    const int slot = atomicAdd(a.any, 1);
+    if (slot < a.N) a.qlist[slot] = q;
+}
 
 __device__ __forceinline__ unsigned bf16_rne_bits(float f)   // finite inputs
 {
@@ -667,6 +679,19 @@ constexpr int kRecBytesMax = rec_bytes(2);              // the workspace is carv
 
 __device__ __forceinline__ int64_t rec_base_tile(const int64_t *__restrict__ ptr, int b) { return (ptr[b] >> 5) + b; }
 
+// Second-form events (kF2MinNodes..kF2MaxNodes nodes, when the second form is enabled) get SINGLE-TERM fp16 records
+// instead of the bf16 split: frag[m][lane], m = 0..2 NH - 1, = the 8 fp16 values (round to nearest even) of features
+// 16 m + 8 hh + 0..7 of row col, then the 32 squared norms at byte kRec16FragBytes * NH (the record stride stays
+// rec_bytes(NH)).  Two MFMAs per 32 x 32 block instead of six; the certificate of the second form carries the fp16
+// rounding (see f2_slack).  A row with a feature outside the range whose doubled value fits fp16 (|v| >= 16384, or not
+// finite) is stored as zeros with norm -inf: its key is -inf for every query, so it is always a candidate of the exact
+// re-rank and never dropped on the strength of an overflowed product (as a QUERY such a row is refused by the
+// certificate through its true norm, kept in nrm[]).
+constexpr int kRec16FragBytes = 2 * kWave * 16;         // 2048: the two fp16 operand fragments of 32 features
+constexpr float kF16WideLimit = 16384.0f;
+
+__device__ __forceinline__ bool f2_in_domain64(int64_t n) { return n >= kF2MinNodes && n <= kF2MaxNodes; }
+
 // One wavefront per record: lane (col, hh) converts the 16 features of row col it will later feed to the MFMAs.
 // Also writes the flat norm array (certificates) and clears the uncertified-query counters / flags (zero_bytes bytes
 // at `zero`, 4-byte aligned) for the launches that follow, which saves a memset launch per call.
@@ -675,7 +700,7 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__
                                                         int B, int64_t N, float *__restrict__ nrm,
                                                         uint8_t *__restrict__ rec, int64_t nrec,
                                                         uint32_t *__restrict__ zero, size_t zero_bytes, KnnPlanOut o0,
-                                                        KnnPlanOut o1)
+                                                        KnnPlanOut o1, int form2)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     {
@@ -703,23 +728,58 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__
     if (li0 >= n) return;                   // a slot between two events: never read
     const bool live = li0 + col < n;
     const int64_t r = ev_lo + (live ? li0 + col : 0);
+    const bool rec16 = form2 != 0 && f2_in_domain64(n);    // wave-uniform: one event per record
     float s = 0.0f;
     uint8_t *recp = rec + tile * rec_bytes(NH);
+    float f[NH][16];
 #pragma unroll
     for (int half = 0; half < NH; ++half) {
-        float f[16];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const float4 *g = reinterpret_cast<const float4 *>(x + r * (32 * NH) + 32 * half + 16 * kb + 8 * hh);
             const float4 v0 = g[0], v1 = g[1];
-            f[8 * kb + 0] = v0.x; f[8 * kb + 1] = v0.y; f[8 * kb + 2] = v0.z; f[8 * kb + 3] = v0.w;
-            f[8 * kb + 4] = v1.x; f[8 * kb + 5] = v1.y; f[8 * kb + 6] = v1.z; f[8 * kb + 7] = v1.w;
+            f[half][8 * kb + 0] = v0.x; f[half][8 * kb + 1] = v0.y; f[half][8 * kb + 2] = v0.z; f[half][8 * kb + 3] = v0.w;
+            f[half][8 * kb + 4] = v1.x; f[half][8 * kb + 5] = v1.y; f[half][8 * kb + 6] = v1.z; f[half][8 * kb + 7] = v1.w;
         }
+    }
+    bool wide = false;
+#pragma unroll
+    for (int half = 0; half < NH; ++half) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float v = live ? f[half][u] : 0.0f;
+            f[half][u] = v;
+            s = __builtin_fmaf(v, v, s);
+            wide = wide || !(__builtin_fabsf(v) < kF16WideLimit);
+        }
+    }
+    s += __shfl_xor(s, 32, 64);             // the row's other features: fixed order, deterministic
+    if (rec16) {
+        wide = wide || (__shfl_xor(wide ? 1 : 0, 32, 64) != 0);
+#pragma unroll
+        for (int half = 0; half < NH; ++half) {
+            uint4 *dst = reinterpret_cast<uint4 *>(recp + half * kRec16FragBytes);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                f16x8 hv;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) hv[u] = wide ? (_Float16)0.0f : (_Float16)f[half][8 * kb + u];   // v_cvt_f16_f32: RNE
+                dst[kb * 64 + lane] = __builtin_bit_cast(uint4, hv);
+            }
+        }
+        if (hh == 0) {
+            reinterpret_cast<float *>(recp + kRec16FragBytes * NH)[col] =
+                !live ? __builtin_inff() : (wide ? -__builtin_inff() : s);
+            if (live) nrm[r] = s;
+        }
+        return;
+    }
+#pragma unroll
+    for (int half = 0; half < NH; ++half) {
         unsigned h[16], m[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const float v = live ? f[u] : 0.0f;
-            s = __builtin_fmaf(v, v, s);
+            const float v = f[half][u];
             h[u] = bf16_rne_bits(v);
             m[u] = bf16_rne_bits(v - __uint_as_float(h[u] << 16));   // the subtraction is exact
         }
@@ -732,7 +792,6 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__
                                                    m[8 * kb + 4] | (m[8 * kb + 5] << 16), m[8 * kb + 6] | (m[8 * kb + 7] << 16));
         }
     }
-    s += __shfl_xor(s, 32, 64);             // the row's other features: fixed order, deterministic
     if (!live) s = __builtin_inff();
     if (hh == 0) {
         reinterpret_cast<float *>(recp + kRecFragBytes * NH)[col] = s;
@@ -1130,10 +1189,7 @@ __device__ __forceinline__ void filter1_wave(const KnnFilterArgs &a, FilterQueue
             const float slack = 2.0f * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1e-30f;
             const bool full = tau < kKnnSentinel;
             if (L.overflow || !fits || (full && !(tau + nx - slack > kth))) {
-                const int xt = a.xtile_ptr[pos] + (myq - ev_lo) / a.xtile_queries;
-                a.qflag[myq] = 1;
-                atomicAdd(a.flags + xt, 1);   // a count: order-independent
-                atomicAdd(a.any, 1);
+                flag_query(a, myq, a.xtile_ptr[pos] + (myq - ev_lo) / a.xtile_queries);
             }
         }
         return;
@@ -1211,12 +1267,17 @@ struct F2Lane {
     bool overflow;
 };
 
-// drop the entries whose tile minimum is above tau (compare with a 2^-10 relative allowance: the stored minimum carries
-// the tile number in its low mantissa bits)
+// Drop the entries whose tile minimum is above tau.  The stored minimum carries the tile number in its low 11 mantissa
+// bits; clearing them is monotone in the float order (x <= y => trunc(x) <= trunc(y)), so "trunc(stored) <= trunc(tau)"
+// keeps every tile with minimum <= tau and at most the tiles within 2^-12 |tau| above it.  (Round 2, second session:
+// the comparison used to allow 2^-10 |tau| on either side; with M = 22 one query per build of the benchmark's
+// embeddings had five tile minima inside that window, ended with 27 entries and was handed to the fallback.)
+// `limit`: entries a lane may keep -- during a sweep it needs room to append before the next compaction, at the end
+// every slot may be in use.
 template <int M>
-__device__ __forceinline__ void f2_compact(F2Lane<M> &L, F2Wave &S, int lane)
+__device__ __forceinline__ void f2_compact(F2Lane<M> &L, F2Wave &S, int lane, int limit)
 {
-    const float tauS = L.tau + __builtin_fabsf(L.tau) * 9.765625e-4f + 1e-30f;
+    const float tauT = __uint_as_float(__float_as_uint(L.tau) & ~kF2TileMask);
     int maxcnt = L.cnt;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) maxcnt = max(maxcnt, __shfl_xor(maxcnt, off, 64));
@@ -1224,23 +1285,73 @@ __device__ __forceinline__ void f2_compact(F2Lane<M> &L, F2Wave &S, int lane)
     for (int s = 0; s < maxcnt; ++s) {
         if (s < L.cnt) {
             const uint2 e = S.ent[s][lane];
-            if (!(__uint_as_float(e.y) > tauS)) { S.ent[out][lane] = e; ++out; }
+            if (!(__uint_as_float(e.y & ~kF2TileMask) > tauT)) { S.ent[out][lane] = e; ++out; }
         }
     }
     L.cnt = out;
-    if (out > kF2Slots - 4) {   // more than ~26 tiles tied at tau: leave the query to the exact path
+    if (out > limit) {   // too many tiles tied at tau: leave the query to the exact path
         L.overflow = true;
         L.cnt = 0;
         L.tau = -__builtin_inff();
     }
 }
 
-// Operands of one candidate tile (A fragments + accumulator seed).
+// Operands of one candidate tile (A fragments + accumulator seed): single-term fp16 records (see knn_prep_kernel).
 template <int NH = 1>
 struct F2Ops {
-    bf16x8 a[4 * NH];
+    f16x8 a[2 * NH];
     f32x16 c;
 };
+
+// One 32(candidates) x 32(queries) block: acc = cinit + sum over the 16-feature k-blocks of h.h' (fp16 operands, fp32
+// accumulate): 2 NH MFMAs.  Operand map of v_mfma_f32_32x32x16_f16: lane (r = lane & 31, hh = lane >> 5) holds
+// A[row r][k = 8 hh + 0..7].
+template <int NH = 1>
+__device__ __forceinline__ f32x16 f2_block(const f16x8 (&av)[2 * NH], const f16x8 (&bv)[2 * NH], const f32x16 &cinit)
+{
+    f32x16 acc = cinit;
+#pragma unroll
+    for (int m = 0; m < 2 * NH; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[m], bv[m], acc, 0, 0, 0);
+    return acc;
+}
+
+// one fp16 candidate tile record: the lane's 2 NH A operands and the squared norms of the 16 candidate rows it receives
+// results for (accumulator seed; rows (e & 3) + 8 (e >> 2) + 4 hh)
+template <int NH = 1>
+__device__ __forceinline__ void f2_load(F2Ops<NH> &o, const uint8_t *__restrict__ rec, int64_t tidx, int lane, int hh)
+{
+    const uint8_t *base = rec + tidx * rec_bytes(NH);
+    const f16x8 *g = reinterpret_cast<const f16x8 *>(base);
+#pragma unroll
+    for (int m = 0; m < 2 * NH; ++m) o.a[m] = g[m * 64 + lane];
+    const float4 *nr = reinterpret_cast<const float4 *>(base + kRec16FragBytes * NH);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = nr[2 * q + hh];
+        o.c[4 * q] = v.x; o.c[4 * q + 1] = v.y; o.c[4 * q + 2] = v.z; o.c[4 * q + 3] = v.w;
+    }
+}
+
+// Certificate slack of the second form (dropped candidates had key >= T; true d >= T + |x_i|^2 - slack).  an >= |x_i|,
+// rn >= |x_i| + sqrt(d_k): a candidate with a larger norm than rn is farther than d_k by the triangle inequality, so the
+// bound only has to hold for |x_j| <= rn.  Terms:
+//   * the bound of the split form (fp32 accumulation inside the MFMAs, squared norms, the R1 chain itself), `scale` x
+//     (1.5 at 64 features: twice the products per key), with its 2 x margin;
+//   * fp16 operands: each rounds with relative error <= 2^-11 (normal range; |v| < 16384 is guaranteed by the record
+//     writer), the products are exact in fp32, so |x.x' - h.h'| <= (2^-10 + 2^-22) sum_c |x_c||x'_c| <= 1.0003 x 2^-10
+//     |x||x'| (Cauchy-Schwarz), twice that on the key: 2^-9 an rn, taken as 1.96e-3 (> 1.0003 x 2^-9 = 1.9537e-3);
+//   * fp16 subnormals (|v| < 2^-14): absolute error <= 2^-25 per feature, on the key <= 2 x 2^-25 x sqrt(D) (|x|+|x'|)
+//     <= 4.8e-7 (an + rn) at D <= 64; taken as 6e-7.
+__device__ __forceinline__ float f2_slack(float an, float rn, float scale)
+{
+    return 2.0f * scale * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1.96e-3f * an * rn + 6e-7f * (an + rn) +
+           1e-30f;
+}
+
+// threshold list length of the second form: the fp16 slack needs the M-th smallest tile minimum two ranks further out
+// than the split form did (measured on the model's embeddings at k = 16: uncertified queries per 4500-node event
+// ~10 at KP + 4, ~2 at KP + 5, ~0.1 at KP + 6); a lane keeps kF2Slots = 30 entries, so the widest list stays at 24
+constexpr int f2_list_len(int KP) { return KP <= 16 ? KP + 6 : KP + 4; }
 
 // One tile of a sweep, software-pipelined inside the wavefront: the 12 MFMAs of tile t + 1 (operands `use`) are
 // issued between the vector instructions that select from tile t's keys (c0, c1, computed one call earlier), and the
@@ -1255,7 +1366,7 @@ struct F2Ops {
 template <int M, bool UPD, bool REC, bool INS, int NH = 1>
 __device__ __forceinline__ void f2_tile(F2Lane<M> &L, F2Wave &S, const uint8_t *__restrict__ rec, int64_t rbase, int t,
                                         int t_hi, f32x16 &c0, f32x16 &c1, f32x16 &n0, f32x16 &n1, const F2Ops<NH> &use,
-                                        F2Ops<NH> &ld, const bf16x8 (&bq)[2][4 * NH], int lane, int hh, bool alive,
+                                        F2Ops<NH> &ld, const f16x8 (&bq)[2][2 * NH], int lane, int hh, bool alive,
                                         float &carry)
 {
 #if defined(DMET_F2_ABL) && DMET_F2_ABL >= 2
@@ -1269,18 +1380,15 @@ __device__ __forceinline__ void f2_tile(F2Lane<M> &L, F2Wave &S, const uint8_t *
     constexpr bool kUpd = UPD;
 #endif
     if (kRec) {
-        if (__any(L.cnt >= kF2Slots - 1)) f2_compact<M>(L, S, lane);
+        if (__any(L.cnt >= kF2Slots - 1)) f2_compact<M>(L, S, lane, kF2Slots - 3);
     }
-    if (NH == 1) {
 #if defined(DMET_F2_SAMEREC)
-        filter_load<NH>(ld.a, ld.c, rec, rbase + (t & 1), lane, hh);   // experiment: operands always cache-resident
+    f2_load<NH>(ld, rec, rbase + (t & 1), lane, hh);   // experiment: operands always cache-resident
 #else
-        filter_load<NH>(ld.a, ld.c, rec, rbase + min(t + 2, t_hi - 1), lane, hh);   // clamped: the last two calls re-read the last tile
+    f2_load<NH>(ld, rec, rbase + min(t + 2, t_hi - 1), lane, hh);   // clamped: the last two calls re-read the last tile
 #endif
-    }
-    n0 = filter_block<NH>(use.a, bq[0], use.c);     // (s_setprio 1 around these was measured: 10 % slower)
-    n1 = filter_block<NH>(use.a, bq[1], use.c);
-    if (NH != 1) filter_load<NH>(ld.a, ld.c, rec, rbase + min(t + 2, t_hi - 1), lane, hh);
+    n0 = f2_block<NH>(use.a, bq[0], use.c);     // (s_setprio 1 around these was measured: 10 % slower)
+    n1 = f2_block<NH>(use.a, bq[1], use.c);
     // lanes 32..63 of block 0 <-> lanes 0..31 of block 1: afterwards c0 = rows {0-3, 8-11, ..} and c1 = rows
     // {4-7, 12-15, ..} of THIS lane's query
 #if !(defined(DMET_F2_ABL) && DMET_F2_ABL >= 4)
@@ -1330,7 +1438,9 @@ __device__ __forceinline__ void f2_tile(F2Lane<M> &L, F2Wave &S, const uint8_t *
     }
     if (kUpd) {
         if (INS) {
-            float v = tmin;
+            // a tile that holds a forced candidate (key -inf: a row outside the fp16 range, see knn_prep_kernel) does
+            // not vote for the threshold: its -inf would take a list slot without standing for a real key below tau
+            float v = tmin < -3.0e38f ? kKnnSentinel : tmin;
             asm("v_min_f32 %0, %0, %1" : "+v"(v) : "v"(carry));     // (both operands are clamped to the sentinel: no NaN)
             carry = kKnnSentinel;
 #pragma unroll
@@ -1354,25 +1464,16 @@ __device__ __forceinline__ void f2_tile(F2Lane<M> &L, F2Wave &S, const uint8_t *
 // One pass over the tiles [t_lo, t_hi) of the event whose first record is rbase.
 template <int M, bool UPD, bool REC, int NH = 1>
 __device__ __forceinline__ void f2_sweep(F2Lane<M> &L, F2Wave &S, const uint8_t *__restrict__ rec, int64_t rbase,
-                                         int t_lo, int t_hi, const bf16x8 (&bq)[2][4 * NH], int lane, int hh, bool alive)
+                                         int t_lo, int t_hi, const f16x8 (&bq)[2][2 * NH], int lane, int hh, bool alive)
 {
     if (t_lo >= t_hi) return;
-    F2Ops<NH> A;
-    filter_load<NH>(A.a, A.c, rec, rbase + t_lo, lane, hh);
-    f32x16 c0 = filter_block<NH>(A.a, bq[0], A.c);      // prologue: the first tile's keys
-    f32x16 c1 = filter_block<NH>(A.a, bq[1], A.c);
+    F2Ops<NH> A, B;
+    f2_load<NH>(A, rec, rbase + t_lo, lane, hh);
+    f32x16 c0 = f2_block<NH>(A.a, bq[0], A.c);      // prologue: the first tile's keys
+    f32x16 c1 = f2_block<NH>(A.a, bq[1], A.c);
     f32x16 n0, n1;
-    filter_load<NH>(A.a, A.c, rec, rbase + min(t_lo + 1, t_hi - 1), lane, hh);
+    f2_load<NH>(A, rec, rbase + min(t_lo + 1, t_hi - 1), lane, hh);
     float carry = kKnnSentinel;
-    if constexpr (NH != 1) {
-        for (int t = t_lo; t < t_hi; t += 2) {
-            f2_tile<M, UPD, REC, true, NH>(L, S, rec, rbase, t, t_hi, c0, c1, n0, n1, A, A, bq, lane, hh, alive, carry);
-            if (t + 1 < t_hi)
-                f2_tile<M, UPD, REC, true, NH>(L, S, rec, rbase, t + 1, t_hi, n0, n1, c0, c1, A, A, bq, lane, hh, alive, carry);
-        }
-        return;
-    }
-    F2Ops<NH> B;
     for (int t = t_lo; t < t_hi; t += 2) {
         // every tile inserts its own minimum (INS = true).  Inserting the minimum of tile PAIRS instead (half the
         // v_med3 chains) was tried: the threshold then admits up to 2M tiles, more than the 26 entries a lane can keep
@@ -1395,7 +1496,7 @@ __device__ __forceinline__ int filter_group(const KnnFilterArgs &a)
 template <int KP, int NH = 1>
 __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, int group, int wv, int lane)
 {
-    constexpr int M = filter_list_len(KP);
+    constexpr int M = f2_list_len(KP);
     constexpr int D = 32 * NH;
     constexpr int MS = (M + 1 + 3) & ~3;
     const int col = lane & 31, hh = lane >> 5;
@@ -1422,9 +1523,7 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
         if (NH != 1 && sub == 0) {
             const int q = q_first + lane;
             if (q < ev_hi) {
-                a.qflag[q] = 1;
-                atomicAdd(a.flags + a.xtile_ptr[pos] + (q - ev_lo) / a.xtile_queries, 1);
-                atomicAdd(a.any, 1);
+                flag_query(a, q, a.xtile_ptr[pos] + (q - ev_lo) / a.xtile_queries);
             }
         }
         return;
@@ -1441,35 +1540,42 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
 
     const int myq = q_first + hh * 32 + col;
     const bool valid = myq < ev_hi;
+    // Second attempt (whole-sweep items only).  A query whose certificate fails by the slack alone -- enough candidates,
+    // but the threshold T too close to its k-th distance: T + |x|^2 - slack <= d_k -- does not need the exact kernels:
+    // the wavefront sweeps the event once more with the FIXED threshold T* = d_k - |x|^2 + slack for those lanes
+    // (-inf, i.e. nothing recorded, for the others), re-ranks what that admits and certifies against T*: every candidate
+    // dropped by that sweep has key >= T*, hence d >= d_k >= the new k-th distance.  With fp16 operands ~0.1 queries per
+    // 4500-node event take this road (one wavefront in ~200 pays a second, masks-only sweep) instead of ~100 us of
+    // per-query fallback per build.
+    float t_fix = -__builtin_inff();
+    bool act = valid;              // lanes whose result this attempt writes and certifies
+    for (int attempt = 0;; ++attempt) {
     F2Lane<M> L;
 #pragma unroll
     for (int p = 0; p < M; ++p) L.tk[p] = kKnnSentinel;
-    L.tau = -__builtin_inff();     // nothing is recorded before tk is full
+    L.tau = attempt == 0 ? -__builtin_inff() : t_fix;     // first attempt: nothing is recorded before tk is full
     L.cnt = 0;
     L.overflow = false;
     {
         // the query operands live only as long as the sweeps (the re-rank needs the registers for the rows)
-        bf16x8 bq[2][4 * NH];
+        f16x8 bq[2][2 * NH];      // -2 x the queries' fp16 fragments (exact: |h| <= 16384)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int64_t qrec = min(rbase + (q_first - ev_lo) / 32 + b, rlast);
-            const bf16x8 *g = reinterpret_cast<const bf16x8 *>(rec + qrec * rec_bytes(NH));
+            const f16x8 *g = reinterpret_cast<const f16x8 *>(rec + qrec * rec_bytes(NH));
 #pragma unroll
-            for (int m = 0; m < 4 * NH; ++m) {
-                const bf16x8 v = g[m * 64 + lane];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float f = -2.0f * __uint_as_float(((unsigned)(unsigned short)v[u]) << 16);
-                    bq[b][m][u] = (short)(__float_as_uint(f) >> 16);
-                }
-            }
+            for (int m = 0; m < 2 * NH; ++m) bq[b][m] = g[m * 64 + lane] * (_Float16)-2.0f;
         }
-        const int t_def = min(t_hi, t_lo + kF2Defer);
-        f2_sweep<M, true, false, NH>(L, S, rec, rbase, t_lo, t_def, bq, lane, hh, valid);     // tau only
-        f2_sweep<M, true, true, NH>(L, S, rec, rbase, t_def, t_hi, bq, lane, hh, valid);
-        f2_sweep<M, false, true, NH>(L, S, rec, rbase, t_lo, t_def, bq, lane, hh, valid);     // against the final tau
+        if (attempt == 0) {
+            const int t_def = min(t_hi, t_lo + kF2Defer);
+            f2_sweep<M, true, false, NH>(L, S, rec, rbase, t_lo, t_def, bq, lane, hh, valid);     // tau only
+            f2_sweep<M, true, true, NH>(L, S, rec, rbase, t_def, t_hi, bq, lane, hh, valid);
+            f2_sweep<M, false, true, NH>(L, S, rec, rbase, t_lo, t_def, bq, lane, hh, valid);     // against the final tau
+        } else {
+            f2_sweep<M, false, true, NH>(L, S, rec, rbase, t_lo, t_hi, bq, lane, hh, valid);      // against T*
+        }
     }
-    f2_compact<M>(L, S, lane);
+    f2_compact<M>(L, S, lane, kF2Slots);
 #if defined(DMET_F2_ABL) && DMET_F2_ABL >= 1
     return;
 #endif
@@ -1491,7 +1597,7 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
     unsigned long long kk[KP];
 #pragma unroll
     for (int p = 0; p < KP; ++p) kk[p] = (unsigned long long)__float_as_uint(kKnnSentinel) << 32;
-    const int nent = (valid && !L.overflow) ? L.cnt : 0;
+    const int nent = (act && !L.overflow) ? L.cnt : 0;
     int slot = 0;
     unsigned cmask = 0u;
     int ctile = 0;
@@ -1628,56 +1734,76 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
         kd[p] = __uint_as_float((unsigned)(kk[p] >> 32));
         kj[p] = kd[p] == kKnnSentinel ? -1 : (int32_t)(unsigned)kk[p];
     }
-    if (!valid) return;
     const int k = a.k;
-    const float tau = L.tk[M - 1];
+    const float tau = attempt == 0 ? L.tk[M - 1] : t_fix;
     if (nsub == 1) {
-        float kth = -1.0f;
+        bool retry = false;
+        if (act) {
+            float kth = -1.0f;
 #pragma unroll
-        for (int p = 0; p < KP; ++p) {
-            if (p < k) {
-                a.nbr[(int64_t)myq * k + p] = kj[p];
-                a.dist[(int64_t)myq * k + p] = kd[p];
+            for (int p = 0; p < KP; ++p) {
+                if (p < k) {
+                    a.nbr[(int64_t)myq * k + p] = kj[p];
+                    a.dist[(int64_t)myq * k + p] = kd[p];
+                }
+                if (p == k - 1 && kj[p] >= 0) kth = kd[p];
             }
-            if (p == k - 1 && kj[p] >= 0) kth = kd[p];
-        }
-        if (a.nbr16) {
-            uint16_t *r16 = a.nbr16 + (int64_t)myq * k;
-            if ((k & 1) == 0) {   // two ids per dword store
+            if (a.nbr16) {
+                uint16_t *r16 = a.nbr16 + (int64_t)myq * k;
+                if ((k & 1) == 0) {   // two ids per dword store
 #pragma unroll
-                for (int p = 0; p + 1 < KP; p += 2)
-                    if (p < k)
-                        reinterpret_cast<unsigned *>(r16)[p >> 1] =
-                            (unsigned)local_id16(kj[p], ev_lo) | ((unsigned)local_id16(kj[p + 1], ev_lo) << 16);
-            } else {
+                    for (int p = 0; p + 1 < KP; p += 2)
+                        if (p < k)
+                            reinterpret_cast<unsigned *>(r16)[p >> 1] =
+                                (unsigned)local_id16(kj[p], ev_lo) | ((unsigned)local_id16(kj[p + 1], ev_lo) << 16);
+                } else {
 #pragma unroll
-                for (int p = 0; p < KP; ++p)
-                    if (p < k) r16[p] = local_id16(kj[p], ev_lo);
+                    for (int p = 0; p < KP; ++p)
+                        if (p < k) r16[p] = local_id16(kj[p], ev_lo);
+                }
             }
+            // certificate: every dropped candidate had key >= tau (see the header of this form).  Candidates were
+            // dropped (tau below the sentinel) but fewer than k neighbours came back (kth < 0): not certified either
+            const float nx = a.nrm[myq];
+            const float an = __builtin_sqrtf(nx) * 1.000001f;
+            const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
+            const float slack = f2_slack(an, rn, NH == 1 ? 1.0f : 1.5f);
+            const bool full = tau < kKnnSentinel;
+            // a query whose own row is outside the fp16 range (or not finite) swept with zero operands: never certified
+            const bool wideq = !(nx < kF16WideLimit * kF16WideLimit);
+            const bool fail = L.overflow || wideq || (full && !(kth >= 0.0f && tau + nx - slack > kth));
+            // slack-only failures get the second attempt: the smallest threshold that certifies this k-th distance,
+            // nudged up by a few ulps of the largest term so that the same fp32 expression holds for it
+            float ts = kth - nx + slack;
+            ts += (__builtin_fabsf(ts) + nx + slack) * 4.8e-7f + 1e-30f;
+            retry = fail && attempt == 0 && !L.overflow && !wideq && kth >= 0.0f && ts + nx - slack > kth &&
+                    ts < kKnnSentinel;
+            if (fail && !retry) {
+                flag_query(a, myq, a.xtile_ptr[pos] + (myq - ev_lo) / a.xtile_queries);
+#ifdef DMET_KNN_WHY
+                a.qflag[myq] = (uint8_t)(1 | (L.overflow ? 2 : 0) | (wideq ? 4 : 0) | (kth < 0.0f ? 8 : 0) | (attempt ? 16 : 0) |
+                                         (!(ts < kKnnSentinel) ? 32 : 0) | (!(ts + nx - slack > kth) ? 64 : 0));
+                a.dist[(int64_t)myq * k + 0] = tau; a.dist[(int64_t)myq * k + 1] = kth; a.dist[(int64_t)myq * k + 2] = slack; a.dist[(int64_t)myq * k + 3] = (float)L.cnt;
+#endif
+            }
+            t_fix = retry ? ts : -__builtin_inff();
         }
-        // certificate: every dropped candidate had key >= tau (see the header of this form)
-        const float nx = a.nrm[myq];
-        const float an = __builtin_sqrtf(nx) * 1.000001f;
-        const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
-        // (64 features: twice the products per key in the fp32 accumulation -- 1.5 x the bound keeps its 2 x margin)
-        const float slack = (NH == 1 ? 2.0f : 3.0f) * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1e-30f;
-        const bool full = tau < kKnnSentinel;
-        if (L.overflow || (full && !(tau + nx - slack > kth))) {
-            const int xt = a.xtile_ptr[pos] + (myq - ev_lo) / a.xtile_queries;
-            a.qflag[myq] = 1;
-            atomicAdd(a.flags + xt, 1);   // a count: order-independent
-            atomicAdd(a.any, 1);
-        }
-        return;
+        if (!__any(retry)) return;
+        act = retry;
+        continue;
     }
     // ---- split (tail) items: the exact top-KP of this candidate range + its threshold, merged by knn_filter2_merge_kernel
-    const int64_t fslot = (int64_t)(tile - n_full) * kFQ + hh * 32 + col;
-    float *ld = a.psd + (fslot * nsub + sub) * MS;
-    int32_t *lj = a.psj + (fslot * nsub + sub) * MS;
+    if (valid) {
+        const int64_t fslot = (int64_t)(tile - n_full) * kFQ + hh * 32 + col;
+        float *ld = a.psd + (fslot * nsub + sub) * MS;
+        int32_t *lj = a.psj + (fslot * nsub + sub) * MS;
 #pragma unroll
-    for (int p = 0; p < KP; ++p) { ld[p] = kd[p]; lj[p] = kj[p]; }
-    ld[M] = tau;
-    lj[M] = L.overflow ? 1 : 0;
+        for (int p = 0; p < KP; ++p) { ld[p] = kd[p]; lj[p] = kj[p]; }
+        ld[M] = tau;
+        lj[M] = L.overflow ? 1 : 0;
+    }
+    return;
+    }   // attempts
 }
 
 // Both forms in ONE launch: a wavefront takes the form its item's event calls for.  Batches that mix event sizes
@@ -1709,7 +1835,7 @@ constexpr int kF2MergeThreads = 1024;   // all kFQ queries of a tile at once at 
 template <int KP>
 __global__ __launch_bounds__(kF2MergeThreads) void knn_filter2_merge_kernel(const KnnFilterArgs a)
 {
-    constexpr int M = filter_list_len(KP);
+    constexpr int M = f2_list_len(KP);
     constexpr int MS = (M + 1 + 3) & ~3;
     constexpr int LPQ = KP <= 16 ? 16 : 32;          // lanes per query
     constexpr int QPB = kF2MergeThreads / LPQ;       // queries per workgroup and round
@@ -1778,15 +1904,13 @@ __global__ __launch_bounds__(kF2MergeThreads) void knn_filter2_merge_kernel(cons
     if (act && p < 2) {
         const float an = __builtin_sqrtf(nx) * 1.000001f;
         const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
-        const float slack = 2.0f * a.slack_scale * (4e-5f * an * rn + 1e-5f * rn * rn + 4e-6f * an * an) + 1e-30f;
-        fail = of != 0 || (tau < kKnnSentinel && !(tau + nx - slack > kth));
+        const float slack = f2_slack(an, rn, a.slack_scale);
+        fail = of != 0 || !(nx < kF16WideLimit * kF16WideLimit) ||
+               (tau < kKnnSentinel && !(kth >= 0.0f && tau + nx - slack > kth));
     }
     const bool other = __shfl_xor(fail ? 1 : 0, 1, 64) != 0;
     if (act && p == 0 && (fail || other)) {          // count the query once
-        const int xt = a.xtile_ptr[pos] + (int)((q - ev_lo) / a.xtile_queries);
-        a.qflag[q] = 1;
-        atomicAdd(a.flags + xt, 1);
-        atomicAdd(a.any, 1);
+        flag_query(a, (int)q, a.xtile_ptr[pos] + (int)((q - ev_lo) / a.xtile_queries));
     }
     }
 }
@@ -1921,51 +2045,47 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
     }
     wave_sync();
     if (active && l == 0 && sfail[slot] != 0) {      // count the query once
-        const int xt = a.xtile_ptr[pos] + (int)((qq - ev_lo) / a.xtile_queries);
-        a.qflag[qq] = 1;
-        atomicAdd(a.flags + xt, 1);   // a count: order-independent
-        atomicAdd(a.any, 1);
+        flag_query(a, (int)qq, a.xtile_ptr[pos] + (int)((qq - ev_lo) / a.xtile_queries));
     }
 }
 
 // Uncertified queries of sparsely flagged tiles (1..kRequeryMax per 128-query tile; denser tiles go to the exact
-// tile kernel): the tile's workgroup takes them one at a time, its 256 lanes stride over the event's candidates with
-// the exact R1 chain (distances cached in LDS when the event fits), then k rounds of "smallest (d, j) above the
-// previous pick" (R2) with a wavefront + cross-wavefront reduction.
+// tile kernel): ONE WORKGROUP PER FLAGGED QUERY, taken from the list the flagging sites append to (round 2: the
+// tile's workgroup used to take its queries one after the other, and a single straggler cost the build ~90 us).  The
+// 256 lanes stride over the event's candidates with the exact R1 chain (four rows in flight per lane; distances cached
+// in LDS when the event fits), then k rounds of "smallest (d, j) above the previous pick" (R2) on 64-bit
+// (distance bits, j) words with a wavefront + cross-wavefront reduction.
 constexpr int kRequeryMax = 8;
-constexpr int kRequeryTiles = 8;   // consecutive tiles per workgroup
+constexpr int kRequeryGroups = 512;    // workgroups of the launch: they exit at once while nothing is flagged
 constexpr int kRequeryCache = 16384;   // floats
 
-__global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a, int ntiles)
+__device__ __forceinline__ unsigned long long requery_word(float d, int j)
+{
+    // a candidate at d >= 1e10 (or NaN) is never a neighbour (upstream's initial best distance, dmet_oracle.c:62)
+    return d < kKnnSentinel ? (((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j) : ~0ull;
+}
+
+__global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a)
 {
     __shared__ float cache[kRequeryCache];
-    __shared__ float red_d[4];
-    __shared__ int red_j[4];
+    __shared__ unsigned long long red[4];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    // a workgroup owns kRequeryTiles consecutive tiles and reads their counters in one round trip: almost every tile
-    // has nothing to redo, and a workgroup per tile (each holding the distance cache in LDS) spent 10 us on
-    // workgroups that exit at once.  Counters of tiles beyond the plan's total are zero (cleared per call).
-    __shared__ int tile_flags[kRequeryTiles];
-    if (*a.any == 0) return;   // (workgroup-uniform) nothing was flagged anywhere
-    if (tid < kRequeryTiles) {
-        const int tile = blockIdx.x * kRequeryTiles + tid;
-        tile_flags[tid] = tile < ntiles ? a.flags[tile] : 0;
-    }
-    __syncthreads();
-    for (int ti = 0; ti < kRequeryTiles; ++ti) {
-    const int tile = blockIdx.x * kRequeryTiles + ti;
-    const int nflag = tile_flags[ti];
-    if (nflag == 0 || nflag > kRequeryMax) continue;   // block-uniform
-    const int pos = find_tile_event(a.xtile_ptr, a.B, tile);
-    const int ev = a.order[pos];
-    const int ev_lo = (int)a.ptr[ev], ev_hi = (int)a.ptr[ev + 1];
-    const int n = ev_hi - ev_lo;
-    const int q_first = ev_lo + (tile - a.xtile_ptr[pos]) * a.xtile_queries;
-    const int q_end = min(ev_hi, q_first + a.xtile_queries);
-    const bool cached = n <= kRequeryCache;
+    const int64_t nf64 = *a.any;
+    const int nflag = (int)(nf64 < a.N ? nf64 : a.N);
     const int k = a.k;
-    for (int q = q_first; q < q_end; ++q) {
-        if (a.qflag[q] == 0) continue;   // block-uniform
+    for (int it = blockIdx.x; it < nflag; it += gridDim.x) {   // block-uniform
+        const int q = a.qlist[it];
+        int lo = 0, hi = a.B;                // event of q: the last b with ptr[b] <= q (empty events share a ptr value
+        while (hi - lo > 1) {                // with their successor and are skipped by taking the last)
+            const int mid = (lo + hi) >> 1;
+            if (a.ptr[mid] <= q) lo = mid; else hi = mid;
+        }
+        const int ev = lo;
+        const int ev_lo = (int)a.ptr[ev], ev_hi = (int)a.ptr[ev + 1];
+        const int n = ev_hi - ev_lo;
+        const int xt = a.xtile_ptr[a.pos_of[ev]] + (q - ev_lo) / a.xtile_queries;
+        if (a.flags[xt] > kRequeryMax) continue;   // a densely flagged tile: the exact tile kernel recomputes it
+        const bool cached = n <= kRequeryCache;
         float qrow[32];
         {
             const float4 *g = reinterpret_cast<const float4 *>(a.x + (int64_t)q * 32);
@@ -1975,45 +2095,59 @@ __global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a,
                 qrow[4 * c] = v.x; qrow[4 * c + 1] = v.y; qrow[4 * c + 2] = v.z; qrow[4 * c + 3] = v.w;
             }
         }
-        __syncthreads();   // previous query's cache / reduction slots are free
+        __syncthreads();   // the previous query's cache / reduction slots are free
         if (cached) {
-            for (int j = tid; j < n; j += 256) cache[j] = chain_dist32(a.x + (int64_t)(ev_lo + j) * 32, qrow);
+            // four candidate rows in flight per lane (clamped re-reads past the end, results unused)
+            for (int j0 = tid; j0 < n; j0 += 4 * 256) {
+                float4 r[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 *g = reinterpret_cast<const float4 *>(a.x + (int64_t)(ev_lo + min(j0 + 256 * u, n - 1)) * 32);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) r[u][c] = g[c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float dc = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        float df;
+                        df = r[u][c].x - qrow[4 * c + 0]; dc = __builtin_fmaf(df, df, dc);
+                        df = r[u][c].y - qrow[4 * c + 1]; dc = __builtin_fmaf(df, df, dc);
+                        df = r[u][c].z - qrow[4 * c + 2]; dc = __builtin_fmaf(df, df, dc);
+                        df = r[u][c].w - qrow[4 * c + 3]; dc = __builtin_fmaf(df, df, dc);
+                    }
+                    if (j0 + 256 * u < n) cache[j0 + 256 * u] = dc;
+                }
+            }
             __syncthreads();
         }
-        float last_d = -1.0f;   // distances are >= 0
-        int last_j = -1;
+        unsigned long long last = 0ull;
+        bool first = true;
         for (int r = 0; r < k; ++r) {
-            float bd = __builtin_inff();
-            int bj = 0x7fffffff;
+            unsigned long long best = ~0ull;
             for (int j = tid; j < n; j += 256) {
                 const float d = cached ? cache[j] : chain_dist32(a.x + (int64_t)(ev_lo + j) * 32, qrow);
-                const int jj = ev_lo + j;
-                const bool after = d > last_d || (d == last_d && jj > last_j);
-                const bool better = d < bd || (d == bd && jj < bj);
-                // a candidate at d >= 1e10 is never a neighbour (upstream's initial best distance, dmet_oracle.c:62)
-                if (after && better && d < kKnnSentinel) { bd = d; bj = jj; }
+                const unsigned long long w = requery_word(d, ev_lo + j);
+                if ((first || w > last) && w < best) best = w;
             }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
-                const float od = __shfl_xor(bd, off, 64);
-                const int oj = __shfl_xor(bj, off, 64);
-                if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
+                const unsigned long long o = __shfl_xor(best, off, 64);
+                if (o < best) best = o;
             }
-            if (lane == 0) { red_d[wv] = bd; red_j[wv] = bj; }
+            if (lane == 0) red[wv] = best;
             __syncthreads();
-            bd = red_d[0]; bj = red_j[0];
+            best = red[0];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) {
-                const float od = red_d[w];
-                const int oj = red_j[w];
-                if (od < bd || (od == bd && oj < bj)) { bd = od; bj = oj; }
-            }
+            for (int w = 1; w < 4; ++w) if (red[w] < best) best = red[w];
             __syncthreads();
-            const bool found = bj != 0x7fffffff;   // block-uniform
+            const bool found = best != ~0ull;   // block-uniform
             if (tid == 0) {
-                a.nbr[(int64_t)q * k + r] = found ? bj : -1;
-                if (a.nbr16) a.nbr16[(int64_t)q * k + r] = local_id16(found ? bj : -1, ev_lo);
-                a.dist[(int64_t)q * k + r] = found ? bd : kKnnSentinel;
+                const int bj = found ? (int)(unsigned)best : -1;
+                a.nbr[(int64_t)q * k + r] = bj;
+                if (a.nbr16) a.nbr16[(int64_t)q * k + r] = local_id16(bj, ev_lo);
+                a.dist[(int64_t)q * k + r] = found ? __uint_as_float((unsigned)(best >> 32)) : kKnnSentinel;
             }
             if (!found) {
                 if (tid == 0)
@@ -2024,10 +2158,9 @@ __global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a,
                     }
                 break;
             }
-            last_d = bd; last_j = bj;
+            last = best;
+            first = false;
         }
-    }
-    __syncthreads();   // the next tile reuses the cache and the reduction slots
     }
 }
 
@@ -2068,6 +2201,7 @@ struct KnnWorkspace {
     int32_t *flags;       // flags[...], any[4] and qflag[N] are one zero-filled region
     int32_t *any;
     uint8_t *qflag;
+    int32_t *qlist;       // [N] flagged queries (not cleared: `any` bounds it)
     size_t zero_bytes;
     size_t bytes;
 };
@@ -2109,6 +2243,7 @@ inline KnnWorkspace carve_workspace(void *ws, int64_t N, int B, int KP)
     w.flags = reinterpret_cast<int32_t *>(take(w.zero_bytes));
     w.any = w.flags + exact_tiles_max(N, B);
     w.qflag = reinterpret_cast<uint8_t *>(w.any + 4);
+    w.qlist = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * (size_t)N));
     w.bytes = (size_t)(p - reinterpret_cast<uintptr_t>(ws));
     return w;
 }
@@ -2141,7 +2276,7 @@ int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, cons
 {
     const int slots = simds * 2;   // two filter wavefronts per SIMD
     hipLaunchKernelGGL((knn_prep_kernel<NH>), dim3((unsigned)((w.nrec * kWave + 255) / 256 + 2)), dim3(256), 0, st, f.x,
-                       f.ptr, f.B, f.N, w.nrm, w.rec, w.nrec, reinterpret_cast<uint32_t *>(w.flags), w.zero_bytes, px, pf);
+                       f.ptr, f.B, f.N, w.nrm, w.rec, w.nrec, reinterpret_cast<uint32_t *>(w.flags), w.zero_bytes, px, pf, f.form2);
     DMET_LAUNCH_CHECK("knn_prep_kernel");
     const int64_t ftiles_max = (f.N + kFQ - 1) / kFQ + f.B;
     const int64_t fblocks = (ftiles_max + slots + kWavesPerGroup - 1) / kWavesPerGroup;
@@ -2196,7 +2331,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     // the tiles the re-rank could not certify
     if (use_filter) {
         KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.rec, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
-                        w.psd, w.psj, nbr, dist, nbr16, w.flags, w.any, w.qflag, w.tile_ptr, QT, filter_form2(),
+                        w.psd, w.psj, nbr, dist, nbr16, w.flags, w.any, w.qflag, w.qlist, w.tile_ptr, QT, filter_form2(),
                         NH == 1 ? 1.0f : 1.5f};
         int rc = 0;
         if constexpr (DP == 32 || DP == 64) {
@@ -2209,10 +2344,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
         a.flags = w.flags;
         a.any = w.any;
         if constexpr (NH == 1) {
-            const int64_t xtiles_max = (N + QT - 1) / QT + B;
-            // counters exist (and are cleared) for at least xtiles_max tiles; the kernel reads none beyond that
-            hipLaunchKernelGGL(knn_requery_kernel, dim3((unsigned)((xtiles_max + kRequeryTiles - 1) / kRequeryTiles)),
-                               dim3(256), 0, st, f, (int)xtiles_max);
+            hipLaunchKernelGGL(knn_requery_kernel, dim3((unsigned)kRequeryGroups), dim3(256), 0, st, f);
             DMET_LAUNCH_CHECK("knn_requery_kernel");
             a.flag_min = kRequeryMax + 1;
         } else {
@@ -2620,6 +2752,16 @@ extern "C" int dmet_knn_fallback_stats(const void *ws, int64_t N, int B, int D, 
     out[0] = 0; out[1] = 0;
     for (int64_t i = 0; i < n; ++i) { out[0] += host[i] != 0; out[1] += host[i]; }
     free(host);
+    if (getenv("DMET_KNN_LIST_FLAGGED") && out[1] > 0) {   // developer aid: the first flagged queries, to stderr
+        int32_t ids[16];
+        const int64_t m = out[1] < 16 ? out[1] : 16;
+        if (hipMemcpy(ids, w.qlist, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int64_t i = 0; i < m; ++i) {
+                uint8_t why = 0;
+                (void)hipMemcpy(&why, w.qflag + ids[i], 1, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[dmet] flagged query %d (qflag %d)\n", ids[i], (int)why);
+            }
+    }
     return 0;
 }
 

@@ -257,10 +257,19 @@ def test_knn_filter_adversarial(dev, monkeypatch, case, sizes, D):
     st = _knn_vs_oracle(dev, x.contiguous(), sizes, k)
     if expect_fallback and filter_runs:
         assert st["flagged_queries"] > 0, st     # the certificate cannot hold here: the exact fallback must have run
-    if case == "feature_tails":
+    if case == "feature_tails" and filter_runs:
         # (at 64 features the events below the second form's 2048 nodes are handed to the exact kernel wholesale)
         by_design = sum(n for n in sizes if n < 2048) if D == 64 else 0
-        assert st["flagged_queries"] - by_design <= N // 20, st
+        # The second filter form's operands are fp16: a row with a feature at or beyond 16384 is a forced candidate of
+        # every query (and as a query goes to the exact path).  exp(4 randn) per feature puts most rows there, so the
+        # second-form events of this case are recomputed exactly BY DESIGN (a stated limit of the fp16 records, DESIGN
+        # K1); first-form events (bf16 split, full fp32 range) must still be certified.
+        second_form = os.environ.get("DMET_KNN_FILTER", "") != "1"
+        wide = bool((x.abs() >= 16384).any())
+        for n in sizes:
+            if second_form and wide and n >= 2048:
+                by_design += n
+        assert st["flagged_queries"] - min(by_design, N) <= N // 20, st
 
 
 def test_knn_second_filter_form_paths_agree_fuzz(dev, monkeypatch):
