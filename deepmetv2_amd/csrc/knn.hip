@@ -1494,7 +1494,7 @@ __device__ __forceinline__ int filter_group(const KnnFilterArgs &a)
 
 // One wavefront's item of the second form; S is the wavefront's own LDS (no workgroup barrier inside).
 template <int KP, int NH = 1>
-__device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, int group, int wv, int lane)
+__device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, int *tickets, int group, int wv, int lane)
 {
     constexpr int M = f2_list_len(KP);
     constexpr int D = 32 * NH;
@@ -1736,32 +1736,37 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
     }
     const int k = a.k;
     const float tau = attempt == 0 ? L.tk[M - 1] : t_fix;
+    // the query's rows of the three tables; returns its k-th distance (-1: fewer than k neighbours)
+    auto emit = [&]() __attribute__((always_inline)) -> float {
+        float kth = -1.0f;
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+            if (p < k) {
+                a.nbr[(int64_t)myq * k + p] = kj[p];
+                a.dist[(int64_t)myq * k + p] = kd[p];
+            }
+            if (p == k - 1 && kj[p] >= 0) kth = kd[p];
+        }
+        if (a.nbr16) {
+            uint16_t *r16 = a.nbr16 + (int64_t)myq * k;
+            if ((k & 1) == 0) {   // two ids per dword store
+#pragma unroll
+                for (int p = 0; p + 1 < KP; p += 2)
+                    if (p < k)
+                        reinterpret_cast<unsigned *>(r16)[p >> 1] =
+                            (unsigned)local_id16(kj[p], ev_lo) | ((unsigned)local_id16(kj[p + 1], ev_lo) << 16);
+            } else {
+#pragma unroll
+                for (int p = 0; p < KP; ++p)
+                    if (p < k) r16[p] = local_id16(kj[p], ev_lo);
+            }
+        }
+        return kth;
+    };
     if (nsub == 1) {
         bool retry = false;
         if (act) {
-            float kth = -1.0f;
-#pragma unroll
-            for (int p = 0; p < KP; ++p) {
-                if (p < k) {
-                    a.nbr[(int64_t)myq * k + p] = kj[p];
-                    a.dist[(int64_t)myq * k + p] = kd[p];
-                }
-                if (p == k - 1 && kj[p] >= 0) kth = kd[p];
-            }
-            if (a.nbr16) {
-                uint16_t *r16 = a.nbr16 + (int64_t)myq * k;
-                if ((k & 1) == 0) {   // two ids per dword store
-#pragma unroll
-                    for (int p = 0; p + 1 < KP; p += 2)
-                        if (p < k)
-                            reinterpret_cast<unsigned *>(r16)[p >> 1] =
-                                (unsigned)local_id16(kj[p], ev_lo) | ((unsigned)local_id16(kj[p + 1], ev_lo) << 16);
-                } else {
-#pragma unroll
-                    for (int p = 0; p < KP; ++p)
-                        if (p < k) r16[p] = local_id16(kj[p], ev_lo);
-                }
-            }
+            const float kth = emit();
             // certificate: every dropped candidate had key >= tau (see the header of this form).  Candidates were
             // dropped (tau below the sentinel) but fewer than k neighbours came back (kth < 0): not certified either
             const float nx = a.nrm[myq];
@@ -1792,15 +1797,62 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
         act = retry;
         continue;
     }
-    // ---- split (tail) items: the exact top-KP of this candidate range + its threshold, merged by knn_filter2_merge_kernel
+    // ---- split (tail) items: the exact top-KP of this candidate range + its threshold go to global memory; the two
+    // sub-sweeps of a tile are neighbouring wavefronts of ONE workgroup (items 4g + {0,1} and 4g + {2,3}: n_full is a
+    // multiple of 4 and the split is 2), and the one that finishes second merges the other's list into its own and
+    // certifies against both thresholds -- a ticket in LDS and workgroup-scope fences, no launch of its own (the
+    // separate merge kernel took 17 us per build behind the whole filter grid).
+    static_assert(kFilterMaxSplit == 2 && kWavesPerGroup % 2 == 0, "pairs of sub-sweeps share a workgroup");
+    const int64_t fslot = (int64_t)(tile - n_full) * kFQ + hh * 32 + col;
     if (valid) {
-        const int64_t fslot = (int64_t)(tile - n_full) * kFQ + hh * 32 + col;
         float *ld = a.psd + (fslot * nsub + sub) * MS;
         int32_t *lj = a.psj + (fslot * nsub + sub) * MS;
 #pragma unroll
         for (int p = 0; p < KP; ++p) { ld[p] = kd[p]; lj[p] = kj[p]; }
         ld[M] = tau;
         lj[M] = L.overflow ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    int arrived = 0;
+    if (lane == 0) arrived = atomicAdd(&tickets[wv >> 1], 1);
+    arrived = __builtin_amdgcn_readfirstlane(arrived);
+    if (arrived == 0) return;                 // the other sub-sweep of this tile is still running: it will merge
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float tau_o = kKnnSentinel;
+    int of_o = 0;
+    if (valid) {
+        const float *ld = a.psd + (fslot * nsub + (sub ^ 1)) * MS;
+        const int32_t *lj = a.psj + (fslot * nsub + (sub ^ 1)) * MS;
+        tau_o = ld[M];
+        of_o = lj[M];
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+            const float od = ld[p];
+            const int32_t oj = lj[p];
+            // (d, j) pairs of the two candidate ranges are distinct; empty slots are never inserted
+            const unsigned long long nk = oj >= 0 ? (((unsigned long long)__float_as_uint(od) << 32) | (unsigned)oj) : ~0ull;
+            bool g[KP];
+#pragma unroll
+            for (int q = 0; q < KP; ++q) g[q] = kk[q] > nk;
+#pragma unroll
+            for (int q = KP - 1; q >= 1; --q) kk[q] = g[q - 1] ? kk[q - 1] : (g[q] ? nk : kk[q]);
+            kk[0] = g[0] ? nk : kk[0];
+        }
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+            kd[p] = __uint_as_float((unsigned)(kk[p] >> 32));
+            kj[p] = kd[p] == kKnnSentinel ? -1 : (int32_t)(unsigned)kk[p];
+        }
+        const float kth = emit();
+        const float nx = a.nrm[myq];
+        const float an = __builtin_sqrtf(nx) * 1.000001f;
+        const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
+        const float slack = f2_slack(an, rn, NH == 1 ? 1.0f : 1.5f);
+        const bool wideq = !(nx < kF16WideLimit * kF16WideLimit);
+        const bool fail_a = tau < kKnnSentinel && !(kth >= 0.0f && tau + nx - slack > kth);
+        const bool fail_b = tau_o < kKnnSentinel && !(kth >= 0.0f && tau_o + nx - slack > kth);
+        if (L.overflow || of_o != 0 || wideq || fail_a || fail_b)
+            flag_query(a, myq, a.xtile_ptr[pos] + (myq - ev_lo) / a.xtile_queries);
     }
     return;
     }   // attempts
@@ -1819,100 +1871,20 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter12_kernel
         FilterQueue<filter_queue_len(filter_list_len(KP))> f1;
     };
     __shared__ WaveLds sh_all[kWavesPerGroup];
+    // arrival tickets of the sub-sweep pairs of split tiles: 4 x 20 480 bytes fill half the CU's LDS exactly, so they
+    // live in the last two padding floats of wavefront 0's row staging area (bytes 20 472..20 479 of its block), which
+    // neither the staging (features 0..15 of a row) nor the first form's queue (at most 19 968 bytes) ever touches;
+    // cleared here, before any wavefront of the group can arrive
+    static_assert(sizeof(WaveLds) == sizeof(F2Wave), "the union is sized by the second form");
+    static_assert(sizeof(FilterQueue<filter_queue_len(filter_list_len(KP))>) <= sizeof(F2Wave) - 8, "ticket bytes are free");
+    static_assert(kWavesPerGroup / 2 <= 2, "two ticket words");
+    int *tickets = reinterpret_cast<int *>(&sh_all[0].f2.rows[kWave - 1][kF2RowF + 2]);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (threadIdx.x < kWavesPerGroup / 2) tickets[threadIdx.x] = 0;
+    __syncthreads();
     const int group = filter_group(a);
-    filter2_wave<KP, NH>(a, sh_all[wv].f2, group, wv, lane);   // returns at once unless the item's event is a second-form event
+    filter2_wave<KP, NH>(a, sh_all[wv].f2, tickets, group, wv, lane);   // returns at once unless the item's event is a second-form event
     if constexpr (NH == 1) filter1_wave<KP>(a, sh_all[wv].f1, group, wv, lane);   // likewise (32 features only)
-}
-
-// Split (tail) tiles of the second form: merge the two exact partial lists of a query by (d, j) and certify against
-// each sub-sweep's threshold.  LPQ lanes per query (element p of both sorted lists on lane p): an element's final rank
-// is its own index plus the number of elements of the OTHER list that precede it -- 2 x KP shuffles and compares per
-// lane, every load issued at once, no dependent chain (a head-pointer merge with one lane per query took 22 us, a
-// register-resident rank merge with one lane per query 37 us).  (d, j) pairs are distinct; empty slots are
-// (sentinel, -1) and are never written.
-constexpr int kF2MergeThreads = 1024;   // all kFQ queries of a tile at once at 16 lanes per query (no dependent rounds)
-template <int KP>
-__global__ __launch_bounds__(kF2MergeThreads) void knn_filter2_merge_kernel(const KnnFilterArgs a)
-{
-    constexpr int M = f2_list_len(KP);
-    constexpr int MS = (M + 1 + 3) & ~3;
-    constexpr int LPQ = KP <= 16 ? 16 : 32;          // lanes per query
-    constexpr int QPB = kF2MergeThreads / LPQ;       // queries per workgroup and round
-    static_assert(kFilterMaxSplit == 2, "two sub-sweeps");
-    const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
-    if (split <= 1) return;
-    // one workgroup per tail tile (its event is looked up once, on the scalar unit), kFQ / QPB rounds of QPB queries
-    const int ft = n_full + (int)blockIdx.x;
-    if (ft >= total) return;
-    const int pos = find_tile_event(a.tile_ptr, a.B, ft);
-    const int ev = a.order[pos];
-    const int64_t ev_lo = a.ptr[ev], ev_hi = a.ptr[ev + 1];
-    if (!f2_in_domain((int)(ev_hi - ev_lo))) return;
-    const int p = threadIdx.x % LPQ;
-    for (int round = 0; round < kFQ / QPB; ++round) {
-    const int qoff = round * QPB + threadIdx.x / LPQ;
-    const int64_t fslot = (int64_t)blockIdx.x * kFQ + qoff;
-    const int64_t q = ev_lo + (int64_t)(ft - a.tile_ptr[pos]) * kFQ + qoff;
-    const bool act = q < ev_hi;
-    const float *pd = a.psd + (act ? fslot : 0) * 2 * MS;
-    const int32_t *pj = a.psj + (act ? fslot : 0) * 2 * MS;
-    const int k = a.k;
-    const bool has = act && p < KP;
-    const float da = has ? pd[p] : kKnnSentinel, db = has ? pd[MS + p] : kKnnSentinel;
-    const int32_t ja = has ? pj[p] : -1, jb = has ? pj[MS + p] : -1;
-    float nx = 0.0f, tau = kKnnSentinel;
-    int32_t of = 0;
-    if (act && p < 2) { tau = pd[p * MS + M]; of = pj[p * MS + M]; nx = a.nrm[q]; }
-    const int base = (threadIdx.x & 63) - p;          // lane of element 0 of this query inside the wavefront
-    int ra = p, rb = p;
-#pragma unroll
-    for (int o = 0; o < KP; ++o) {
-        const float dbo = __shfl(db, base + o, 64), dao = __shfl(da, base + o, 64);
-        const int32_t jbo = __shfl(jb, base + o, 64), jao = __shfl(ja, base + o, 64);
-        ra += (jbo >= 0 && (dbo < da || (dbo == da && jbo < ja))) ? 1 : 0;
-        rb += (jao >= 0 && (dao < db || (dao == db && jao < jb))) ? 1 : 0;
-    }
-    // slots beyond the number of real candidates stay empty: lane p < k clears slot p first if nothing will land there
-    int na = ja >= 0 ? 1 : 0, nb = jb >= 0 ? 1 : 0;
-#pragma unroll
-    for (int off = 1; off < LPQ; off <<= 1) {
-        na += __shfl_xor(na, off, 64);
-        nb += __shfl_xor(nb, off, 64);
-    }
-    float kth = -1.0f;
-    if (act) {
-        if (p < k && p >= na + nb) {
-            a.dist[q * k + p] = kKnnSentinel; a.nbr[q * k + p] = -1;
-            if (a.nbr16) a.nbr16[q * k + p] = 0xFFFFu;
-        }
-        if (ja >= 0 && ra < k) {
-            a.dist[q * k + ra] = da; a.nbr[q * k + ra] = ja;
-            if (a.nbr16) a.nbr16[q * k + ra] = local_id16(ja, (int)ev_lo);
-            if (ra == k - 1) kth = da;
-        }
-        if (jb >= 0 && rb < k) {
-            a.dist[q * k + rb] = db; a.nbr[q * k + rb] = jb;
-            if (a.nbr16) a.nbr16[q * k + rb] = local_id16(jb, (int)ev_lo);
-            if (rb == k - 1) kth = db;
-        }
-    }
-    // the k-th distance to the two lanes that hold a sub-sweep's threshold
-#pragma unroll
-    for (int off = 1; off < LPQ; off <<= 1) kth = fmaxf(kth, __shfl_xor(kth, off, 64));
-    bool fail = false;
-    if (act && p < 2) {
-        const float an = __builtin_sqrtf(nx) * 1.000001f;
-        const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
-        const float slack = f2_slack(an, rn, a.slack_scale);
-        fail = of != 0 || !(nx < kF16WideLimit * kF16WideLimit) ||
-               (tau < kKnnSentinel && !(kth >= 0.0f && tau + nx - slack > kth));
-    }
-    const bool other = __shfl_xor(fail ? 1 : 0, 1, 64) != 0;
-    if (act && p == 0 && (fail || other)) {          // count the query once
-        flag_query(a, (int)q, a.xtile_ptr[pos] + (int)((q - ev_lo) / a.xtile_queries));
-    }
-    }
 }
 
 // Exact R1 chain for the kept candidates of one query, top-k by (d, j), certification.  M lanes per query (one kept
@@ -1946,7 +1918,7 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
     const int pos = find_tile_event(a.tile_ptr, a.B, ft);
     const int ev = a.order[pos];
     const int64_t ev_lo = a.ptr[ev], ev_hi = a.ptr[ev + 1];
-    if (a.form2 && f2_in_domain((int)(ev_hi - ev_lo))) return;   // merged by knn_filter2_merge_kernel
+    if (a.form2 && f2_in_domain((int)(ev_hi - ev_lo))) return;   // merged inside the filter kernel
     const int qoff = part * QPB + wv * QPW + qw;         // query within the tile
     const int64_t q = ev_lo + (int64_t)(ft - a.tile_ptr[pos]) * kFQ + qoff;
     const bool active = qw < QPW && qoff < kFQ && q < ev_hi;
@@ -2294,10 +2266,6 @@ int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, cons
     if constexpr (NH == 1) {    // tail tiles of the first form (32 features only)
         hipLaunchKernelGGL((knn_rerank_kernel<KF>), dim3((unsigned)(tail_max * kRerankParts)), dim3(256), 0, st, f);
         DMET_LAUNCH_CHECK("knn_rerank_kernel");
-    }
-    if (f.form2) {
-        hipLaunchKernelGGL((knn_filter2_merge_kernel<KF>), dim3((unsigned)tail_max), dim3(kF2MergeThreads), 0, st, f);
-        DMET_LAUNCH_CHECK("knn_filter2_merge_kernel");
     }
     return 0;
 }
