@@ -714,7 +714,9 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__
         knn_plan_body(ptr, B, blockIdx.x + 2 == gridDim.x ? o0 : o1);
         return;
     }
-    const int64_t tile = t >> 6;            // wave-uniform
+    // wave-uniform, and said so: the search below then runs on the scalar unit (s_load through the constant cache)
+    // instead of six dependent vector loads per wavefront
+    const int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (tile >= nrec) return;
     const int lane = (int)(t & 63), col = lane & 31, hh = lane >> 5;
     // event that owns the record: the last b with (ptr[b] >> 5) + b <= tile
