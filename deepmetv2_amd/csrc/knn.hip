@@ -6,11 +6,13 @@
 //   R2  top-k by (d, j) lexicographic order == upstream's strict-'>' insertion in ascending j
 // R1 / R2 define the RESULT, not the work done on pairs that cannot win.  Three paths, one stream, no host sync:
 //   * D = 32 (the model's shape) or 64 (the DRN's), k <= 20: a matrix-core FILTER ranks all pairs approximately
-//     (key = |x_j|^2 - 2 x_i.x_j from a bf16 split on v_mfma_f32_32x32x16_bf16), keeps a certified superset of every
-//     query's neighbours, and only those go through the exact R1 chain and the (d, j) order.  Second form
-//     (filter2_wave, events of 2048..65536 nodes): per-tile hit masks, threshold from tile minima; first form
-//     (filter1_wave): per-key queue; one launch (knn_filter12_kernel), each wavefront takes the form its event calls
-//     for.  A query whose certificate does not hold is recomputed exactly.
+//     (key = |x_j|^2 - 2 x_i.x_j), keeps a certified superset of every query's neighbours, and only those go through
+//     the exact R1 chain and the (d, j) order.  Second form (filter2_wave, events of 2048..65536 nodes): single-term
+//     fp16 operands on v_mfma_f32_32x32x16_f16 (2 MFMAs per 32 x 32 block and 32 features; the certificate carries the
+//     fp16 rounding), per-tile hit masks, threshold from tile minima, a second in-wavefront sweep for queries that
+//     miss the certificate by the slack alone; first form (filter1_wave): bf16 split x = h + m on
+//     v_mfma_f32_32x32x16_bf16 (6 MFMAs per block), per-key queue; one launch (knn_filter12_kernel), each wavefront
+//     takes the form its event calls for.  A query whose certificate does not hold is recomputed exactly.
 //   * everything else, and the recomputation: the exact kernel below (knn_kernel).
 //
 // The exact kernel is fp32-VALU bound (a subtract and an fma per (query, candidate, feature); the difference form

@@ -59,10 +59,12 @@ int dmet_knn_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, in
 int dmet_knn_local_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,
                        float *dist, uint16_t *nbr_local, void *ws, size_t ws_bytes, dmet_stream_t stream);
 
-/* Diagnostics of the matrix-core kNN path (D = 32, k <= 20): dmet_knn_f32 first ranks candidates with a bf16-split
- * MFMA filter, re-ranks the kept ones with the exact R1 chain and certifies every query; uncertified queries are
- * recomputed exactly (one at a time when their 128-query tile has at most 8 of them, by the exact tile kernel
- * otherwise).  For the LAST dmet_knn_f32 call on this workspace: out[0] = tiles holding an uncertified query,
+/* Diagnostics of the matrix-core kNN path (D = 32 or 64, k <= 20): dmet_knn_f32 first ranks candidates with an MFMA
+ * filter (fp16 operands for events of 2048..65536 nodes, a bf16 split for smaller ones), re-ranks the kept ones with
+ * the exact R1 chain and certifies every query; uncertified queries are recomputed exactly (one workgroup per query
+ * when their 128-query tile has at most 8 of them, by the exact tile kernel otherwise).  Rows with a feature of
+ * magnitude >= 16384 (or not finite) in an event of 2048..65536 nodes are outside the fp16 operand range: they stay
+ * candidates of every query and are themselves recomputed exactly -- same results, slower.  For the LAST dmet_knn_f32 call on this workspace: out[0] = tiles holding an uncertified query,
  * out[1] = uncertified queries (both 0 when the exact kernel ran alone).  Synchronises the stream.
  * Environment: DMET_KNN_PATH=exact forces the exact kernel for everything. */
 int dmet_knn_fallback_stats(const void *ws, int64_t N, int B, int D, int k, int64_t *out, dmet_stream_t stream);
