@@ -272,6 +272,35 @@ def test_knn_filter_adversarial(dev, monkeypatch, case, sizes, D):
         assert st["flagged_queries"] - min(by_design, N) <= N // 20, st
 
 
+@pytest.mark.parametrize("D", [32, 64])
+@pytest.mark.parametrize("case", ["fp16_subnormal_operands", "few_rows_beyond_fp16", "unit_scale_certified"])
+def test_knn_fp16_operand_range(dev, case, D):
+    """The second filter form ranks pairs with single-term fp16 operands (DESIGN K1, second session of round 2); its
+    certificate assumes (a) round-to-nearest fp16 with subnormals KEPT by v_mfma_f32_32x32x16_f16 -- inputs of ~3e-5 are
+    all subnormal in fp16: a flush would zero every product, every key would be |x_j|^2 and the wrong neighbours would be
+    certified -- and (b) that rows with |v| >= 16384 are forced candidates rather than overflowed products.  Bits must
+    equal the C oracle's in all cases; at unit scale (and with a handful of rows beyond the range) nearly every query
+    must be certified by the filter itself."""
+    g = torch.Generator().manual_seed(77 + D)
+    sizes = [4500, 2300]
+    N, k = sum(sizes), 16
+    x = torch.randn(N, D, generator=g)
+    if case == "fp16_subnormal_operands":
+        x = x * 3.0e-5
+    elif case == "few_rows_beyond_fp16":
+        idx = torch.randperm(N, generator=g)[:5]
+        x[idx, 3] = torch.tensor([2.0e4, -3.0e4, 1.7e4, 6.6e4, -7.0e4])   # still far below the 1e10 distance sentinel for most
+    st = _knn_vs_oracle(dev, x.contiguous(), sizes, k)
+    if os.environ.get("DMET_KNN_PATH", "") != "exact" and os.environ.get("DMET_KNN_FILTER", "") != "1":
+        if case == "unit_scale_certified":
+            assert st["flagged_queries"] <= 2, st
+        elif case == "few_rows_beyond_fp16":
+            assert st["flagged_queries"] <= 5 + 2, st       # the five rows themselves (as queries) + slack
+        else:
+            # most queries must have been certified from the subnormal operands themselves (the fallback would hide a flush)
+            assert st["flagged_queries"] <= N // 4, st
+
+
 def test_knn_second_filter_form_paths_agree_fuzz(dev, monkeypatch):
     """Events of 2048..7000 nodes (second filter form, including the split tail tiles of a small batch) against the
     exact kernel on gaussian / clustered-with-duplicates / heavy-tailed / rank-2 data, k in {16, 8, 20, 13, 1}."""
