@@ -186,6 +186,12 @@ struct KnnArgs {
     const int32_t *flags;  // optional [tiles] = number of uncertified queries per tile (matrix-core path): only
     int flag_min;          // tiles with flags[tile] >= flag_min are computed here
     const int32_t *any;    // optional: total number of uncertified queries (0: nothing to do for any workgroup)
+    // per-query fallback of the matrix-core path, run by the first requery_groups workgroups of the same launch (32
+    // features): the flagged queries in flagging order, the event -> position map of the plans, queries per exact tile
+    const int32_t *qlist;
+    const int32_t *pos_of;
+    int requery_groups;
+    int requery_tile_queries;
 };
 
 __device__ __forceinline__ uint16_t local_id16(int32_t j, int ev_lo)
@@ -348,6 +354,137 @@ __device__ __forceinline__ void load_tile(float4 (&pf)[NLD], const float *__rest
     }
 }
 
+__device__ __forceinline__ float chain_dist32(const float *__restrict__ xj, const float (&q)[32])
+{
+    const float4 *g = reinterpret_cast<const float4 *>(xj);
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float4 v = g[c];
+        float df;
+        df = v.x - q[4 * c + 0]; acc = __builtin_fmaf(df, df, acc);
+        df = v.y - q[4 * c + 1]; acc = __builtin_fmaf(df, df, acc);
+        df = v.z - q[4 * c + 2]; acc = __builtin_fmaf(df, df, acc);
+        df = v.w - q[4 * c + 3]; acc = __builtin_fmaf(df, df, acc);
+    }
+    return acc;
+}
+
+// Uncertified queries of sparsely flagged tiles (1..kRequeryMax per 128-query tile; denser tiles go to the exact
+// tile kernel): ONE WORKGROUP PER FLAGGED QUERY, taken from the list the flagging sites append to (round 2: the
+// tile's workgroup used to take its queries one after the other, and a single straggler cost the build ~90 us).  The
+// 256 lanes stride over the event's candidates with the exact R1 chain (four rows in flight per lane; distances cached
+// in LDS when the event fits), then k rounds of "smallest (d, j) above the previous pick" (R2) on 64-bit
+// (distance bits, j) words with a wavefront + cross-wavefront reduction.
+constexpr int kRequeryMax = 8;
+constexpr int kRequeryGroups = 512;    // workgroups of the launch: they exit at once while nothing is flagged
+
+__device__ __forceinline__ unsigned long long requery_word(float d, int j)
+{
+    // a candidate at d >= 1e10 (or NaN) is never a neighbour (upstream's initial best distance, dmet_oracle.c:62)
+    return d < kKnnSentinel ? (((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j) : ~0ull;
+}
+
+// Runs as the first kRequeryGroups workgroups of the exact kernel's launch (its own launch cost 4.7 us per build while
+// nothing is flagged); `cache` / `red` alias that kernel's LDS.
+__device__ __forceinline__ void knn_requery_body(const KnnArgs &a, float *__restrict__ cache, const int cache_floats,
+                                                 unsigned long long *__restrict__ red, const int group, const int ngroups)
+{
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int64_t nf64 = *a.any;
+    const int nflag = (int)(nf64 < a.N ? nf64 : a.N);
+    const int k = a.k;
+    for (int it = group; it < nflag; it += ngroups) {   // block-uniform
+        const int q = a.qlist[it];
+        int lo = 0, hi = a.B;                // event of q: the last b with ptr[b] <= q (empty events share a ptr value
+        while (hi - lo > 1) {                // with their successor and are skipped by taking the last)
+            const int mid = (lo + hi) >> 1;
+            if (a.ptr[mid] <= q) lo = mid; else hi = mid;
+        }
+        const int ev = lo;
+        const int ev_lo = (int)a.ptr[ev], ev_hi = (int)a.ptr[ev + 1];
+        const int n = ev_hi - ev_lo;
+        const int xt = a.tile_ptr[a.pos_of[ev]] + (q - ev_lo) / a.requery_tile_queries;
+        if (a.flags[xt] > kRequeryMax) continue;   // a densely flagged tile: the exact tile kernel recomputes it
+        const bool cached = n <= cache_floats;
+        float qrow[32];
+        {
+            const float4 *g = reinterpret_cast<const float4 *>(a.x + (int64_t)q * 32);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 v = g[c];
+                qrow[4 * c] = v.x; qrow[4 * c + 1] = v.y; qrow[4 * c + 2] = v.z; qrow[4 * c + 3] = v.w;
+            }
+        }
+        __syncthreads();   // the previous query's cache / reduction slots are free
+        if (cached) {
+            // four candidate rows in flight per lane (clamped re-reads past the end, results unused)
+            for (int j0 = tid; j0 < n; j0 += 4 * 256) {
+                float4 r[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 *g = reinterpret_cast<const float4 *>(a.x + (int64_t)(ev_lo + min(j0 + 256 * u, n - 1)) * 32);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) r[u][c] = g[c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float dc = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        float df;
+                        df = r[u][c].x - qrow[4 * c + 0]; dc = __builtin_fmaf(df, df, dc);
+                        df = r[u][c].y - qrow[4 * c + 1]; dc = __builtin_fmaf(df, df, dc);
+                        df = r[u][c].z - qrow[4 * c + 2]; dc = __builtin_fmaf(df, df, dc);
+                        df = r[u][c].w - qrow[4 * c + 3]; dc = __builtin_fmaf(df, df, dc);
+                    }
+                    if (j0 + 256 * u < n) cache[j0 + 256 * u] = dc;
+                }
+            }
+            __syncthreads();
+        }
+        unsigned long long last = 0ull;
+        bool first = true;
+        for (int r = 0; r < k; ++r) {
+            unsigned long long best = ~0ull;
+            for (int j = tid; j < n; j += 256) {
+                const float d = cached ? cache[j] : chain_dist32(a.x + (int64_t)(ev_lo + j) * 32, qrow);
+                const unsigned long long w = requery_word(d, ev_lo + j);
+                if ((first || w > last) && w < best) best = w;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(best, off, 64);
+                if (o < best) best = o;
+            }
+            if (lane == 0) red[wv] = best;
+            __syncthreads();
+            best = red[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) if (red[w] < best) best = red[w];
+            __syncthreads();
+            const bool found = best != ~0ull;   // block-uniform
+            if (tid == 0) {
+                const int bj = found ? (int)(unsigned)best : -1;
+                a.nbr[(int64_t)q * k + r] = bj;
+                if (a.nbr16) a.nbr16[(int64_t)q * k + r] = local_id16(bj, ev_lo);
+                a.dist[(int64_t)q * k + r] = found ? __uint_as_float((unsigned)(best >> 32)) : kKnnSentinel;
+            }
+            if (!found) {
+                if (tid == 0)
+                    for (int rr = r + 1; rr < k; ++rr) {
+                        a.nbr[(int64_t)q * k + rr] = -1;
+                        a.dist[(int64_t)q * k + rr] = kKnnSentinel;
+                        if (a.nbr16) a.nbr16[(int64_t)q * k + rr] = 0xFFFFu;
+                    }
+                break;
+            }
+            last = best;
+            first = false;
+        }
+    }
+}
+
 template <int DP, int KP, int TQ, bool EXACT_D>
 __global__ __launch_bounds__(kWave * kWavesPerGroup, 3) void knn_kernel(const KnnArgs a)
 {
@@ -359,7 +496,21 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 3) void knn_kernel(const Kn
     // (wave-uniform, and said so: without readfirstlane the tile, the event and every derived address are per-lane math)
     const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     KnnShared<DP, TQ> &sh = sh_all[wv_];
-    const int item = blockIdx.x * kWavesPerGroup + wv_;
+    int first_group = 0;
+    if constexpr (DP == 32) {
+        if (a.qlist) {    // (kernel-uniform) matrix-core path: the leading workgroups are the per-query fallback
+            if (a.any && *a.any == 0) return;
+            if ((int)blockIdx.x < a.requery_groups) {
+                constexpr int kFloats = (int)((sizeof(sh_all) - 64) / sizeof(float));
+                knn_requery_body(a, reinterpret_cast<float *>(sh_all), kFloats,
+                                 reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(sh_all) + sizeof(sh_all) - 64),
+                                 (int)blockIdx.x, a.requery_groups);
+                return;
+            }
+            first_group = a.requery_groups;
+        }
+    }
+    const int item = ((int)blockIdx.x - first_group) * kWavesPerGroup + wv_;
     const int lane = threadIdx.x & 63;
 #ifdef DMET_KNN_STAMP
     if (lane == 0 && item < (1 << 16)) {
@@ -380,7 +531,9 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 3) void knn_kernel(const Kn
     // which (query tile, candidate sub-sweep) is this wavefront?  (plan lives in device memory)
     const int n_full = a.plan->n_full, split = a.plan->split, total = a.plan->total_tiles;
     int tile = item, sub = 0, nsub = 1;
-    if (item >= n_full) {
+    // as the fallback of the matrix-core path (flags given) every tile is swept whole: the few flagged tiles need no
+    // balancing, and without partial lists the merge launch is not needed either
+    if (item >= n_full && !a.flags) {
         const int r = item - n_full;
         tile = n_full + r / split;
         sub = r % split;
@@ -953,21 +1106,6 @@ __device__ __forceinline__ void filter_select(FilterLane<M> &L, const f32x16 &ac
     }
 }
 
-__device__ __forceinline__ float chain_dist32(const float *__restrict__ xj, const float (&q)[32])
-{
-    const float4 *g = reinterpret_cast<const float4 *>(xj);
-    float acc = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const float4 v = g[c];
-        float df;
-        df = v.x - q[4 * c + 0]; acc = __builtin_fmaf(df, df, acc);
-        df = v.y - q[4 * c + 1]; acc = __builtin_fmaf(df, df, acc);
-        df = v.z - q[4 * c + 2]; acc = __builtin_fmaf(df, df, acc);
-        df = v.w - q[4 * c + 3]; acc = __builtin_fmaf(df, df, acc);
-    }
-    return acc;
-}
 
 // events of the second form (filter2_wave below): kF2MinNodes .. kF2MaxNodes nodes (constants with the plan)
 __device__ __forceinline__ bool f2_in_domain(int n) { return n >= kF2MinNodes && n <= kF2MaxNodes; }
@@ -2025,121 +2163,6 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(const KnnFilterArgs a)
     }
 }
 
-// Uncertified queries of sparsely flagged tiles (1..kRequeryMax per 128-query tile; denser tiles go to the exact
-// tile kernel): ONE WORKGROUP PER FLAGGED QUERY, taken from the list the flagging sites append to (round 2: the
-// tile's workgroup used to take its queries one after the other, and a single straggler cost the build ~90 us).  The
-// 256 lanes stride over the event's candidates with the exact R1 chain (four rows in flight per lane; distances cached
-// in LDS when the event fits), then k rounds of "smallest (d, j) above the previous pick" (R2) on 64-bit
-// (distance bits, j) words with a wavefront + cross-wavefront reduction.
-constexpr int kRequeryMax = 8;
-constexpr int kRequeryGroups = 512;    // workgroups of the launch: they exit at once while nothing is flagged
-constexpr int kRequeryCache = 16384;   // floats
-
-__device__ __forceinline__ unsigned long long requery_word(float d, int j)
-{
-    // a candidate at d >= 1e10 (or NaN) is never a neighbour (upstream's initial best distance, dmet_oracle.c:62)
-    return d < kKnnSentinel ? (((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j) : ~0ull;
-}
-
-__global__ __launch_bounds__(256) void knn_requery_kernel(const KnnFilterArgs a)
-{
-    __shared__ float cache[kRequeryCache];
-    __shared__ unsigned long long red[4];
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int64_t nf64 = *a.any;
-    const int nflag = (int)(nf64 < a.N ? nf64 : a.N);
-    const int k = a.k;
-    for (int it = blockIdx.x; it < nflag; it += gridDim.x) {   // block-uniform
-        const int q = a.qlist[it];
-        int lo = 0, hi = a.B;                // event of q: the last b with ptr[b] <= q (empty events share a ptr value
-        while (hi - lo > 1) {                // with their successor and are skipped by taking the last)
-            const int mid = (lo + hi) >> 1;
-            if (a.ptr[mid] <= q) lo = mid; else hi = mid;
-        }
-        const int ev = lo;
-        const int ev_lo = (int)a.ptr[ev], ev_hi = (int)a.ptr[ev + 1];
-        const int n = ev_hi - ev_lo;
-        const int xt = a.xtile_ptr[a.pos_of[ev]] + (q - ev_lo) / a.xtile_queries;
-        if (a.flags[xt] > kRequeryMax) continue;   // a densely flagged tile: the exact tile kernel recomputes it
-        const bool cached = n <= kRequeryCache;
-        float qrow[32];
-        {
-            const float4 *g = reinterpret_cast<const float4 *>(a.x + (int64_t)q * 32);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float4 v = g[c];
-                qrow[4 * c] = v.x; qrow[4 * c + 1] = v.y; qrow[4 * c + 2] = v.z; qrow[4 * c + 3] = v.w;
-            }
-        }
-        __syncthreads();   // the previous query's cache / reduction slots are free
-        if (cached) {
-            // four candidate rows in flight per lane (clamped re-reads past the end, results unused)
-            for (int j0 = tid; j0 < n; j0 += 4 * 256) {
-                float4 r[4][8];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 *g = reinterpret_cast<const float4 *>(a.x + (int64_t)(ev_lo + min(j0 + 256 * u, n - 1)) * 32);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) r[u][c] = g[c];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float dc = 0.0f;
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        float df;
-                        df = r[u][c].x - qrow[4 * c + 0]; dc = __builtin_fmaf(df, df, dc);
-                        df = r[u][c].y - qrow[4 * c + 1]; dc = __builtin_fmaf(df, df, dc);
-                        df = r[u][c].z - qrow[4 * c + 2]; dc = __builtin_fmaf(df, df, dc);
-                        df = r[u][c].w - qrow[4 * c + 3]; dc = __builtin_fmaf(df, df, dc);
-                    }
-                    if (j0 + 256 * u < n) cache[j0 + 256 * u] = dc;
-                }
-            }
-            __syncthreads();
-        }
-        unsigned long long last = 0ull;
-        bool first = true;
-        for (int r = 0; r < k; ++r) {
-            unsigned long long best = ~0ull;
-            for (int j = tid; j < n; j += 256) {
-                const float d = cached ? cache[j] : chain_dist32(a.x + (int64_t)(ev_lo + j) * 32, qrow);
-                const unsigned long long w = requery_word(d, ev_lo + j);
-                if ((first || w > last) && w < best) best = w;
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned long long o = __shfl_xor(best, off, 64);
-                if (o < best) best = o;
-            }
-            if (lane == 0) red[wv] = best;
-            __syncthreads();
-            best = red[0];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) if (red[w] < best) best = red[w];
-            __syncthreads();
-            const bool found = best != ~0ull;   // block-uniform
-            if (tid == 0) {
-                const int bj = found ? (int)(unsigned)best : -1;
-                a.nbr[(int64_t)q * k + r] = bj;
-                if (a.nbr16) a.nbr16[(int64_t)q * k + r] = local_id16(bj, ev_lo);
-                a.dist[(int64_t)q * k + r] = found ? __uint_as_float((unsigned)(best >> 32)) : kKnnSentinel;
-            }
-            if (!found) {
-                if (tid == 0)
-                    for (int rr = r + 1; rr < k; ++rr) {
-                        a.nbr[(int64_t)q * k + rr] = -1;
-                        a.dist[(int64_t)q * k + rr] = kKnnSentinel;
-                        if (a.nbr16) a.nbr16[(int64_t)q * k + rr] = 0xFFFFu;
-                    }
-                break;
-            }
-            last = best;
-            first = false;
-        }
-    }
-}
-
 int num_simds()
 {
     static int cached = 0;
@@ -2293,7 +2316,8 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
         hipLaunchKernelGGL(knn_plan_kernel, dim3(1), dim3(256), 0, st, ptr, B, px, pf);
         DMET_LAUNCH_CHECK("knn_plan_kernel");
     }
-    KnnArgs a{x, ptr, B, N, D, k, nbr, dist, nbr16, w.wsd, w.wsj, w.plan, w.order, w.tile_ptr, w.psd, w.psj, nullptr, 0, nullptr};
+    KnnArgs a{x, ptr, B, N, D, k, nbr, dist, nbr16, w.wsd, w.wsj, w.plan, w.order, w.tile_ptr, w.psd, w.psj, nullptr, 0, nullptr,
+              nullptr, nullptr, 0, QT};
     // uncertified-query counters: zero for every call, so dmet_knn_fallback_stats is meaningful on any path (the
     // matrix-core path clears them in its prep kernel)
     if (!use_filter && hipMemsetAsync(w.flags, 0, w.zero_bytes, st) != hipSuccess)
@@ -2316,8 +2340,9 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
         a.flags = w.flags;
         a.any = w.any;
         if constexpr (NH == 1) {
-            hipLaunchKernelGGL(knn_requery_kernel, dim3((unsigned)kRequeryGroups), dim3(256), 0, st, f);
-            DMET_LAUNCH_CHECK("knn_requery_kernel");
+            a.qlist = w.qlist;             // the per-query fallback rides in front of the exact kernel's grid
+            a.pos_of = w.pos_of;
+            a.requery_groups = kRequeryGroups;
             a.flag_min = kRequeryMax + 1;
         } else {
             a.flag_min = 1;    // no per-query fallback at 64 features: the exact kernel takes every flagged tile
@@ -2327,7 +2352,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     // worst-case grid (the plan is on the device): every event adds at most one partial tile, and splitting the
     // fewer-than-`simds` tail tiles adds fewer than `simds` workgroups; surplus workgroups exit at once
     const int64_t tiles_max = (N + QT - 1) / QT + B;
-    const int64_t blocks = (tiles_max + simds + kWavesPerGroup - 1) / kWavesPerGroup;
+    const int64_t blocks = (tiles_max + simds + kWavesPerGroup - 1) / kWavesPerGroup + a.requery_groups;
     unsigned dyn = 0;
 #ifdef DMET_KNN_EXPERIMENT
     if (const char *e = getenv("DMET_KNN_EXTRA_LDS")) dyn = (unsigned)atoi(e);
@@ -2337,7 +2362,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     else
         hipLaunchKernelGGL((knn_kernel<DP, KP, TQ, false>), dim3((unsigned)blocks), dim3(kWave * kWavesPerGroup), dyn, st, a);
     DMET_LAUNCH_CHECK("knn_kernel");
-    {   // split tiles (the tail of a large batch, every tile of a small one) merge their partial lists
+    if (!use_filter) {   // split tiles (the tail of a large batch, every tile of a small one) merge their partial lists
         int64_t slots = (int64_t)simds * QT;
         if (tiles_max * QT < slots) slots = tiles_max * QT;
         hipLaunchKernelGGL((knn_merge_kernel<KP>), dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, st, a, QT);
