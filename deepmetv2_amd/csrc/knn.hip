@@ -1495,6 +1495,9 @@ __device__ __forceinline__ float f2_slack(float an, float rn, float scale)
 // ~10 at KP + 4, ~2 at KP + 5, ~0.1 at KP + 6); a lane keeps kF2Slots = 30 entries, so the widest list stays at 24
 constexpr int f2_list_len(int KP) { return KP <= 16 ? KP + 6 : KP + 4; }
 
+// candidate row (0..31) of hit-mask position p (counted from the most significant bit), see f2_tile
+__device__ __forceinline__ int f2_mask_row(int p) { return (p & 3) + 8 * ((p & 15) >> 2) + 4 * (p >> 4); }
+
 // One tile of a sweep, software-pipelined inside the wavefront: the 12 MFMAs of tile t + 1 (operands `use`) are
 // issued between the vector instructions that select from tile t's keys (c0, c1, computed one call earlier), and the
 // operands of tile t + 2 are loaded into `ld`.  On gfx950 independent VALU work of the same wavefront hides under an
@@ -1531,46 +1534,43 @@ __device__ __forceinline__ void f2_tile(F2Lane<M> &L, F2Wave &S, const uint8_t *
 #endif
     n0 = f2_block<NH>(use.a, bq[0], use.c);     // (s_setprio 1 around these was measured: 10 % slower)
     n1 = f2_block<NH>(use.a, bq[1], use.c);
-    // lanes 32..63 of block 0 <-> lanes 0..31 of block 1: afterwards c0 = rows {0-3, 8-11, ..} and c1 = rows
-    // {4-7, 12-15, ..} of THIS lane's query
-#if !(defined(DMET_F2_ABL) && DMET_F2_ABL >= 4)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c0[e]), __float_as_uint(c1[e]), false, false);
-        c0[e] = __uint_as_float(r[0]);
-        c1[e] = __uint_as_float(r[1]);
-    }
-#endif
-#if defined(DMET_F2_ABL) && DMET_F2_ABL >= 2
-#pragma unroll
-    for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(c0[e]), "v"(c1[e]));
-#endif
+    // The accumulators stay where the MFMAs left them: lane (col, hh) holds, for candidate rows (e & 3) + 8 (e >> 2) + 4 hh,
+    // the keys of query (0, col) in c0 and of query (1, col) in c1 -- 16 keys of each of the two queries the lane PAIR
+    // (col, 0), (col, 1) owns.  Every lane reduces both halves it holds (hit mask against the owner's threshold, minimum)
+    // and the pair exchanges the REDUCED values: v_permlane32_swap(V0, V1) trades V0 of lanes 32..63 for V1 of lanes
+    // 0..31, so with V0 = "my part for query (0, col)" and V1 = "my part for query (1, col)" every lane ends up with
+    // V0 = the hh = 0 rows' part and V1 = the hh = 1 rows' part of ITS OWN query.  Three swaps per tile (thresholds,
+    // masks, minima) instead of the sixteen that moved the accumulators themselves (second session of round 2; a swap
+    // costs two issue slots and sat between the MFMA results and everything else).
     unsigned mask = 0u;
     if (kRec) {
-        // candidate row r = 8 (r >> 3) + 4 a + (r & 3) sits in c{a}[(r & 3) + 4 (r >> 3)]; rows in ascending order, so
-        // row r ends up in bit 31 - r.  Two VALU ops per key: key - tau, then v_alignbit shifts its sign bit into the
-        // mask (a NaN key may set a bit: its exact distance is NaN and never enters the result).
+        const auto tt = __builtin_amdgcn_permlane32_swap(__float_as_uint(L.tau), __float_as_uint(L.tau), false, false);
+        const float t0 = __uint_as_float(tt[0]), t1 = __uint_as_float(tt[1]);   // thresholds of query (0, col) / (1, col)
+        // Two VALU ops per key: key - tau, then v_alignbit shifts its sign bit into the mask (a NaN key may set a bit:
+        // its exact distance is NaN and never enters the result).  Element e of a half ends up in bit 15 - e.
         // (v_pk_add_f32 for two rows at once was measured: no gain -- packed fp32 issues at half rate here)
-        unsigned mlo = 0u, mhi = 0u;
+        unsigned ma = 0u, mb = 0u;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ra = r, rb = r + 16;
-            const float ka = ((ra >> 2) & 1) ? c1[(ra & 3) + 4 * (ra >> 3)] : c0[(ra & 3) + 4 * (ra >> 3)];
-            const float kb = ((rb >> 2) & 1) ? c1[(rb & 3) + 4 * (rb >> 3)] : c0[(rb & 3) + 4 * (rb >> 3)];
-            mhi = __builtin_amdgcn_alignbit(mhi, __float_as_uint(ka - L.tau), 31);
-            mlo = __builtin_amdgcn_alignbit(mlo, __float_as_uint(kb - L.tau), 31);
+        for (int e = 0; e < 16; ++e) {
+            ma = __builtin_amdgcn_alignbit(ma, __float_as_uint(c0[e] - t0), 31);
+            mb = __builtin_amdgcn_alignbit(mb, __float_as_uint(c1[e] - t1), 31);
         }
-        mask = (mhi << 16) | mlo;
+        const auto mm = __builtin_amdgcn_permlane32_swap(ma, mb, false, false);
+        // bit 31 - p: p < 16 -> element p of the hh = 0 rows, else element p - 16 of the hh = 1 rows (f2_mask_row)
+        mask = (mm[0] << 16) | mm[1];
     }
     float tmin = -__builtin_inff();   // deferred tiles: "never drop" (their tau is already final)
     if (kUpd) {
-        tmin = kKnnSentinel;          // also keeps a NaN key out of the v_med3 chain
+        float na = kKnnSentinel, nb = kKnnSentinel;   // (the start value also keeps a NaN key out of the v_med3 chain)
         // v_min3_f32 by hand: fminf() makes hipcc canonicalise every MFMA output with a v_max first (twice the ops)
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(tmin) : "v"(c0[e]), "v"(c0[e + 1]));
-            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(tmin) : "v"(c1[e]), "v"(c1[e + 1]));
+            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(na) : "v"(c0[e]), "v"(c0[e + 1]));
+            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(nb) : "v"(c1[e]), "v"(c1[e + 1]));
         }
+        const auto nn = __builtin_amdgcn_permlane32_swap(__float_as_uint(na), __float_as_uint(nb), false, false);
+        tmin = __uint_as_float(nn[0]);
+        asm("v_min_f32 %0, %0, %1" : "+v"(tmin) : "v"(__uint_as_float(nn[1])));
     }
     if (kRec) {
         // one 8-byte entry per tile and lane, kept only when the mask is non-zero (branch-free append)
@@ -1743,7 +1743,7 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
     int slot = 0;
     unsigned cmask = 0u;
     int ctile = 0;
-    // next candidate of this lane (tiles as appended, ascending rows inside a tile), -1 when exhausted
+    // next candidate of this lane (tiles as appended, mask order inside a tile), -1 when exhausted
     auto pop = [&]() __attribute__((always_inline)) -> int32_t {
         if (cmask == 0u && slot < nent) {
             const uint2 e = S.ent[slot][lane];
@@ -1755,7 +1755,7 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
         if (cmask != 0u) {
             const int r = __builtin_clz(cmask);
             cmask &= ~(0x80000000u >> r);
-            j = ev_lo + ctile * 32 + r;   // < ev_hi: rows past the event's end have key = +inf and are never set
+            j = ev_lo + ctile * 32 + f2_mask_row(r);   // < ev_hi: rows past the event's end have key = +inf and are never set
         }
         return j;
     };
