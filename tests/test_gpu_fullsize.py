@@ -301,6 +301,25 @@ def test_knn_fp16_operand_range(dev, case, D):
             assert st["flagged_queries"] <= N // 4, st
 
 
+def test_knn_many_sparse_uncertified_queries(dev):
+    """More flagged queries than the per-query fallback has workgroups (512), at most a few per 128-query tile: clusters
+    of 40 exact duplicates scattered over 8 events -- every member has 39 neighbours at distance 0, more ties at the
+    threshold than the filter keeps, so its certificate fails and the list-driven fallback (the leading workgroups of
+    the exact kernel's launch, each walking the list with a stride) recomputes it.  Bits equal the C oracle's."""
+    g = torch.Generator().manual_seed(991)
+    sizes = [4500] * 8
+    N, D, k = sum(sizes), 32, 16
+    x = torch.randn(N, D, generator=g)
+    for c in range(40):
+        ev = c % len(sizes)
+        rows = ev * 4500 + torch.randperm(4500, generator=g)[:40]
+        x[rows] = x[rows[0]].clone()
+    st = _knn_vs_oracle(dev, x.contiguous(), sizes, k)
+    if os.environ.get("DMET_KNN_PATH", "") != "exact":
+        assert st["flagged_queries"] > 512, st           # (about half of the 1 600 duplicates: the rest certify)
+        assert st["flagged_queries"] <= N // 10, st      # sparse: the rest of the batch stays certified
+
+
 def test_knn_second_filter_form_paths_agree_fuzz(dev, monkeypatch):
     """Events of 2048..7000 nodes (second filter form, including the split tail tiles of a small batch) against the
     exact kernel on gaussian / clustered-with-duplicates / heavy-tailed / rank-2 data, k in {16, 8, 20, 13, 1}."""
