@@ -68,24 +68,23 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd
     // software pipeline: the rows of the NEXT chunk are loaded into registers while the matrix products of the
     // current one run (two wavefronts per SIMD do not hide a global round trip per chunk by themselves)
     float4 np[kChunk / 8], nq[kChunk / 8], nx[kChunk / 8];
+    unsigned na[kChunk / 8];    // the four winning-slot bytes that go with np[g] (0: keep every channel)
+    // The slot bytes are only LOADED here; the mask is applied when the rows go to LDS.  (Round 2, second session:
+    // masking inside the prefetch consumed the loaded values on the spot -- s_waitcnt vmcnt(0) after each of the four
+    // row groups, i.e. four exposed memory round trips per 32-node chunk: 8 us per chunk, matrix pipe 28 % busy.)
     auto fetch = [&](const int64_t base) {
 #pragma unroll
         for (int g = 0; g < kChunk / 8; ++g) {
             const int64_t i = base + g * 8 + lr;
             float4 vp = make_float4(0.f, 0.f, 0.f, 0.f), vq = vp, vx = vp;
+            unsigned va = 0u;
             if (i < hi) {
                 vp = reinterpret_cast<const float4 *>(g_out + i * kH)[lp];
                 vq = reinterpret_cast<const float4 *>(gQ + i * kH)[lp];
                 vx = reinterpret_cast<const float4 *>(x + i * kH)[lp];
-                if (arg) {   // nodes without any neighbour produced 0 (R3): no gradient reaches P there
-                    const uchar4 a4 = reinterpret_cast<const uchar4 *>(arg + i * kH)[lp];
-                    if (a4.x == 255) vp.x = 0.f;
-                    if (a4.y == 255) vp.y = 0.f;
-                    if (a4.z == 255) vp.z = 0.f;
-                    if (a4.w == 255) vp.w = 0.f;
-                }
+                if (arg) va = reinterpret_cast<const unsigned *>(arg + i * kH)[lp];
             }
-            np[g] = vp; nq[g] = vq; nx[g] = vx;
+            np[g] = vp; nq[g] = vq; nx[g] = vx; na[g] = va;
         }
     };
     if (lo < hi) fetch(lo);
@@ -94,6 +93,11 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd
 #pragma unroll
         for (int g = 0; g < kChunk / 8; ++g) {
             const int r = g * 8 + lr;
+            // nodes without any neighbour produced 0 (R3): no gradient reaches P there (slot byte 255)
+            if ((na[g] & 0xFFu) == 0xFFu) np[g].x = 0.f;
+            if (((na[g] >> 8) & 0xFFu) == 0xFFu) np[g].y = 0.f;
+            if (((na[g] >> 16) & 0xFFu) == 0xFFu) np[g].z = 0.f;
+            if ((na[g] >> 24) == 0xFFu) np[g].w = 0.f;
             *reinterpret_cast<float4 *>(&P[r * kPad + 4 * lp]) = np[g];
             *reinterpret_cast<float4 *>(&Q[r * kPad + 4 * lp]) = nq[g];
             *reinterpret_cast<float4 *>(&X[r * kPad + 4 * lp]) = nx[g];
