@@ -120,7 +120,9 @@ def _note_gather(name: str) -> None:
 
 
 # ---- K1 ------------------------------------------------------------------------------------------------------
-def _knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict], want_local: bool):
+def _knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict], want_local: bool, dense=None):
+    """dense = (W[32,64], b or None, sliced): also ask the build for the node-level dense layer of the EdgeConv that
+    consumes the graph (dmet_knn_local_dense_f32); a fourth result (P, Q) or None is then returned."""
     dev = _require_device(x, ptr)
     L = _lib.load()
     x = _f32c(x.detach(), "x")
@@ -134,11 +136,30 @@ def _knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict], want
     loc = torch.empty((N, k), dtype=torch.int16, device=dev) if want_local else None
     nb = L.dmet_knn_workspace_bytes(N, B, D, k)
     ws = _ws(nb, dev)
+    pq = None
+    asked = dense is not None
+    if dense is not None and (D != 32 or N == 0 or B == 0 or tuple(dense[0].shape) != (32, 64)):
+        dense = None
     _t = timer.record('knn', dev)
     with _on(dev):
-        _lib.check(L.dmet_knn_local_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, k, nbr.data_ptr(), dist.data_ptr(),
-                                        loc.data_ptr() if want_local else None, ws.data_ptr(), ws.numel(),
-                                        _stream(dev)), "dmet_knn_local_f32")
+        if dense is None:
+            _lib.check(L.dmet_knn_local_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, k, nbr.data_ptr(), dist.data_ptr(),
+                                            loc.data_ptr() if want_local else None, ws.data_ptr(), ws.numel(),
+                                            _stream(dev)), "dmet_knn_local_f32")
+        else:
+            import ctypes
+            W, b, sliced = dense
+            W = _f32c(W.detach(), "W")
+            bp = _f32c(b.detach(), "b").data_ptr() if b is not None else None
+            PQ = torch.empty((2, 4, N, 8) if sliced else (2, N, 32), dtype=torch.float32, device=dev)
+            done = ctypes.c_int(0)
+            _lib.check(L.dmet_knn_local_dense_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, k, nbr.data_ptr(),
+                                                  dist.data_ptr(), loc.data_ptr() if want_local else None,
+                                                  W.data_ptr(), bp, 1 if sliced else 0, PQ[0].data_ptr(),
+                                                  PQ[1].data_ptr(), ctypes.cast(ctypes.pointer(done), ctypes.c_void_p),
+                                                  ws.data_ptr(), ws.numel(), _stream(dev)), "dmet_knn_local_dense_f32")
+            if done.value:
+                pq = (PQ[0], PQ[1], bool(sliced))
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))
     if stats is not None and N > 0 and B > 0:
@@ -149,6 +170,8 @@ def _knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict], want
                                                  _stream(dev)), "dmet_knn_fallback_stats")
             stats["flagged_tiles"], stats["flagged_queries"] = int(out[0]), int(out[1])
             stats["tiles"] = (N + 127) // 128
+    if asked:
+        return nbr, dist, loc, pq
     return nbr, dist, loc
 
 
@@ -158,6 +181,15 @@ def knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict] = None
     exactly; diagnostics only)."""
     nbr, dist, _ = _knn(x, ptr, k, stats, False)
     return nbr, dist
+
+
+def knn_local_dense(x: torch.Tensor, ptr: torch.Tensor, k: int, W: torch.Tensor, b: Optional[torch.Tensor],
+                    sliced: bool, stats: Optional[dict] = None):
+    """knn_local() for the DynamicEdgeConv call shape: (nbr, dist, loc, pq) with pq = (P, Q, sliced) -- the node-level
+    dense layer of node_linear_split(x, W, b, sliced), computed by trailing workgroups of the build's filter launch --
+    or pq = None when this build took a path that cannot carry it (the caller then runs node_linear_split)."""
+    out = _knn(x, ptr, k, stats, True, dense=(W, b, sliced))
+    return out if len(out) == 4 else (*out, None)
 
 
 def knn_local(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict] = None

@@ -27,7 +27,7 @@ def _check_x(x: torch.Tensor) -> torch.Tensor:
 
 
 def knn_table(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loop: bool = True,
-              num_events: Optional[int] = None) -> NeighborTable:
+              num_events: Optional[int] = None, dense=None) -> NeighborTable:
     """Fixed-width neighbour table for `x` (row i = the message sources of node i).  loop=False searches k+1
     and blanks j == i, exactly like upstream's `row != col` mask (a node whose k+1 nearest do not include itself,
     possible only with >= k+1 duplicates at lower index, keeps all k+1)."""
@@ -39,8 +39,14 @@ def knn_table(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loo
         raise ValueError(f"k={k} (searching {kk}) exceeds the supported maximum {MAX_K}")
     info = batch_info(batch, x.shape[0], x.device, num_events)
     # the LDS gather kernel reads the table as event-local uint16 ids when the kNN kernels wrote them alongside
+    # dense = (W, b, sliced_of(max_nodes)): DynamicEdgeConv asks the build to carry the node-level dense layer of its
+    # fused form (table.pq = (P, Q, sliced), or None when the build could not)
     loc = None
-    if loop and kk in (8, 16, 32):
+    pq = None
+    if loop and kk in (8, 16, 32) and dense is not None and x.shape[1] == 32:
+        W, b, sliced_of = dense
+        nbr, dist, loc, pq = _native.knn_local_dense(x, info.ptr, kk, W, b, bool(sliced_of(info.max_nodes)))
+    elif loop and kk in (8, 16, 32):
         nbr, dist, loc = _native.knn_local(x, info.ptr, kk)
     else:
         nbr, dist = _native.knn(x, info.ptr, kk)
@@ -50,7 +56,9 @@ def knn_table(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loo
     if not loop:
         self_id = torch.arange(x.shape[0], dtype=torch.int32, device=x.device).view(-1, 1)
         nbr = torch.where(nbr == self_id, torch.full_like(nbr, -1), nbr)
-    return NeighborTable(nbr, info.ptr, dense=dense, dist=dist, max_nodes=info.max_nodes, nbr_local=loc)
+    table = NeighborTable(nbr, info.ptr, dense=dense, dist=dist, max_nodes=info.max_nodes, nbr_local=loc)
+    table.pq = pq
+    return table
 
 
 def knn_graph(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loop: bool = False,

@@ -58,6 +58,8 @@ EDGECONV_FORM = os.environ.get("DMET_EDGECONV_FORM", "split")
 # 160 KB LDS / 32 B per node, minus the -inf row: events up to this size gather from the LDS image.  A batch that also
 # holds larger events gathers from L2 as a whole (faster than the per-event mix, see _EdgeConvLinearMax.forward).
 _LDS_MAX_EVENT_NODES = int(os.environ.get("DMET_LDS_MAX_NODES", "5119"))
+# the node-level dense layer of a DynamicEdgeConv rides in the kNN build's filter launch (dmet_knn_local_dense_f32)
+KNN_RIDER = os.environ.get("DMET_KNN_RIDER", "1")
 
 
 def _lds_eligible(x, weight, table: NeighborTable, any_size: bool = False) -> bool:
@@ -111,7 +113,12 @@ class _EdgeConvLinearMax(torch.autograd.Function):
                      and os.environ.get("DMET_GATHER_MIXED", "0") == "1")
             # the LDS-resident gather reads P / Q slice by slice: have the dense layer write them slice-major
             sliced = lds and _native.GATHER_MAX_FORM != "l2-only" and os.environ.get("DMET_PQ_SLICED", "1") != "0"
-            P, Q = _native.node_linear_split(x, weight, bias, sliced=sliced)
+            pq = table.pq
+            table.pq = None   # one consumer: the tables must not outlive this forward inside a cached graph
+            if pq is not None and pq[2] == bool(sliced) and pq[0].shape[-2 if sliced else 0] == x.shape[0]:
+                P, Q = pq[0], pq[1]   # the kNN build of this x carried the dense layer (dmet_knn_local_dense_f32)
+            else:
+                P, Q = _native.node_linear_split(x, weight, bias, sliced=sliced)
             out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad, lds=lds,
                                           nbr_local=table.nbr_local, sliced=sliced, mixed=mixed)
         if need_grad:
@@ -401,15 +408,31 @@ class DynamicEdgeConv(EdgeConv):
             raise ValueError("Static graphs not supported in DynamicEdgeConv")  # upstream's message
         if x.dtype != torch.float32:
             raise TypeError(f"x must be float32, got {x.dtype}")
-        table = knn_table(x, self.k, batch, loop=True)
+        table = knn_table(x, self.k, batch, loop=True, dense=self._dense_request(x))
         return self._forward_table(x, table)
 
     def forward_with_residual_input(self, x: torch.Tensor, batch: Optional[torch.Tensor] = None):
         """EdgeConv.forward_with_residual_input for the dynamic graph: (conv(x), x')."""
         if x.dim() != 2 or x.dtype != torch.float32:
             return self.forward(x, batch), x
-        table = knn_table(x, self.k, batch, loop=True)
+        table = knn_table(x, self.k, batch, loop=True, dense=self._dense_request(x))
         return self._forward_table(x, table, passthrough=True)
+
+    def _dense_request(self, x: torch.Tensor):
+        """(W, b, sliced_of(max_nodes)) when this layer runs the fused fp32 form on 32 -> 32 features: the graph build
+        then carries the node-level dense layer in its filter launch (DMET_KNN_RIDER=0: its own launch, as before)."""
+        if KNN_RIDER == "0" or self.aggr != "max" or EDGECONV_FORM != "split" or x.shape[1] != 32 or not x.is_cuda:
+            return None
+        lin = _as_fusable_linear(self.nn)
+        if lin is None or lin.in_features != 64 or lin.out_features != 32 or self.k not in (8, 16, 32):
+            return None
+        if self._wants_bf16():
+            return None
+
+        def sliced_of(max_nodes):
+            return (max_nodes is not None and max_nodes <= _LDS_MAX_EVENT_NODES and _native.GATHER_MAX_FORM != "l2-only"
+                    and os.environ.get("DMET_PQ_SLICED", "1") != "0")
+        return lin.weight, lin.bias, sliced_of
 
     def __repr__(self) -> str:
         return f"{self.__class__.__name__}(nn={self.nn}, k={self.k})"

@@ -14,6 +14,7 @@
 #include <hip/hip_bf16.h>
 
 #include "common.h"
+#include "nls_body.h"
 
 namespace dmet {
 namespace {
@@ -21,113 +22,20 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------------------
-// node_linear_split: one wavefront computes [32 nodes] x [HOUT] for both P and Q with 32x32x2 fp32 MFMAs.
-// MFMA operand maps (32x32x2): lane l holds A[row l&31][k l>>5], B[k l>>5][col l&31];
-// C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
-// k-step s, half h  <->  input feature f = s + (HIN/2)*h, so a lane reads HIN/2 CONTIGUOUS floats of its node row.
+// node_linear_split: the node-level dense layer; the wavefront-level body lives in nls_body.h (shared with the kNN
+// filter launch, whose trailing workgroups can run it behind the graph build: dmet_knn_local_dense_f32).
 // ---------------------------------------------------------------------------------------------------------
-// SLICED: P and Q are written slice-major, [HOUT/8][N][8] (the 8-channel slice of every node contiguous), which is how
-// gather_max_lds_kernel's (event, slice) workgroups read them: their LDS staging and P reads become contiguous
-// streams instead of 32-byte pieces of 128-byte rows.
 template <int HIN, int HOUT, bool SLICED = false>
 __global__ __launch_bounds__(256) void node_linear_split_kernel(const float *__restrict__ x, int64_t N,
                                                                  const float *__restrict__ W,
                                                                  const float *__restrict__ bias,
                                                                  float *__restrict__ P, float *__restrict__ Q)
 {
-    constexpr int KS = HIN / 2;     // k-steps
-    constexpr int JT = HOUT / 32;   // output column tiles
-    constexpr int TP = 36;          // LDS row stride of the transposition tiles (SLICED only)
-    __shared__ __attribute__((aligned(16))) float tpose[SLICED ? 4 : 1][SLICED ? 2 : 1][SLICED ? 32 * TP : 1];
-    const int lane = threadIdx.x & 63;
-    const int r = lane & 31, h = lane >> 5;
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) float tpose[SLICED ? 4 : 1][SLICED ? kNlsLdsFloats : 1];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t ntiles = (N + 31) / 32;
-
-    // B operands: column j = jt*32 + r of (W1-W2)^T and W2^T for feature f = s + KS*h
-    float wd[JT][KS], w2[JT][KS], bj[JT];
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt) {
-        const float *wrow = W + (int64_t)(jt * 32 + r) * (2 * HIN);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const float a = wrow[s + KS * h];
-            const float b2 = wrow[HIN + s + KS * h];
-            wd[jt][s] = a - b2;
-            w2[jt][s] = b2;
-        }
-        bj[jt] = bias ? bias[jt * 32 + r] : 0.0f;
-    }
-
-    // the rows of the NEXT tile are loaded while the matrix products of the current one run (second session of round 2:
-    // load / wait / 32 MFMAs / store left the matrix pipe 24 % busy with 43 % of the wave cycles in s_waitcnt)
-    float4 nxt[KS / 4];
-    auto fetch = [&](const int64_t tile) __attribute__((always_inline)) {
-        const int64_t node = tile * 32 + r;
-        const int64_t nload = node < N ? node : N - 1;
-        const float4 *src = reinterpret_cast<const float4 *>(x + nload * HIN + KS * h);
-#pragma unroll
-        for (int s = 0; s < KS / 4; ++s) nxt[s] = src[s];
-    };
-    if (wave < ntiles) fetch(wave);
-    for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
-        float a[KS];
-#pragma unroll
-        for (int s = 0; s < KS; s += 4) {
-            const float4 v = nxt[s / 4];
-            a[s] = v.x; a[s + 1] = v.y; a[s + 2] = v.z; a[s + 3] = v.w;
-        }
-        if (tile + nwaves < ntiles) fetch(tile + nwaves);
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            f32x16 accP, accQ;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { accP[e] = bj[jt]; accQ[e] = 0.0f; }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                accP = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wd[jt][s], accP, 0, 0, 0);
-                accQ = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], w2[jt][s], accQ, 0, 0, 0);
-            }
-            if constexpr (SLICED) {
-                // slice-major rows are 32 bytes: go through LDS so that a lane stores 16 bytes and the 16 lanes of a
-                // slice cover 8 consecutive nodes (256 contiguous bytes) instead of 32-byte pieces per store
-                float *tP = tpose[threadIdx.x >> 6][0], *tQ = tpose[threadIdx.x >> 6][1];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                    tP[row * TP + r] = accP[e];
-                    tQ[row * TP + r] = accQ[e];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int sl = lane >> 4, idx = lane & 15;
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int row = p * 8 + (idx >> 1);
-                    const int64_t n = tile * 32 + row;
-                    if (n < N) {
-                        const int64_t at = ((int64_t)(jt * 4 + sl) * N + n) * 8 + (idx & 1) * 4;
-                        *reinterpret_cast<float4 *>(P + at) = *reinterpret_cast<const float4 *>(&tP[row * TP + sl * 8 + (idx & 1) * 4]);
-                        *reinterpret_cast<float4 *>(Q + at) = *reinterpret_cast<const float4 *>(&tQ[row * TP + sl * 8 + (idx & 1) * 4]);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const int64_t n = tile * 32 + row;
-                    if (n < N) {
-                        P[n * HOUT + jt * 32 + r] = accP[e];
-                        Q[n * HOUT + jt * 32 + r] = accQ[e];
-                    }
-                }
-            }
-        }
-    }
+    node_linear_split_wave<HIN, HOUT, SLICED>(x, N, W, bias, P, Q, tpose[SLICED ? wv : 0], wave, nwaves, threadIdx.x & 63);
 }
 
 // ---------------------------------------------------------------------------------------------------------

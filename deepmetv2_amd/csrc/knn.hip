@@ -35,6 +35,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "nls_body.h"
 
 namespace dmet {
 namespace {
@@ -799,7 +800,34 @@ struct KnnFilterArgs {
     int xtile_queries;
     int form2;                  // 1: events of kF2MinNodes..kF2MaxNodes nodes are swept by the second form
     float slack_scale;          // certificate slack relative to the 32-feature bound (1.5 at 64 features)
+    // rider (dmet_knn_local_dense_f32): workgroups first_rider .. gridDim.x - 1 of the filter launch compute the
+    // node-level dense layer of the EdgeConv that consumes this graph (nls_body.h; 32 -> 32 features), rP == nullptr: none
+    const float *rW, *rb;
+    float *rP, *rQ;
+    int r_sliced;
+    int first_rider;
 };
+
+// The dense layer a build may carry (set by dmet_knn_local_dense_f32 around its call of the build on this thread).
+struct KnnRider {
+    const float *W = nullptr, *b = nullptr;
+    float *P = nullptr, *Q = nullptr;
+    int sliced = 0;
+    bool done = false;
+};
+thread_local KnnRider g_rider;
+// rider workgroups per launch (DMET_KNN_RIDER_GROUPS: experiments; 128..1024 measured within 1 % of each other at
+// 64 x 4500 nodes: the last round leaves ~1150 of the 2048 wavefront slots empty)
+inline int rider_groups()
+{
+    static int cached = 0;
+    if (cached == 0) {
+        const char *e = getenv("DMET_KNN_RIDER_GROUPS");
+        const int v = e ? atoi(e) : 0;
+        cached = (v >= 1 && v <= 4096) ? v : 512;
+    }
+    return cached;
+}
 
 // A query whose result is not certified: counted per exact-kernel tile (dense tiles go to the exact tile kernel) and
 // appended to the list the per-query fallback walks.  Every query is flagged at most once per call.
@@ -2013,6 +2041,19 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter12_kernel
         FilterQueue<filter_queue_len(filter_list_len(KP))> f1;
     };
     __shared__ WaveLds sh_all[kWavesPerGroup];
+    if constexpr (NH == 1) {
+        // rider workgroups (behind every filter workgroup of the grid: dispatched last, into the slots of the last round)
+        if (a.rP != nullptr && (int)blockIdx.x >= a.first_rider) {
+            static_assert(sizeof(WaveLds) >= sizeof(float) * kNlsLdsFloats, "a wavefront's LDS holds the transposition tiles");
+            const int rwv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            const int64_t wave = (int64_t)((int)blockIdx.x - a.first_rider) * kWavesPerGroup + rwv;
+            const int64_t nwaves = (int64_t)((int)gridDim.x - a.first_rider) * kWavesPerGroup;
+            float *tp = reinterpret_cast<float *>(&sh_all[rwv]);
+            if (a.r_sliced) node_linear_split_wave<32, 32, true>(a.x, a.N, a.rW, a.rb, a.rP, a.rQ, tp, wave, nwaves, threadIdx.x & 63);
+            else node_linear_split_wave<32, 32, false>(a.x, a.N, a.rW, a.rb, a.rP, a.rQ, tp, wave, nwaves, threadIdx.x & 63);
+            return;
+        }
+    }
     // arrival tickets of the sub-sweep pairs of split tiles: 4 x 20 480 bytes fill half the CU's LDS exactly, so they
     // live in the last two padding floats of wavefront 0's row staging area (bytes 20 472..20 479 of its block), which
     // neither the staging (features 0..15 of a row) nor the first form's queue (at most 19 968 bytes) ever touches;
@@ -2280,7 +2321,15 @@ int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, cons
     const int64_t ftiles_max = (f.N + kFQ - 1) / kFQ + f.B;
     const int64_t fblocks = (ftiles_max + slots + kWavesPerGroup - 1) / kWavesPerGroup;
     if (f.form2) {
-        hipLaunchKernelGGL((knn_filter12_kernel<KF, NH>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
+        KnnFilterArgs fr = f;
+        int64_t grid = fblocks;
+        if (NH == 1 && g_rider.P != nullptr && !g_rider.done) {
+            fr.rW = g_rider.W; fr.rb = g_rider.b; fr.rP = g_rider.P; fr.rQ = g_rider.Q; fr.r_sliced = g_rider.sliced;
+            fr.first_rider = (int)fblocks;
+            grid = fblocks + rider_groups();
+            g_rider.done = true;
+        }
+        hipLaunchKernelGGL((knn_filter12_kernel<KF, NH>), dim3((unsigned)grid), dim3(kWave * kWavesPerGroup), 0, st, fr);
         DMET_LAUNCH_CHECK("knn_filter12_kernel");
     } else {
         if constexpr (NH == 1) hipLaunchKernelGGL((knn_filter_kernel<KF>), dim3((unsigned)fblocks), dim3(kWave * kWavesPerGroup), 0, st, f);
@@ -2328,7 +2377,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     if (use_filter) {
         KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.rec, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
                         w.psd, w.psj, nbr, dist, nbr16, w.flags, w.any, w.qflag, w.qlist, w.tile_ptr, QT, filter_form2(),
-                        NH == 1 ? 1.0f : 1.5f};
+                        NH == 1 ? 1.0f : 1.5f, nullptr, nullptr, nullptr, nullptr, 0, 0};
         int rc = 0;
         if constexpr (DP == 32 || DP == 64) {
             if constexpr (KP == 8) rc = launch_filter<8, NH>(f, w, simds, px, pf, st);
@@ -2726,6 +2775,26 @@ extern "C" int dmet_knn_local_f32(const float *x, const int64_t *ptr, int B, int
     if (D <= 16) return dispatch_k<16>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
     if (D <= 32) return dispatch_k<32>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
     return dispatch_k<64>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
+}
+
+extern "C" int dmet_knn_local_dense_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,
+                                        float *dist, uint16_t *nbr16, const float *W, const float *bias, int sliced,
+                                        float *P, float *Q, int *dense_done, void *ws, size_t ws_bytes,
+                                        dmet_stream_t stream)
+{
+    DMET_REQUIRE(dense_done, "dmet_knn_local_dense_f32: dense_done is null");
+    *dense_done = 0;
+    DMET_REQUIRE(W && P && Q, "dmet_knn_local_dense_f32: null pointer");
+    DMET_REQUIRE(aligned16(P) && aligned16(Q), "dmet_knn_local_dense_f32: P / Q must be 16-byte aligned");
+    // the dense layer rides in the matrix-core filter launch (32 features); any other build leaves it to the caller
+    g_rider = KnnRider{};
+    if (D == 32 && N > 0 && B > 0 && aligned16(x)) {
+        g_rider.W = W; g_rider.b = bias; g_rider.P = P; g_rider.Q = Q; g_rider.sliced = sliced;
+    }
+    const int rc = dmet_knn_local_f32(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, ws_bytes, stream);
+    *dense_done = (rc == 0 && g_rider.done) ? 1 : 0;
+    g_rider = KnnRider{};
+    return rc;
 }
 
 extern "C" int dmet_knn_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,

@@ -163,6 +163,7 @@ class NeighborTable:
                  nbr_local: Optional[torch.Tensor] = None, nonempty: bool = False,
                  rows16: Optional[torch.Tensor] = None):
         self.nbr = nbr
+        self.pq = None              # (P, Q, sliced) of the consuming EdgeConv's dense layer when the kNN build carried it
         self.rows16 = rows16        # counted tables: the rows again as event-local uint16 ids (_native.radius(local=True))
         self.nonempty = nonempty    # True: every row holds at least one entry (tables built with self loops)
         self._order = None

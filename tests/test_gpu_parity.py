@@ -1129,3 +1129,44 @@ def test_counted_gather_winner_ids_and_ordered_rows(dev):
     gq0 = _native.gather_max_bwd_lds(gout, arg8, t.nbr, t.ptr)
     gq1 = _native.gather_max_bwd_j16(gout, argj, t.ptr)
     assert torch.equal(gq0, gq1)           # integer LDS sums: bitwise, whatever the order of the atomics
+
+
+@pytest.mark.parametrize("sizes,k,sliced", [([4500, 4500, 300, 2100], 16, True), ([4500, 77, 0, 2500], 16, False),
+                                             ([50, 450, 800], 16, True), ([3000, 1], 8, True), ([2200, 2300], 20, False)])
+def test_knn_build_carries_the_dense_layer(dev, sizes, k, sliced):
+    """dmet_knn_local_dense_f32: the node-level dense layer computed by trailing workgroups of the filter launch has the
+    bits of dmet_node_linear_split_(sliced_)f32, and the graph is the one of dmet_knn_local_f32 (= the oracle's)."""
+    from deepmetv2_amd import _native
+    from oracle import ref_ops
+    x, batch, ptr = _ragged(sizes, 32, 77)
+    g = torch.Generator().manual_seed(5)
+    W = torch.randn(32, 64, generator=g) * 0.2
+    b = torch.randn(32, generator=g)
+    xd, pd, Wd, bd = x.to(dev), ptr.to(dev), W.to(dev), b.to(dev)
+    for bias in (bd, None):
+        nbr, dist, loc, pq = _native.knn_local_dense(xd, pd, k, Wd, bias, sliced)
+        assert pq is not None, "a 32-feature build with k <= 20 takes the matrix-core path and carries the dense layer"
+        P_ref, Q_ref = _native.node_linear_split(xd, Wd, bias, sliced=sliced)
+        assert pq[2] == sliced and torch.equal(pq[0], P_ref) and torch.equal(pq[1], Q_ref)
+        nbr0, dist0, loc0 = _native.knn_local(xd, pd, k)
+        assert torch.equal(nbr, nbr0) and torch.equal(dist, dist0) and torch.equal(loc, loc0)
+    nbr_ref, _ = ref_ops.knn_table(x, ptr, k)
+    assert torch.equal(nbr.cpu(), nbr_ref)
+
+
+def test_knn_build_without_matrix_core_path_leaves_the_dense_layer(dev, monkeypatch):
+    """Builds that cannot carry the dense layer say so (pq None) and DynamicEdgeConv launches it itself: same output."""
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import _native, conv
+    x, batch, ptr = _ragged([300, 500], 32, 3)
+    xd, pd = x.to(dev), ptr.to(dev)
+    W = torch.randn(32, 64, device=dev)
+    assert _native.knn_local_dense(xd, pd, 32, W, None, False)[3] is None        # k > 20: exact kernel
+    x16 = torch.randn(800, 16, device=dev)
+    assert _native._knn(x16, pd, 16, None, True, dense=(W, None, False))[3] is None   # 16 features
+    torch.manual_seed(0)
+    layer = dm.DynamicEdgeConv(torch.nn.Linear(64, 32), k=16).to(dev)
+    out1 = layer(xd, batch.to(dev))
+    monkeypatch.setattr(conv, "KNN_RIDER", "0")
+    out0 = layer(xd, batch.to(dev))
+    assert torch.equal(out0, out1)
