@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--hip-graph", action="store_true",
                     help="replay the step as two hipGraphs around the gradient all-reduce (launch-bound small batches; "
                          "per-kernel HIP-event timing, hence the roofline block, is not available in this mode)")
+    ap.add_argument("--optimizer", choices=["dmet", "torch"], default="dmet",
+                    help="AdamW as one HIP launch on the flat parameter tensor (default) or torch.optim.AdamW(fused=True)")
     ap.add_argument("--input", choices=["device", "host"], default="device",
                     help="device: the batch is resident in HBM when the timed region starts (the metric's definition); "
                          "host: every step takes its batch from pinned host memory through deepmetv2_amd.DeviceLoader "
@@ -344,8 +346,13 @@ def main():
     flat = FlatModule(model)
     sync = GradSync(flat)
     sync.broadcast_state(0)
-    # one fused kernel for the whole (flat) parameter vector; it is also graph-capturable
-    opt = torch.optim.AdamW([flat.flat_param], lr=1e-3, fused=True, capturable=args.hip_graph)
+    # AdamW (train.py:75) on the flat parameter vector: one launch (deepmetv2_amd.optim.FlatAdamW = dmet_adamw_f32, device-side
+    # step counter: capturable); --optimizer torch: torch.optim.AdamW(fused=True), two launches, 16 us more per step
+    if args.optimizer == "torch":
+        opt = torch.optim.AdamW([flat.flat_param], lr=1e-3, fused=True, capturable=args.hip_graph)
+    else:
+        from deepmetv2_amd.optim import FlatAdamW
+        opt = FlatAdamW([flat.flat_param], lr=1e-3)
 
     if args.mode == "train":
         model.train()

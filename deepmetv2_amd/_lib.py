@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("DMET_HIP_LIB") or os.path.join(_PKG_DIR, "libdmet_hip
 _lock = threading.Lock()
 _lib = None
 
-_vp, _i, _i64, _sz, _f = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float
+_vp, _i, _i64, _sz, _f, _d = C.c_void_p, C.c_int, C.c_int64, C.c_size_t, C.c_float, C.c_double
 
 # name -> (restype, argtypes); must list every symbol declared in include/dmet.h
 SIGNATURES = {
@@ -25,6 +25,7 @@ SIGNATURES = {
     "dmet_knn_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
     "dmet_knn_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "dmet_knn_local_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dmet_adamw_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _vp]),
     "dmet_knn_local_dense_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_knn_fallback_stats": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
     "dmet_radius_f32": (_i, [_vp, _vp, _i, _i64, _i, _f, _i, _i, _vp, _vp, _vp]),

@@ -1170,3 +1170,28 @@ def test_knn_build_without_matrix_core_path_leaves_the_dense_layer(dev, monkeypa
     monkeypatch.setattr(conv, "KNN_RIDER", "0")
     out0 = layer(xd, batch.to(dev))
     assert torch.equal(out0, out1)
+
+
+@pytest.mark.parametrize("wd", [1e-2, 0.0])
+def test_flat_adamw_matches_torch_adamw(dev, wd):
+    """dmet_adamw_f32 (train.py:75's optimizer on the flat parameter tensor) against torch.optim.AdamW, 25 steps."""
+    from deepmetv2_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(6641, generator=g)
+    pa = torch.nn.Parameter(p0.clone().to(dev))
+    pb = torch.nn.Parameter(p0.clone().double())           # fp64 torch reference on the CPU
+    oa = FlatAdamW([pa], lr=1e-3, weight_decay=wd)
+    ob = torch.optim.AdamW([pb], lr=1e-3, weight_decay=wd)
+    for it in range(25):
+        gr = torch.randn(6641, generator=g) * (10.0 ** ((it % 5) - 3))
+        pa.grad = gr.to(dev)
+        pb.grad = gr.double()
+        oa.step()
+        ob.step()
+    st = oa.state[pa]
+    assert float(st["step"]) == 25.0
+    torch.testing.assert_close(pa.detach().cpu().double(), pb.detach(), rtol=2e-6, atol=2e-7)
+    # the moments are sums of terms of either sign and of magnitudes 1e-3 .. 10: fp32 rounding relative to the largest
+    m_ref, v_ref = ob.state[pb]["exp_avg"], ob.state[pb]["exp_avg_sq"]
+    torch.testing.assert_close(st["exp_avg"].cpu().double(), m_ref, rtol=1e-5, atol=1e-6 * float(m_ref.abs().max()))
+    torch.testing.assert_close(st["exp_avg_sq"].cpu().double(), v_ref, rtol=1e-5, atol=1e-6 * float(v_ref.abs().max()))
