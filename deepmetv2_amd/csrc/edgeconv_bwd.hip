@@ -25,7 +25,7 @@ constexpr int kPad = 36;                   // LDS row stride in floats (16-byte 
 constexpr int kWavesPerBlock = 4;
 constexpr int kPartial = 2 * 1024 + kH;    // per wavefront: gP^T x, gQ^T x, column sums of gP
 constexpr int kFinGroups = 33;             // finalize: 32 groups of 32 weight-tile elements + the bias
-constexpr int kFinChunks = 8;              // ... each summed over 8 contiguous ranges of wavefronts by separate workgroups
+constexpr int kFinChunks = 8;              // (workspace layout of the former two-level finalize, kept: the size query is ABI)
 
 __device__ __forceinline__ void ecb_wave_sync()
 {
@@ -38,14 +38,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd
     const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ g_out,
     const uint8_t *__restrict__ arg, const float *__restrict__ gQ, int64_t N, int64_t nodes_per_wave,
     const float *__restrict__ g_add, float *__restrict__ gx, float *__restrict__ partial,
-    int *__restrict__ fin_counters)
+    int *__restrict__ /*unused: tickets of the former two-level finalize*/)
 {
     __shared__ float sP[kWavesPerBlock][kChunk * kPad];
     __shared__ float sQ[kWavesPerBlock][kChunk * kPad];
     __shared__ float sX[kWavesPerBlock][kChunk * kPad];
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int c = lane & 31, hh = lane >> 5;
-    if (blockIdx.x == 0 && threadIdx.x < kFinGroups) fin_counters[threadIdx.x] = 0;   // tickets of the finalize kernel
     float *P = sP[wv], *Q = sQ[wv], *X = sX[wv];
     const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + wv;
     const int64_t lo = wave * nodes_per_wave, hi = min(N, lo + nodes_per_wave);
@@ -173,58 +172,39 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd
     }
 }
 
-// gW[o][0:32] = sum gP^T x,  gW[o][32:64] = sum gQ^T x - sum gP^T x,  gb[o] = sum gP.  Partials are added in a fixed
-// order: the wavefronts are cut into kFinChunks contiguous ranges; inside a range 32 thread groups each take every
-// 32nd wavefront and the 32 group sums are added in order; the workgroup that finishes LAST for an element group
-// (ticket counter) adds the kFinChunks range sums in order.  Which workgroup that is varies, the sum order does not.
-// Workgroup (cg, q): element group cg (0..31: 32 elements of both weight tiles; 32: the bias), range q.
+// gW[o][0:32] = sum gP^T x,  gW[o][32:64] = sum gQ^T x - sum gP^T x,  gb[o] = sum gP.  Partials (one per workgroup of the
+// kernel above: 512 at 288 000 nodes) are added in a fixed order in ONE pass: workgroup cg owns 32 elements of both
+// weight tiles (cg = 32: the bias); its 32 thread groups each take every 32nd partial (all loads of a thread in
+// flight at once), the 32 group sums are added in order.  (Until the third session of round 2 the partials were cut
+// into 8 ranges over 8 x 33 workgroups and the last one to finish -- a ticket -- added the range sums: a chain of four
+// dependent device-scope round trips of ~1.6 us each, 10.7 us; with one partial per WORKGROUP there are few enough for
+// one level.)
 __global__ __launch_bounds__(1024) void edgeconv_linear_bwd_finalize_kernel(const float *__restrict__ partial,
-                                                                             int64_t nwaves, float *chunk_sums,
-                                                                             int *fin_counters,
-                                                                             float *__restrict__ gW,
+                                                                             int64_t nparts, float *__restrict__ gW,
                                                                              float *__restrict__ gb)
 {
     __shared__ float red0[32][33], red1[32][33];
-    __shared__ int ticket;
-    const int cg = blockIdx.x / kFinChunks, q = blockIdx.x % kFinChunks;
+    const int cg = blockIdx.x;
     const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const bool bias = cg == 32;
     const int idx = bias ? (2048 + e) : (cg * 32 + e);
-    const int64_t per = (nwaves + kFinChunks - 1) / kFinChunks;
-    const int64_t w0 = q * per, w1 = min(nwaves, w0 + per);
     float s0 = 0.0f, s1 = 0.0f;
     if (bias) {
-#pragma unroll 8   // independent loads: keep eight in flight (the sum order is unchanged)
-        for (int64_t w = w0 + grp; w < w1; w += 32) s0 += partial[w * kPartial + idx];
+#pragma unroll 16   // independent loads: all in flight (the sum order is unchanged)
+        for (int64_t w = grp; w < nparts; w += 32) s0 += partial[w * kPartial + idx];
     } else {
-#pragma unroll 8
-        for (int64_t w = w0 + grp; w < w1; w += 32) {
+#pragma unroll 16
+        for (int64_t w = grp; w < nparts; w += 32) {
             s0 += partial[w * kPartial + idx];
             s1 += partial[w * kPartial + 1024 + idx];
         }
     }
     red0[grp][e] = s0; red1[grp][e] = s1;
     __syncthreads();
-    if (grp == 0) {
-        s0 = 0.0f; s1 = 0.0f;
-#pragma unroll
-        for (int g = 0; g < 32; ++g) { s0 += red0[g][e]; s1 += red1[g][e]; }
-        chunk_sums[q * kPartial + idx] = s0;
-        if (!bias) chunk_sums[q * kPartial + 1024 + idx] = s1;
-        __threadfence();
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) ticket = atomicAdd(&fin_counters[cg], 1);
-    __syncthreads();
-    if (ticket != kFinChunks - 1 || grp != 0) return;
-    __threadfence();
+    if (grp != 0) return;
     s0 = 0.0f; s1 = 0.0f;
 #pragma unroll
-    for (int qq = 0; qq < kFinChunks; ++qq) {
-        s0 += __hip_atomic_load(&chunk_sums[qq * kPartial + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!bias)
-            s1 += __hip_atomic_load(&chunk_sums[qq * kPartial + 1024 + idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    for (int g = 0; g < 32; ++g) { s0 += red0[g][e]; s1 += red1[g][e]; }
     if (bias) {
         if (gb) gb[e] = s0;
     } else {
@@ -420,8 +400,8 @@ extern "C" int dmet_edgeconv_linear_bwd_add_f32(const float *x, const float *W, 
     hipLaunchKernelGGL(edgeconv_linear_bwd_kernel, dim3((unsigned)(nw / kWavesPerBlock)), dim3(kWave * kWavesPerBlock), 0, st,
                        x, W, g_out, arg, gQ, N, npw, g_add, gx, partial, fin_counters);
     DMET_LAUNCH_CHECK("edgeconv_linear_bwd_kernel");
-    hipLaunchKernelGGL(edgeconv_linear_bwd_finalize_kernel, dim3(kFinGroups * kFinChunks), dim3(1024), 0, st, partial,
-                       nw / kWavesPerBlock, chunk_sums, fin_counters, gW, gb);
+    hipLaunchKernelGGL(edgeconv_linear_bwd_finalize_kernel, dim3(kFinGroups), dim3(1024), 0, st, partial, nw / kWavesPerBlock,
+                       gW, gb);
     DMET_LAUNCH_CHECK("edgeconv_linear_bwd_finalize_kernel");
     return 0;
 }
