@@ -148,18 +148,25 @@ def _knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict], want
                                             _stream(dev)), "dmet_knn_local_f32")
         else:
             import ctypes
-            W, b, sliced = dense
+            W, b, sliced = dense            # sliced: False / True, or "bf16" (P fp32, Q bf16: node_linear_split_bf16)
             W = _f32c(W.detach(), "W")
             bp = _f32c(b.detach(), "b").data_ptr() if b is not None else None
-            PQ = torch.empty((2, 4, N, 8) if sliced else (2, N, 32), dtype=torch.float32, device=dev)
+            if sliced == "bf16":
+                Pt = torch.empty((N, 32), dtype=torch.float32, device=dev)
+                Qt = torch.empty((N, 32), dtype=torch.bfloat16, device=dev)
+                layout = 2
+            else:
+                PQ = torch.empty((2, 4, N, 8) if sliced else (2, N, 32), dtype=torch.float32, device=dev)
+                Pt, Qt = PQ[0], PQ[1]
+                layout, sliced = (1 if sliced else 0), bool(sliced)
             done = ctypes.c_int(0)
             _lib.check(L.dmet_knn_local_dense_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, k, nbr.data_ptr(),
                                                   dist.data_ptr(), loc.data_ptr() if want_local else None,
-                                                  W.data_ptr(), bp, 1 if sliced else 0, PQ[0].data_ptr(),
-                                                  PQ[1].data_ptr(), ctypes.cast(ctypes.pointer(done), ctypes.c_void_p),
+                                                  W.data_ptr(), bp, layout, Pt.data_ptr(),
+                                                  Qt.data_ptr(), ctypes.cast(ctypes.pointer(done), ctypes.c_void_p),
                                                   ws.data_ptr(), ws.numel(), _stream(dev)), "dmet_knn_local_dense_f32")
             if done.value:
-                pq = (PQ[0], PQ[1], bool(sliced))
+                pq = (Pt, Qt, sliced)
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))
     if stats is not None and N > 0 and B > 0:
@@ -184,10 +191,11 @@ def knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict] = None
 
 
 def knn_local_dense(x: torch.Tensor, ptr: torch.Tensor, k: int, W: torch.Tensor, b: Optional[torch.Tensor],
-                    sliced: bool, stats: Optional[dict] = None):
+                    sliced, stats: Optional[dict] = None):
     """knn_local() for the DynamicEdgeConv call shape: (nbr, dist, loc, pq) with pq = (P, Q, sliced) -- the node-level
-    dense layer of node_linear_split(x, W, b, sliced), computed by trailing workgroups of the build's filter launch --
-    or pq = None when this build took a path that cannot carry it (the caller then runs node_linear_split)."""
+    dense layer of node_linear_split(x, W, b, sliced) (sliced = "bf16": of node_linear_split_bf16(x, W, b)), computed by
+    trailing workgroups of the build's filter launch -- or pq = None when this build took a path that cannot carry it
+    (the caller then runs the dense layer itself)."""
     out = _knn(x, ptr, k, stats, True, dense=(W, b, sliced))
     return out if len(out) == 4 else (*out, None)
 

@@ -45,7 +45,7 @@ def knn_table(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loo
     pq = None
     if loop and kk in (8, 16, 32) and dense is not None and x.shape[1] == 32:
         W, b, sliced_of = dense
-        nbr, dist, loc, pq = _native.knn_local_dense(x, info.ptr, kk, W, b, bool(sliced_of(info.max_nodes)))
+        nbr, dist, loc, pq = _native.knn_local_dense(x, info.ptr, kk, W, b, sliced_of(info.max_nodes))
     elif loop and kk in (8, 16, 32):
         nbr, dist, loc = _native.knn_local(x, info.ptr, kk)
     else:

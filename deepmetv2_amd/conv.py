@@ -79,7 +79,12 @@ class _EdgeConvLinearMax(torch.autograd.Function):
         if bf16:
             # BASELINE configs[2]: dense layer on the bf16 matrix cores, bf16 Q table (half the gathered bytes);
             # max / add / backward stay fp32 (straight-through over the bf16 roundings)
-            P, Qh = _native.node_linear_split_bf16(x, weight, bias)
+            pq = table.pq
+            table.pq = None
+            if pq is not None and pq[2] == "bf16" and pq[0].shape[0] == x.shape[0]:
+                P, Qh = pq[0], pq[1]   # carried by the kNN build of this x (dmet_knn_local_dense_f32, layout 2)
+            else:
+                P, Qh = _native.node_linear_split_bf16(x, weight, bias)
             out, arg = _native.gather_max_bf16q(P, Qh, table.nbr, want_arg=need_grad)
         elif table.cnt is not None:
             lds = (x.shape[1] == 32 and weight.shape[0] == 32 and table.ptr is not None
@@ -115,7 +120,7 @@ class _EdgeConvLinearMax(torch.autograd.Function):
             sliced = lds and _native.GATHER_MAX_FORM != "l2-only" and os.environ.get("DMET_PQ_SLICED", "1") != "0"
             pq = table.pq
             table.pq = None   # one consumer: the tables must not outlive this forward inside a cached graph
-            if pq is not None and pq[2] == bool(sliced) and pq[0].shape[-2 if sliced else 0] == x.shape[0]:
+            if pq is not None and pq[2] is bool(sliced) and pq[0].shape[-2 if sliced else 0] == x.shape[0]:
                 P, Q = pq[0], pq[1]   # the kNN build of this x carried the dense layer (dmet_knn_local_dense_f32)
             else:
                 P, Q = _native.node_linear_split(x, weight, bias, sliced=sliced)
@@ -426,12 +431,13 @@ class DynamicEdgeConv(EdgeConv):
         lin = _as_fusable_linear(self.nn)
         if lin is None or lin.in_features != 64 or lin.out_features != 32 or self.k not in (8, 16, 32):
             return None
-        if self._wants_bf16():
-            return None
+        bf16 = self._wants_bf16()
 
         def sliced_of(max_nodes):
-            return (max_nodes is not None and max_nodes <= _LDS_MAX_EVENT_NODES and _native.GATHER_MAX_FORM != "l2-only"
-                    and os.environ.get("DMET_PQ_SLICED", "1") != "0")
+            if bf16:
+                return "bf16"
+            return bool(max_nodes is not None and max_nodes <= _LDS_MAX_EVENT_NODES and _native.GATHER_MAX_FORM != "l2-only"
+                        and os.environ.get("DMET_PQ_SLICED", "1") != "0")
         return lin.weight, lin.bias, sliced_of
 
     def __repr__(self) -> str:

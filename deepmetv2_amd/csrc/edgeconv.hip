@@ -44,16 +44,6 @@ __global__ __launch_bounds__(256) void node_linear_split_kernel(const float *__r
 // node's own row, read once), Q is STORED as bf16 because it is the table that is gathered k times per node.
 // Operand maps (32x32x16): lane l (r = l&31, h = l>>5) holds A[row r][k = 8h+j], B[k = 8h+j][col r], j = 0..7.
 // ---------------------------------------------------------------------------------------------------------
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f)
-{
-    __hip_bfloat16 h = __float2bfloat16(f);
-    return *reinterpret_cast<unsigned short *>(&h);
-}
-
-__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
-
 template <int HIN, int HOUT>
 __global__ __launch_bounds__(256) void node_linear_split_bf16_kernel(const float *__restrict__ x, int64_t N,
                                                                       const float *__restrict__ W,
@@ -61,64 +51,9 @@ __global__ __launch_bounds__(256) void node_linear_split_bf16_kernel(const float
                                                                       float *__restrict__ P,
                                                                       unsigned short *__restrict__ Qh)
 {
-    constexpr int KB = HIN / 16;    // k-blocks of 16 features
-    constexpr int JT = HOUT / 32;
-    const int lane = threadIdx.x & 63;
-    const int r = lane & 31, h = lane >> 5;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    const int64_t ntiles = (N + 31) / 32;
-
-    bf16x8 wd[JT][KB], w2[JT][KB];
-    float bj[JT];
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt) {
-        const float *wrow = W + (int64_t)(jt * 32 + r) * (2 * HIN);
-#pragma unroll
-        for (int s = 0; s < KB; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float a = wrow[16 * s + 8 * h + j];
-                const float b2 = wrow[HIN + 16 * s + 8 * h + j];
-                wd[jt][s][j] = (short)f32_to_bf16_rne(a - b2);
-                w2[jt][s][j] = (short)f32_to_bf16_rne(b2);
-            }
-        bj[jt] = bias ? bias[jt * 32 + r] : 0.0f;
-    }
-    for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
-        const int64_t node = tile * 32 + r;
-        const int64_t nload = node < N ? node : N - 1;
-        bf16x8 a[KB];
-#pragma unroll
-        for (int s = 0; s < KB; ++s) {
-            const float4 *src = reinterpret_cast<const float4 *>(x + nload * HIN + 16 * s + 8 * h);
-            const float4 v0 = src[0], v1 = src[1];
-            a[s][0] = (short)f32_to_bf16_rne(v0.x); a[s][1] = (short)f32_to_bf16_rne(v0.y);
-            a[s][2] = (short)f32_to_bf16_rne(v0.z); a[s][3] = (short)f32_to_bf16_rne(v0.w);
-            a[s][4] = (short)f32_to_bf16_rne(v1.x); a[s][5] = (short)f32_to_bf16_rne(v1.y);
-            a[s][6] = (short)f32_to_bf16_rne(v1.z); a[s][7] = (short)f32_to_bf16_rne(v1.w);
-        }
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            f32x16 accP, accQ;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { accP[e] = bj[jt]; accQ[e] = 0.0f; }
-#pragma unroll
-            for (int s = 0; s < KB; ++s) {
-                accP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], wd[jt][s], accP, 0, 0, 0);
-                accQ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], w2[jt][s], accQ, 0, 0, 0);
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int64_t n = tile * 32 + row;
-                if (n < N) {
-                    P[n * HOUT + jt * 32 + r] = accP[e];
-                    Qh[n * HOUT + jt * 32 + r] = f32_to_bf16_rne(accQ[e]);
-                }
-            }
-        }
-    }
+    node_linear_split_bf16_wave<HIN, HOUT>(x, N, W, bias, P, Qh, wave, nwaves, threadIdx.x & 63);   // nls_body.h
 }
 
 // gather+max over a bf16 Q table (H = 32): 4 lanes per node, 8 channels (16 B of bf16) per lane.

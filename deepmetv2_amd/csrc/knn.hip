@@ -804,7 +804,7 @@ struct KnnFilterArgs {
     // node-level dense layer of the EdgeConv that consumes this graph (nls_body.h; 32 -> 32 features), rP == nullptr: none
     const float *rW, *rb;
     float *rP, *rQ;
-    int r_sliced;
+    int r_sliced;               // layout: 0 row-major fp32, 1 slice-major fp32, 2 row-major with Q as bf16 bits
     int first_rider;
 };
 
@@ -2049,7 +2049,10 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter12_kernel
             const int64_t wave = (int64_t)((int)blockIdx.x - a.first_rider) * kWavesPerGroup + rwv;
             const int64_t nwaves = (int64_t)((int)gridDim.x - a.first_rider) * kWavesPerGroup;
             float *tp = reinterpret_cast<float *>(&sh_all[rwv]);
-            if (a.r_sliced) node_linear_split_wave<32, 32, true>(a.x, a.N, a.rW, a.rb, a.rP, a.rQ, tp, wave, nwaves, threadIdx.x & 63);
+            if (a.r_sliced == 2)
+                node_linear_split_bf16_wave<32, 32>(a.x, a.N, a.rW, a.rb, a.rP, reinterpret_cast<unsigned short *>(a.rQ), wave,
+                                                    nwaves, threadIdx.x & 63);
+            else if (a.r_sliced == 1) node_linear_split_wave<32, 32, true>(a.x, a.N, a.rW, a.rb, a.rP, a.rQ, tp, wave, nwaves, threadIdx.x & 63);
             else node_linear_split_wave<32, 32, false>(a.x, a.N, a.rW, a.rb, a.rP, a.rQ, tp, wave, nwaves, threadIdx.x & 63);
             return;
         }
@@ -2778,18 +2781,20 @@ extern "C" int dmet_knn_local_f32(const float *x, const int64_t *ptr, int B, int
 }
 
 extern "C" int dmet_knn_local_dense_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,
-                                        float *dist, uint16_t *nbr16, const float *W, const float *bias, int sliced,
-                                        float *P, float *Q, int *dense_done, void *ws, size_t ws_bytes,
+                                        float *dist, uint16_t *nbr16, const float *W, const float *bias, int layout,
+                                        float *P, void *Q, int *dense_done, void *ws, size_t ws_bytes,
                                         dmet_stream_t stream)
 {
     DMET_REQUIRE(dense_done, "dmet_knn_local_dense_f32: dense_done is null");
     *dense_done = 0;
     DMET_REQUIRE(W && P && Q, "dmet_knn_local_dense_f32: null pointer");
+    DMET_REQUIRE(layout >= 0 && layout <= 2, "dmet_knn_local_dense_f32: layout=%d not in {0, 1, 2}", layout);
+    const int sliced = layout;
     DMET_REQUIRE(aligned16(P) && aligned16(Q), "dmet_knn_local_dense_f32: P / Q must be 16-byte aligned");
     // the dense layer rides in the matrix-core filter launch (32 features); any other build leaves it to the caller
     g_rider = KnnRider{};
     if (D == 32 && N > 0 && B > 0 && aligned16(x)) {
-        g_rider.W = W; g_rider.b = bias; g_rider.P = P; g_rider.Q = Q; g_rider.sliced = sliced;
+        g_rider.W = W; g_rider.b = bias; g_rider.P = P; g_rider.Q = reinterpret_cast<float *>(Q); g_rider.sliced = sliced;
     }
     const int rc = dmet_knn_local_f32(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, ws_bytes, stream);
     *dense_done = (rc == 0 && g_rider.done) ? 1 : 0;

@@ -60,14 +60,16 @@ int dmet_knn_local_f32(const float *x, const int64_t *ptr, int B, int64_t N, int
                        float *dist, uint16_t *nbr_local, void *ws, size_t ws_bytes, dmet_stream_t stream);
 /* dmet_knn_local_f32 for the DynamicEdgeConv call shape (model/graph_met_network.py:63: the graph is built in the
  * space of the rows the convolution then consumes): the node-level dense layer of the fused EdgeConv,
- *   P = x.(W1-W2)^T + b, Q = x.W2^T   (dmet_node_linear_split_f32 / _sliced_f32 when `sliced`; W[32,64], D = 32),
+ *   P = x.(W1-W2)^T + b, Q = x.W2^T   (W[32,64], D = 32),
  * depends on x only, like the graph, and is computed by trailing workgroups of the matrix-core filter launch: they are
- * dispatched last and fill the wavefront slots the build's last round leaves empty.  *dense_done = 1: P and Q were
- * written (same bits as dmet_node_linear_split_*); 0: this build took another path (D != 32, k > 20, the matrix-core
+ * dispatched last and fill the wavefront slots the build's last round leaves empty.  layout = 0: P, Q fp32 [N,32]
+ * (dmet_node_linear_split_f32), 1: slice-major [4][N][8] (dmet_node_linear_split_sliced_f32), 2: bf16 operands on
+ * the bf16 matrix cores, P fp32 [N,32], Q as bf16 bits [N,32] (dmet_node_linear_split_bf16).  *dense_done = 1: P and
+ * Q were written (same bits as the call named); 0: this build took another path (D != 32, k > 20, the matrix-core
  * path switched off) and the caller launches the dense layer itself.  nbr / dist / nbr_local as above. */
 int dmet_knn_local_dense_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,
-                             float *dist, uint16_t *nbr_local, const float *W, const float *bias, int sliced,
-                             float *P, float *Q, int *dense_done, void *ws, size_t ws_bytes, dmet_stream_t stream);
+                             float *dist, uint16_t *nbr_local, const float *W, const float *bias, int layout,
+                             float *P, void *Q, int *dense_done, void *ws, size_t ws_bytes, dmet_stream_t stream);
 
 /* Diagnostics of the matrix-core kNN path (D = 32 or 64, k <= 20): dmet_knn_f32 first ranks candidates with an MFMA
  * filter (fp16 operands for events of 2048..65536 nodes, a bf16 split for smaller ones), re-ranks the kept ones with

@@ -1152,6 +1152,12 @@ def test_knn_build_carries_the_dense_layer(dev, sizes, k, sliced):
         assert torch.equal(nbr, nbr0) and torch.equal(dist, dist0) and torch.equal(loc, loc0)
     nbr_ref, _ = ref_ops.knn_table(x, ptr, k)
     assert torch.equal(nbr.cpu(), nbr_ref)
+    # layout 2 (BASELINE configs[2]): bf16 operands, Q stored as bf16 -- the bits of dmet_node_linear_split_bf16
+    nbr, dist, loc, pq = _native.knn_local_dense(xd, pd, k, Wd, bd, "bf16")
+    P_ref, Qh_ref = _native.node_linear_split_bf16(xd, Wd, bd)
+    assert pq is not None and pq[2] == "bf16" and pq[1].dtype == torch.bfloat16
+    assert torch.equal(pq[0], P_ref) and torch.equal(pq[1].view(torch.int16), Qh_ref.view(torch.int16))
+    assert torch.equal(nbr.cpu(), nbr_ref)
 
 
 def test_knn_build_without_matrix_core_path_leaves_the_dense_layer(dev, monkeypatch):
