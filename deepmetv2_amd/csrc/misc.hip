@@ -119,36 +119,43 @@ inline unsigned bit_length(uint64_t v)
 }
 
 // ---- H1: the optimizer step of train.py:52,75 (torch.optim.AdamW) on ONE flat fp32 parameter tensor ----------------
-// One workgroup walks the tensor (the model has 6 641 parameters: a grid would only add a second launch for the step
-// counter).  The step count lives on the device (float, like torch's capturable state), so the launch replays
-// inside a hipGraph; thread 0 increments it and hands the bias corrections to the others through LDS.
+// One workgroup walks the tensor (the model has 6 641 parameters: a grid would need a second launch, or a grid barrier,
+// for the step state).  The step state lives on the device so that the launch replays inside a hipGraph: step[0] (float,
+// like torch's capturable state) and bias_pow[2] = beta1^t, beta2^t kept as running products in double (a double pow()
+// per launch cost 3 us of one thread's time; t multiplications lose t x 2^-53).  Thread 0 advances the state and hands the
+// bias corrections to the others through LDS while their first elements are already in flight.
 __global__ __launch_bounds__(1024) void adamw_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                      float *__restrict__ m, float *__restrict__ v,
-                                                     float *__restrict__ step, int64_t n, double lr, double beta1,
-                                                     double beta2, double eps, double weight_decay)
+                                                     float *__restrict__ step, double *__restrict__ bias_pow, int64_t n,
+                                                     double lr, double beta1, double beta2, double eps, double weight_decay)
 {
     __shared__ float sh[2];
+    int64_t i = threadIdx.x;
+    float gi = 0.f, pi = 0.f, mi = 0.f, vi = 0.f;
+    if (i < n) { gi = g[i]; pi = p[i]; mi = m[i]; vi = v[i]; }
     if (threadIdx.x == 0) {
-        const float t = step[0] + 1.0f;
-        step[0] = t;
-        // bias corrections in double (the pow of a float loses digits exactly where 1 - beta^t is small)
-        const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
-        sh[0] = (float)(lr / bc1);
-        sh[1] = (float)(1.0 / sqrt(bc2));
+        step[0] = step[0] + 1.0f;
+        const double p1 = bias_pow[0] * beta1, p2 = bias_pow[1] * beta2;
+        bias_pow[0] = p1; bias_pow[1] = p2;
+        sh[0] = (float)(lr / (1.0 - p1));
+        sh[1] = (float)(1.0 / sqrt(1.0 - p2));
     }
     __syncthreads();
     const float step_size = sh[0], inv_sqrt_bc2 = sh[1];
     // hyper-parameters arrive as doubles (python floats): 1 - beta2 formed in fp32 would be off by 5e-5 of itself
     const float decay = (float)(1.0 - lr * weight_decay), omb1 = (float)(1.0 - beta1), b2 = (float)beta2,
                 omb2 = (float)(1.0 - beta2), epsf = (float)eps;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const float gi = g[i];
-        float pi = p[i] * decay;                                   // decoupled weight decay
-        const float mi = m[i] + (gi - m[i]) * omb1;               // lerp, like torch's fused kernel
-        const float vi = b2 * v[i] + omb2 * gi * gi;
+    while (i < n) {
+        const int64_t nx = i + blockDim.x;
+        float gn = 0.f, pn = 0.f, mn = 0.f, vn = 0.f;
+        if (nx < n) { gn = g[nx]; pn = p[nx]; mn = m[nx]; vn = v[nx]; }
+        pi *= decay;                                               // decoupled weight decay
+        mi = mi + (gi - mi) * omb1;                                // lerp, like torch's fused kernel
+        vi = b2 * vi + omb2 * gi * gi;
         const float denom = sqrtf(vi) * inv_sqrt_bc2 + epsf;
         pi -= step_size * (mi / denom);
         p[i] = pi; m[i] = mi; v[i] = vi;
+        i = nx; gi = gn; pi = pn; mi = mn; vi = vn;
     }
 }
 
@@ -249,14 +256,15 @@ extern "C" int dmet_met_reduce_bwd_f32(const float *g_met, const float *x, int64
     return dmet_met_reduce_bwd_scaled_f32(g_met, nullptr, x, x_stride, ptr, B, N, g_w, stream);
 }
 
-extern "C" int dmet_adamw_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, int64_t n,
-                              double lr, double beta1, double beta2, double eps, double weight_decay, dmet_stream_t stream)
+extern "C" int dmet_adamw_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step,
+                              double *bias_pow, int64_t n, double lr, double beta1, double beta2, double eps,
+                              double weight_decay, dmet_stream_t stream)
 {
     DMET_REQUIRE(n >= 0, "dmet_adamw_f32: n=%lld", (long long)n);
     if (n == 0) return 0;
-    DMET_REQUIRE(param && grad && exp_avg && exp_avg_sq && step, "dmet_adamw_f32: null pointer");
-    hipLaunchKernelGGL(adamw_kernel, dim3(1), dim3(1024), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, step, n, lr,
-                       beta1, beta2, eps, weight_decay);
+    DMET_REQUIRE(param && grad && exp_avg && exp_avg_sq && step && bias_pow, "dmet_adamw_f32: null pointer");
+    hipLaunchKernelGGL(adamw_kernel, dim3(1), dim3(1024), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, step,
+                       bias_pow, n, lr, beta1, beta2, eps, weight_decay);
     DMET_LAUNCH_CHECK("adamw_kernel");
     return 0;
 }

@@ -2,7 +2,8 @@
 stepped at train.py:52) for the flat parameter tensor of `parallel.FlatModule`: one HIP launch per step
 (`dmet_adamw_f32`) where `torch.optim.AdamW(fused=True)` takes two (its multi-tensor kernel, 15 us for 6 641
 parameters, and the step-counter increment).  Same update rule, same hyper-parameters and defaults, same state names
-(`step`, `exp_avg`, `exp_avg_sq`); the step counter is a device float, so the step replays inside a hipGraph.
+(`step`, `exp_avg`, `exp_avg_sq`, plus `bias_pow` = beta^step as running products in double); the step state lives on
+the device, so the step replays inside a hipGraph.
 """
 from __future__ import annotations
 
@@ -43,9 +44,11 @@ class FlatAdamW(torch.optim.Optimizer):
                     st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["bias_pow"] = torch.ones(2, dtype=torch.float64, device=p.device)   # beta1^step, beta2^step
                 with _native._on(p.device):
                     _lib.check(L.dmet_adamw_f32(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
-                                                st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), p.numel(),
+                                                st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(),
+                                                st["bias_pow"].data_ptr(), p.numel(),
                                                 float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                 float(group["weight_decay"]), _native._stream(p.device)),
                                "dmet_adamw_f32")

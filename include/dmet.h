@@ -292,11 +292,13 @@ int dmet_met_reduce_f32(const float *w, const float *x, int64_t x_stride, const 
                         float *met, dmet_stream_t stream);
 int dmet_met_reduce_bwd_f32(const float *g_met, const float *x, int64_t x_stride, const int64_t *ptr,
                             int B, int64_t N, float *g_w, dmet_stream_t stream);
-/* H1: torch.optim.AdamW's step (train.py:52,75; decoupled weight decay, no amsgrad) on one flat fp32 tensor, one launch;
- * step[0] (device float, the number of steps taken so far) is incremented by the launch: replayable in a hipGraph.
+/* H1: torch.optim.AdamW's step (train.py:52,75; decoupled weight decay, no amsgrad) on one flat fp32 tensor, one launch.
+ * Device-side step state, advanced by the launch (replayable in a hipGraph): step[0] = number of steps taken (float),
+ * bias_pow[2] = beta1^step, beta2^step as running products in double (both 1.0 before the first step).
  * Hyper-parameters are doubles (python floats): 1 - beta is formed before the rounding to fp32, as torch does. */
-int dmet_adamw_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, int64_t n,
-                   double lr, double beta1, double beta2, double eps, double weight_decay, dmet_stream_t stream);
+int dmet_adamw_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, double *bias_pow,
+                   int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay,
+                   dmet_stream_t stream);
 /* loss[0] = 0.5 * mean_b((met[b,0] + truth[b,0])^2 + (met[b,1] + truth[b,1])^2)  (model/net.py:58-61) and
  * g_met[B,2] = d loss / d met, one launch, fixed summation order. */
 int dmet_met_loss_f32(const float *met, const float *truth, int B, float *loss, float *g_met, dmet_stream_t stream);
