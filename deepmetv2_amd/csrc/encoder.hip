@@ -11,6 +11,8 @@
 // the nodes in-kernel: per 64-node chunk the per-node vectors are transposed through LDS and multiplied on the
 // fp32 matrix cores, C = A^T B with K = nodes; fixed node ranges per wavefront, block partials summed in order by a
 // second kernel => bitwise reproducible, no float atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dmet {
@@ -102,6 +104,97 @@ __global__ __launch_bounds__(256, 2) void encode_fwd_kernel(const float *__restr
 #pragma unroll
     for (int c = 0; c < 8; ++c)
         o[c] = make_float4(elu(z3[4 * c]), elu(z3[4 * c + 1]), elu(z3[4 * c + 2]), elu(z3[4 * c + 3]));
+}
+
+// ---- forward on the fp32 matrix cores (third session of round 2) ---------------------------------------------------
+// encode_fwd_kernel above streams 1.5k weights per wavefront through the scalar cache: its vector ALU is 23 % busy and
+// every wavefront spends half of its life in s_waitcnt (counters in DESIGN section 4 N3).  Here the weights are MFMA
+// A operands held in registers for the whole launch, and the chain needs NO transposition between its layers:
+//   C = W . X^T with v_mfma_f32_32x32x2_f32: A = W (row = output channel), B = X^T (column = node).
+//   Lane (n = l & 31, hh = l >> 5) receives, for node n, the 16 output channels row(e) = (e & 3) + 8 (e >> 2) + 4 hh --
+//   and a B operand is exactly that: lane (n, hh) supplies, at k-step s, feature f(s, hh) of node n.  With the k-steps of
+//   the next product numbered like the accumulator registers, f(s, hh) = row(s), ELU(C) IS the next B operand.
+// Product 1 (16 MFMAs): the block-diagonal [32 x 32] matrix [[Wk 0] [0 Wc]] on the input [cat24 | x_cont] gives
+// [z2 | z1], i.e. `joint` in the reference's order (graph_met_network.py:57-58); product 2 (16 MFMAs): Wa.
+// The two lanes of a node load the halves of its table rows and of its 8 continuous features that their k-steps need.
+__global__ __launch_bounds__(256) void encode_fwd_mfma_kernel(const float *__restrict__ x, int64_t x_stride,
+                                                               const int64_t *__restrict__ xcat, int64_t N, ENC_PARAMS,
+                                                               float *__restrict__ h)
+{
+    const int lane = threadIdx.x & 63, r = lane & 31, hh = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t ntiles = (N + 31) / 32;
+    float w12[16], w3[16], b12[16], b3[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int f = (s & 3) + 8 * (s >> 2) + 4 * hh;        // feature of k-step s in this half-wave = channel of register s
+        // branch-free: one load from an address that always exists, masked afterwards (the guarded form compiled to 16
+        // divergent branches, i.e. 16 memory round trips one after the other before the first tile)
+        const float *src = r < 16 ? Wk + r * 24 + min(f, 23) : Wc + (r - 16) * 8 + max(f - 24, 0);
+        const bool keep = r < 16 ? f < 24 : f >= 24;
+        const float a = *src;
+        w12[s] = keep ? a : 0.0f;
+        w3[s] = Wa[r * 32 + f];
+        const float *bsrc = f < 16 ? bk + f : bc + (f - 16);
+        b12[s] = *bsrc;
+        b3[s] = ba[f];
+    }
+    // two-stage pipeline over the wavefront's tiles: while tile t is multiplied, the table rows of tile t + 1 (whose
+    // categorical columns arrived an iteration ago) and the raw row of tile t + 2 are in flight
+    struct Raw { float c[4]; long long k0, k1, k2; };
+    auto load_raw = [&](const int64_t tile, Raw &q) __attribute__((always_inline)) {
+        const int64_t node = tile * 32 + r;
+        const int64_t i = node < N ? node : N - 1;
+        const float *row = x + i * x_stride;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q.c[u] = row[4 * hh + u];
+        if (xcat) { q.k0 = xcat[i * 3 + 0]; q.k1 = xcat[i * 3 + 1]; q.k2 = xcat[i * 3 + 2]; }
+        else { q.k0 = (long long)row[8]; q.k1 = (long long)row[9]; q.k2 = (long long)row[10]; }
+    };
+    auto load_tables = [&](const Raw &q, float (&in)[16]) __attribute__((always_inline)) {
+        long long c = q.k0 < 0 ? -q.k0 : q.k0;    // cat_indices(): the reference's sequential remap, clamped into the tables
+        const long long table[7] = {1, 2, 11, 13, 22, 130, 211};
+#pragma unroll
+        for (int t = 0; t < 7; ++t) c = (c == table[t]) ? (long long)t : c;
+        const int ipdg = (int)min(max(c, 0ll), 6ll), ichg = (int)min(max(q.k1 + 1, 0ll), 2ll), ipv = (int)min(max(q.k2, 0ll), 7ll);
+        const float4 e0 = *reinterpret_cast<const float4 *>(Echg + ichg * 8 + 4 * hh);
+        const float4 e1 = *reinterpret_cast<const float4 *>(Epdg + ipdg * 8 + 4 * hh);
+        const float4 e2 = *reinterpret_cast<const float4 *>(Epv + ipv * 8 + 4 * hh);
+        in[0] = e0.x; in[1] = e0.y; in[2] = e0.z; in[3] = e0.w; in[4] = e1.x; in[5] = e1.y; in[6] = e1.z; in[7] = e1.w;
+        in[8] = e2.x; in[9] = e2.y; in[10] = e2.z; in[11] = e2.w;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) in[12 + u] = q.c[u];
+    };
+    Raw raw;
+    float in[16], nxt[16];
+    if (wave < ntiles) { load_raw(wave, raw); load_tables(raw, in); }
+    if (wave + nwaves < ntiles) load_raw(wave + nwaves, raw);
+    for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+        const int64_t node = tile * 32 + r;
+        if (tile + nwaves < ntiles) load_tables(raw, nxt);
+        if (tile + 2 * nwaves < ntiles) load_raw(tile + 2 * nwaves, raw);
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = b12[e];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w12[s], in[s], acc, 0, 0, 0);
+        float joint[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) joint[e] = elu(acc[e]);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = b3[e];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[s], joint[s], acc, 0, 0, 0);
+        if (node < N) {
+            float4 *o = reinterpret_cast<float4 *>(h + node * 32 + 4 * hh);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)     // channels 8 g + 4 hh .. + 3
+                o[2 * g] = make_float4(elu(acc[4 * g]), elu(acc[4 * g + 1]), elu(acc[4 * g + 2]), elu(acc[4 * g + 3]));
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) in[u] = nxt[u];
+    }
 }
 
 // ---- backward -------------------------------------------------------------------------------------------------
@@ -364,6 +457,22 @@ extern "C" int dmet_encode_fwd_f32(const float *x, int64_t x_stride, const int64
     DMET_REQUIRE(aligned16(h), "dmet_encode_fwd_f32: h must be 16-B aligned");
     const int64_t blocks = (N + 255) / 256;
     DMET_REQUIRE(blocks < (1ll << 31), "dmet_encode_fwd_f32: too many nodes");
+    static int form = -1;    // DMET_ENCODER_FWD=valu: the scalar-weight kernel (experiments, A/B)
+    if (form < 0) {
+        const char *e = getenv("DMET_ENCODER_FWD");
+        form = (e && strcmp(e, "valu") == 0) ? 0 : 1;
+    }
+    if (form == 1 && aligned16(Echg) && aligned16(Epdg) && aligned16(Epv)) {
+        const int64_t tiles = (N + 31) / 32;
+        int64_t grid = (tiles + 3) / 4;
+        static int gmax = 0;
+        if (gmax == 0) { const char *e = getenv("DMET_ENC_GRID"); gmax = e ? atoi(e) : 512; if (gmax < 1) gmax = 512; }
+        if (grid > gmax) grid = gmax;       // 2048 wavefronts (three per SIMD fit), 4-5 tiles each at 288 000 nodes: the weights are loaded once per wavefront
+        hipLaunchKernelGGL(encode_fwd_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, x_stride, xcat, N,
+                           ENC_ARGS, h);
+        DMET_LAUNCH_CHECK("encode_fwd_mfma_kernel");
+        return 0;
+    }
     hipLaunchKernelGGL(encode_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, x_stride, xcat, N, ENC_ARGS, h);
     DMET_LAUNCH_CHECK("encode_fwd_kernel");
     return 0;
