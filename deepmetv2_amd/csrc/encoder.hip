@@ -393,6 +393,239 @@ __global__ __launch_bounds__(64 * kEncBwdWaves, 2) void encode_bwd_kernel(const 
     }
 }
 
+// ---- backward with the per-node chain on the fp32 matrix cores (third session of round 2) --------------------------
+// Same outputs and partial layout as encode_bwd_kernel; the recomputed activations and the two transposed products
+// (g_joint = Wa^T g_z3, g_in = [[Wk 0] [0 Wc]]^T g_z12) run as MFMA chains in the accumulator layout of
+// encode_fwd_mfma_kernel (lane (n, hh) holds the 16 channels (e & 3) + 8 (e >> 2) + 4 hh of node n; the weights are A
+// operands in registers), 32 nodes per step; the K = nodes weight-gradient tiles still go through LDS (the operands of
+// those products are indexed the other way round).  No scalar weight stream.
+// Ordering of a wavefront's own LDS traffic WITHOUT draining its global loads: enc_wave_sync()'s wavefront-scope fences
+// compile to s_waitcnt vmcnt(0) lgkmcnt(0), so every staging step waited for the prefetched rows of the next tiles.
+// DS instructions of one wavefront complete in order; waiting for the LDS counter alone is enough.
+__device__ __forceinline__ void enc_lds_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void tile_mma32(f32x16 &acc, const float *__restrict__ A, const float *__restrict__ Bm, int lane)
+{
+    const int c = lane & 31, hh = lane >> 5;
+#pragma unroll 8
+    for (int s = 0; s < 16; ++s) {
+        const int node = 2 * s + hh;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[node * 33 + c], Bm[node * 33 + c], acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void tile_mma_onehot32(f32x16 &acc, const int *__restrict__ packed, const float *__restrict__ Bm,
+                                                  int lane)
+{
+    const int c = lane & 31, hh = lane >> 5;
+    int sh, mask, tgt;
+    if (c < 3) { sh = 0; mask = 3; tgt = c; }
+    else if (c < 10) { sh = 2; mask = 7; tgt = c - 3; }
+    else if (c < 18) { sh = 5; mask = 7; tgt = c - 10; }
+    else { sh = 0; mask = 0; tgt = 1; }
+#pragma unroll 8
+    for (int s = 0; s < 16; ++s) {
+        const int node = 2 * s + hh;
+        const float a = (((packed[node] >> sh) & mask) == tgt) ? 1.0f : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bm[node * 33 + c], acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ float column_half_sum32(const float *__restrict__ A, int lane)
+{
+    const int c = lane & 31, hh = lane >> 5;
+    float s = 0.0f;
+#pragma unroll 8
+    for (int n = 0; n < 16; ++n) s += A[(hh * 16 + n) * 33 + c];
+    return s;
+}
+
+__global__ __launch_bounds__(64 * kEncBwdWaves, 2) void encode_bwd_mfma_kernel(const float *__restrict__ x, int64_t x_stride,
+                                                                               const int64_t *__restrict__ xcat, int64_t N,
+                                                                               ENC_PARAMS, const float *__restrict__ gh,
+                                                                               const float *__restrict__ hout,
+                                                                               int64_t /*nodes_per_wave: tiles are dealt round-robin*/,
+                                                                               float *__restrict__ partial)
+{
+    __shared__ float bufA[kEncBwdWaves][64 * 33];
+    __shared__ float bufB[kEncBwdWaves][64 * 33];
+    __shared__ int bufI[kEncBwdWaves][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    float *A = bufA[wv], *Bm = bufB[wv];
+    int *packed = bufI[wv];
+    // 32-node tiles dealt round-robin over the wavefronts (contiguous ranges of whole 64-node chunks left half of the
+    // SIMDs with two wavefronts and half with one at 288 000 nodes)
+    const int64_t wave = (int64_t)blockIdx.x * kEncBwdWaves + wv, nwaves = (int64_t)gridDim.x * kEncBwdWaves;
+    const int64_t ntiles = (N + 31) / 32, hi = N;
+    // A operands of the three chain products (branch-free loads, see encode_fwd_mfma_kernel) and the first bias
+    float w12[16], w3t[16], w12t[16], b12[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int f = (s & 3) + 8 * (s >> 2) + 4 * hh;
+        {   // W12[r][f]
+            const float *src = r < 16 ? Wk + r * 24 + min(f, 23) : Wc + (r - 16) * 8 + max(f - 24, 0);
+            const bool keep = r < 16 ? f < 24 : f >= 24;
+            const float a = *src;
+            w12[s] = keep ? a : 0.0f;
+        }
+        w3t[s] = Wa[f * 32 + r];                                   // Wa^T[r][f]
+        {   // W12^T[r][f] = W12[f][r]
+            const float *src = f < 16 ? Wk + f * 24 + min(r, 23) : Wc + (f - 16) * 8 + max(r - 24, 0);
+            const bool keep = f < 16 ? r < 24 : r >= 24;
+            const float a = *src;
+            w12t[s] = keep ? a : 0.0f;
+        }
+        const float *bsrc = f < 16 ? bk + f : bc + (f - 16);
+        b12[s] = *bsrc;
+    }
+    f32x16 acc[kEncTiles];
+#pragma unroll
+    for (int t = 0; t < kEncTiles; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.0f;
+    float bias3 = 0.0f, bias21 = 0.0f;
+
+    // two-stage prefetch (as in encode_fwd_mfma_kernel): the table rows of tile t + 1 and the raw row of tile t + 2 are in
+    // flight while tile t is processed
+    struct Raw { float c[4]; long long k0, k1, k2; };
+    auto load_raw = [&](const int64_t tile, Raw &q) __attribute__((always_inline)) {
+        const int64_t nd = tile * 32 + r;
+        const int64_t i = nd < N ? nd : N - 1;
+        const float *row = x + i * x_stride;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q.c[u] = row[4 * hh + u];
+        if (xcat) { q.k0 = xcat[i * 3 + 0]; q.k1 = xcat[i * 3 + 1]; q.k2 = xcat[i * 3 + 2]; }
+        else { q.k0 = (long long)row[8]; q.k1 = (long long)row[9]; q.k2 = (long long)row[10]; }
+    };
+    auto load_tables = [&](const Raw &q, float (&in)[16], int &pk) __attribute__((always_inline)) {
+        long long c = q.k0 < 0 ? -q.k0 : q.k0;    // cat_indices(): the reference's sequential remap, clamped into the tables
+        const long long table[7] = {1, 2, 11, 13, 22, 130, 211};
+#pragma unroll
+        for (int t = 0; t < 7; ++t) c = (c == table[t]) ? (long long)t : c;
+        const int ipdg = (int)min(max(c, 0ll), 6ll), ichg = (int)min(max(q.k1 + 1, 0ll), 2ll), ipv = (int)min(max(q.k2, 0ll), 7ll);
+        pk = ichg | (ipdg << 2) | (ipv << 5);
+        const float4 e0 = *reinterpret_cast<const float4 *>(Echg + ichg * 8 + 4 * hh);
+        const float4 e1 = *reinterpret_cast<const float4 *>(Epdg + ipdg * 8 + 4 * hh);
+        const float4 e2 = *reinterpret_cast<const float4 *>(Epv + ipv * 8 + 4 * hh);
+        in[0] = e0.x; in[1] = e0.y; in[2] = e0.z; in[3] = e0.w; in[4] = e1.x; in[5] = e1.y; in[6] = e1.z; in[7] = e1.w;
+        in[8] = e2.x; in[9] = e2.y; in[10] = e2.z; in[11] = e2.w;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) in[12 + u] = q.c[u];
+    };
+    Raw raw;
+    float in[16], nxt[16];
+    int pk = 0, pk_nxt = 0;
+    if (wave < ntiles) { load_raw(wave, raw); load_tables(raw, in, pk); }
+    if (wave + nwaves < ntiles) load_raw(wave + nwaves, raw);
+    for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+        const int64_t node = tile * 32 + r;
+        const bool live = node < hi;
+        const int64_t ii = live ? node : (hi - 1);
+        if (tile + nwaves < ntiles) load_tables(raw, nxt, pk_nxt);
+        if (tile + 2 * nwaves < ntiles) load_raw(tile + 2 * nwaves, raw);
+        if (hh == 0) packed[r] = pk;
+        // g_z3 = g_h * ELU'(z3), ELU' from h itself: this lane's 16 channels of the node
+        float gz[16];
+        {
+            const float4 *gp = reinterpret_cast<const float4 *>(gh + ii * 32 + 4 * hh);
+            const float4 *hp = reinterpret_cast<const float4 *>(hout + ii * 32 + 4 * hh);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 gv = gp[2 * g], hv = hp[2 * g];
+                const float gg[4] = {gv.x, gv.y, gv.z, gv.w}, hh4[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float d = hh4[u] > 0.0f ? 1.0f : (hh4[u] + 1.0f);
+                    gz[4 * g + u] = live ? gg[u] * d : 0.0f;
+                }
+            }
+        }
+        // product 1: [z2 | z1] -> joint
+        f32x16 c1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c1[e] = b12[e];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w12[s], in[s], c1, 0, 0, 0);
+        float joint[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) joint[e] = elu(c1[e]);
+        // tile 0: g_z3^T joint
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ch = (e & 3) + 8 * (e >> 2) + 4 * hh;
+            A[r * 33 + ch] = gz[e];
+            Bm[r * 33 + ch] = joint[e];
+        }
+        enc_lds_sync();
+        tile_mma32(acc[0], A, Bm, lane);
+        bias3 += column_half_sum32(A, lane);
+        // product 2: g_joint = Wa^T g_z3, then the two ELUs -> [g_z2 | g_z1]
+        f32x16 c2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c2[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3t[s], gz[s], c2, 0, 0, 0);
+        float gj[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) gj[e] = c2[e] * (joint[e] > 0.0f ? 1.0f : (joint[e] + 1.0f));
+        enc_lds_sync();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ch = (e & 3) + 8 * (e >> 2) + 4 * hh;
+            A[r * 33 + ch] = gj[e];
+            Bm[r * 33 + ch] = in[e];
+        }
+        enc_lds_sync();
+        tile_mma32(acc[1], A, Bm, lane);           // [g_z2|g_z1]^T [cat24|x_cont]
+        bias21 += column_half_sum32(A, lane);
+        // product 3: g_in = W12^T [g_z2 | g_z1]; its first 24 features are g_cat24
+        f32x16 c3;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c3[e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(w12t[s], gj[s], c3, 0, 0, 0);
+        enc_lds_sync();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ch = (e & 3) + 8 * (e >> 2) + 4 * hh;
+            Bm[r * 33 + ch] = ch < 24 ? c3[e] : 0.0f;
+        }
+        enc_lds_sync();
+        tile_mma_onehot32(acc[2], packed, Bm, lane);   // S^T [g_cat24|0]
+        enc_lds_sync();
+#pragma unroll
+        for (int u = 0; u < 16; ++u) in[u] = nxt[u];
+        pk = pk_nxt;
+    }
+    // one partial per WORKGROUP, as in encode_bwd_kernel
+    const int c = lane & 31;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int rr = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        A[rr * 32 + c] = acc[0][e];
+        A[1024 + rr * 32 + c] = acc[2][e];
+        Bm[rr * 32 + c] = acc[1][e];
+    }
+    const float b3 = bias3 + __shfl_xor(bias3, 32), b21 = bias21 + __shfl_xor(bias21, 32);
+    if (hh == 0) { Bm[1024 + c] = b3; Bm[1024 + 32 + c] = b21; }
+    __syncthreads();
+    float *out = partial + (int64_t)blockIdx.x * kEncPartial;
+    for (int i = threadIdx.x; i < kEncPartial; i += 64 * kEncBwdWaves) {
+        const float *src = i < 1024 ? &bufA[0][i] : i < 2048 ? &bufB[0][i - 1024] : i < 3072 ? &bufA[0][i - 1024]
+                                                                                              : &bufB[0][i - 2048];
+        float t = src[0];
+#pragma unroll
+        for (int w = 1; w < kEncBwdWaves; ++w) t += src[w * 64 * 33];
+        out[i] = t;
+    }
+}
+
 struct EncGrads {
     float *Wc, *bc, *Wk, *bk, *Wa, *ba, *Echg, *Epdg, *Epv;
 };
@@ -503,12 +736,30 @@ extern "C" int dmet_encode_bwd_f32(const float *x, int64_t x_stride, const int64
     const int64_t npw = enc_nodes_per_wave(N, &nw);
     float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(encode_bwd_kernel, dim3((unsigned)(nw / kEncBwdWaves)), dim3(64 * kEncBwdWaves), 0, st, x, x_stride,
-                       xcat, N, ENC_ARGS, g_h, h, npw, partial);
+    static int form = -1;    // DMET_ENCODER_BWD=valu: the scalar-weight kernel (experiments, A/B)
+    if (form < 0) {
+        const char *e = getenv("DMET_ENCODER_BWD");
+        form = (e && strcmp(e, "valu") == 0) ? 0 : 1;
+    }
+    int64_t nparts = nw / kEncBwdWaves;    // workgroup partials the finalize kernel sums
+    if (form == 1 && aligned16(Echg) && aligned16(Epdg) && aligned16(Epv) && aligned16(g_h) && aligned16(h)) {
+        // 2048 wavefronts = two per SIMD everywhere, 32-node tiles dealt round-robin; never more workgroups than the
+        // workspace holds partials for
+        const int64_t tiles = (N + 31) / 32;
+        int64_t grid = (tiles + kEncBwdWaves - 1) / kEncBwdWaves;
+        if (grid > 512) grid = 512;
+        if (grid > nparts) grid = nparts;
+        nparts = grid;
+        hipLaunchKernelGGL(encode_bwd_mfma_kernel, dim3((unsigned)grid), dim3(64 * kEncBwdWaves), 0, st, x, x_stride, xcat, N,
+                           ENC_ARGS, g_h, h, npw, partial);
+    } else {
+        hipLaunchKernelGGL(encode_bwd_kernel, dim3((unsigned)(nw / kEncBwdWaves)), dim3(64 * kEncBwdWaves), 0, st, x, x_stride,
+                           xcat, N, ENC_ARGS, g_h, h, npw, partial);
+    }
     DMET_LAUNCH_CHECK("encode_bwd_kernel");
     EncGrads gr{gWc, gbc, gWk, gbk, gWa, gba, gEchg, gEpdg, gEpv};
     static_assert(kEncPartial % 32 == 0, "finalize blocks own 32 elements");
-    hipLaunchKernelGGL(encode_bwd_finalize_kernel, dim3(kEncPartial / 32), dim3(1024), 0, st, partial, nw / kEncBwdWaves, gr);
+    hipLaunchKernelGGL(encode_bwd_finalize_kernel, dim3(kEncPartial / 32), dim3(1024), 0, st, partial, nparts, gr);
     DMET_LAUNCH_CHECK("encode_bwd_finalize_kernel");
     return 0;
 }
