@@ -1145,7 +1145,11 @@ def test_knn_build_carries_the_dense_layer(dev, sizes, k, sliced):
     xd, pd, Wd, bd = x.to(dev), ptr.to(dev), W.to(dev), b.to(dev)
     for bias in (bd, None):
         nbr, dist, loc, pq = _native.knn_local_dense(xd, pd, k, Wd, bias, sliced)
-        assert pq is not None, "a 32-feature build with k <= 20 takes the matrix-core path and carries the dense layer"
+        if pq is None:   # diagnostic switches that take the build off the second filter form (tools/toggle_sweep.sh)
+            import os
+            assert os.environ.get("DMET_KNN_PATH") or os.environ.get("DMET_KNN_FILTER"), \
+                "a 32-feature build with k <= 20 takes the matrix-core path and carries the dense layer"
+            pytest.skip("this build cannot carry the dense layer (diagnostic switch)")
         P_ref, Q_ref = _native.node_linear_split(xd, Wd, bias, sliced=sliced)
         assert pq[2] == sliced and torch.equal(pq[0], P_ref) and torch.equal(pq[1], Q_ref)
         nbr0, dist0, loc0 = _native.knn_local(xd, pd, k)
