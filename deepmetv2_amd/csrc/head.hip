@@ -7,6 +7,8 @@
 // LDS with coalesced loads, weights as scalar loads) and a backward kernel that recomputes the hidden layer,
 // back-propagates per node and reduces all four parameter gradients in-kernel on the fp32 matrix cores
 // (fixed node ranges per wavefront, ordered partial sums: bitwise reproducible).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dmet {
@@ -69,6 +71,55 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
         z = __builtin_fmaf(W2[o], head_elu(a), z);
     }
     if (base + lane < N) out[base + lane] = 1.0f / (1.0f + __expf(-z));
+}
+
+// Forward on the fp32 matrix cores (third session of round 2): the hidden layer as C = W1 . X^T with
+// v_mfma_f32_16x16x4_f32 (A = W1: lane (o = l & 15, q = l >> 4) holds W1[o][8 q + s] at k-step s; B = X^T: lane (n, q)
+// holds emb[n][8 q + s], i.e. 32 contiguous bytes of its node's row; C: lane (n, q) receives hidden units 4 q .. 4 q + 3
+// of node n), then ELU, the 16 -> 1 layer as four products per lane and two xor steps across q, the sigmoid.  No LDS, no
+// scalar weight stream; 64 nodes (four 16-node groups) per wavefront.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void head_fwd_mfma_kernel(const float *__restrict__ emb, int64_t N,
+                                                             const float *__restrict__ W1, const float *__restrict__ b1,
+                                                             const float *__restrict__ W2, const float *__restrict__ b2,
+                                                             float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+    const int64_t base = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * 64;
+    if (base >= N) return;
+    float w1[8];
+    {
+        const float4 *wp = reinterpret_cast<const float4 *>(W1 + n * kHin + 8 * q);
+        const float4 a = wp[0], b = wp[1];
+        w1[0] = a.x; w1[1] = a.y; w1[2] = a.z; w1[3] = a.w; w1[4] = b.x; w1[5] = b.y; w1[6] = b.z; w1[7] = b.w;
+    }
+    const float4 bb = *reinterpret_cast<const float4 *>(b1 + 4 * q), ww = *reinterpret_cast<const float4 *>(W2 + 4 * q);
+    const float bias2 = b2[0];
+    float xin[4][8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int64_t node = min(base + 16 * g + n, N - 1);
+        const float4 *xp = reinterpret_cast<const float4 *>(emb + node * kHin + 8 * q);
+        const float4 a = xp[0], b = xp[1];
+        xin[g][0] = a.x; xin[g][1] = a.y; xin[g][2] = a.z; xin[g][3] = a.w;
+        xin[g][4] = b.x; xin[g][5] = b.y; xin[g][6] = b.z; xin[g][7] = b.w;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 acc = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[s2], xin[g][s2], acc, 0, 0, 0);
+        float z = ww.x * head_elu(acc[0]);
+        z = __builtin_fmaf(ww.y, head_elu(acc[1]), z);
+        z = __builtin_fmaf(ww.z, head_elu(acc[2]), z);
+        z = __builtin_fmaf(ww.w, head_elu(acc[3]), z);
+        z += __shfl_xor(z, 16, 64);             // q pairs (0,1), (2,3), then the two pairs: a fixed order
+        z += __shfl_xor(z, 32, 64);
+        z += bias2;
+        const int64_t node = base + 16 * g + n;
+        if (q == 0 && node < N) out[node] = 1.0f / (1.0f + __expf(-z));
+    }
 }
 
 // C += A^T B over the 64 staged nodes; A tile [64][kAPad] (columns >= kAPad are zero), B = emb tile or the second A-like tile
@@ -253,8 +304,17 @@ extern "C" int dmet_head_fwd_f32(const float *emb, int64_t N, const float *W1, c
     if (N == 0) return 0;
     DMET_REQUIRE(emb && W1 && b1 && W2 && b2 && out, "dmet_head_fwd_f32: null pointer");
     DMET_REQUIRE(aligned16(emb), "dmet_head_fwd_f32: emb must be 16-byte aligned");
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), emb, N, W1, b1,
-                       W2, b2, out);
+    static int form = -1;    // DMET_HEAD_FWD=valu: the scalar-weight kernel (experiments, A/B)
+    if (form < 0) {
+        const char *e = getenv("DMET_HEAD_FWD");
+        form = (e && strcmp(e, "valu") == 0) ? 0 : 1;
+    }
+    if (form == 1 && aligned16(W1) && aligned16(b1) && aligned16(W2))
+        hipLaunchKernelGGL(head_fwd_mfma_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), emb, N, W1,
+                           b1, W2, b2, out);
+    else
+        hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), emb, N, W1, b1,
+                           W2, b2, out);
     DMET_LAUNCH_CHECK("head_fwd_kernel");
     return 0;
 }
