@@ -252,6 +252,133 @@ __global__ __launch_bounds__(64 * kHeadWaves, 2) void head_bwd_kernel(const floa
     }
 }
 
+// Backward with the per-node chain on the fp32 matrix cores (third session of round 2): same outputs and partial layout
+// as head_bwd_kernel.  Per 16-node group the recomputed hidden layer (8 x v_mfma_f32_16x16x4_f32, operands as in
+// head_fwd_mfma_kernel: lane (n, q) receives hidden units 4 q .. 4 q + 3 of node n) and g_emb = W1^T g_z1 (two groups of 4
+// MFMAs: the accumulator layout of the first product is the B operand of the second, lane (n, q) receives channels
+// 4 q .. 4 q + 3 and 16 + 4 q .. of node n and stores them as two float4); the K = nodes tile gW1 = g_z1^T emb still
+// goes through LDS.  No scalar weight stream, no g_emb staging.
+__device__ __forceinline__ void head_lds_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wavefront's DS instructions complete in order; global loads stay in flight
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64 * kHeadWaves, 2) void head_bwd_mfma_kernel(const float *__restrict__ emb, int64_t N,
+                                                                           const float *__restrict__ W1,
+                                                                           const float *__restrict__ b1,
+                                                                           const float *__restrict__ W2,
+                                                                           const float *__restrict__ wout,
+                                                                           const float *__restrict__ g_w,
+                                                                           int64_t nodes_per_wave, float *__restrict__ g_emb,
+                                                                           float *__restrict__ partial)
+{
+    __shared__ float sX[kHeadWaves][64 * kXPad];
+    __shared__ float sA[kHeadWaves][64 * kAPad];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = lane & 15, q = lane >> 4;
+    float *X = sX[wv], *A = sA[wv];
+    const int64_t wave = (int64_t)blockIdx.x * kHeadWaves + wv;
+    const int64_t lo = wave * nodes_per_wave, hi = min(N, lo + nodes_per_wave);
+    // A operands: W1[n][8 q + s] (hidden layer) and W1^T[i][4 q + s] for channel rows i = n and 16 + n (g_emb)
+    float w1[8], wtl[4], wth[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) w1[s2] = W1[n * kHin + 8 * q + s2];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) { wtl[s2] = W1[(4 * q + s2) * kHin + n]; wth[s2] = W1[(4 * q + s2) * kHin + 16 + n]; }
+    float bq[4], w2q[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bq[r] = b1[4 * q + r]; w2q[r] = W2[4 * q + r]; }
+    f32x16 acc0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc0[e] = 0.0f;
+    float aW2[4] = {0.f, 0.f, 0.f, 0.f}, ab1[4] = {0.f, 0.f, 0.f, 0.f}, ab2 = 0.0f;   // hidden units 4 q + r of this lane's nodes
+    for (int64_t base = lo; base < hi; base += 64) {
+        head_lds_sync();
+        head_load_tile(X, emb, base, hi, lane);
+        // sigmoid gradients of the chunk's four groups while the tile lands
+        float gz[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int64_t i = base + 16 * g + n;
+            const bool live = i < hi;
+            const float w = live ? wout[i] : 0.0f;
+            gz[g] = live ? g_w[i] * w * (1.0f - w) : 0.0f;
+        }
+        head_lds_sync();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float *xrow = &X[(16 * g + n) * kXPad + 8 * q];
+            const float4 xa = *reinterpret_cast<const float4 *>(xrow), xb = *reinterpret_cast<const float4 *>(xrow + 4);
+            const float xin[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            f32x4 a = {bq[0], bq[1], bq[2], bq[3]};
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) a = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[s2], xin[s2], a, 0, 0, 0);
+            float gz1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float h = head_elu(a[r]);
+                gz1[r] = gz[g] * w2q[r] * (a[r] > 0.0f ? 1.0f : h + 1.0f);      // through Linear 2 and the ELU
+                aW2[r] = __builtin_fmaf(gz[g], h, aW2[r]);
+                ab1[r] += gz1[r];
+            }
+            if (q == 0) ab2 += gz[g];
+            *reinterpret_cast<float4 *>(&A[(16 * g + n) * kAPad + 4 * q]) = make_float4(gz1[0], gz1[1], gz1[2], gz1[3]);
+            if (q == 0) *reinterpret_cast<float4 *>(&A[(16 * g + n) * kAPad + 16]) = make_float4(0.f, 0.f, 0.f, 0.f);
+            // g_emb = W1^T g_z1
+            f32x4 cl = {0.f, 0.f, 0.f, 0.f}, ch = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                cl = __builtin_amdgcn_mfma_f32_16x16x4f32(wtl[s2], gz1[s2], cl, 0, 0, 0);
+                ch = __builtin_amdgcn_mfma_f32_16x16x4f32(wth[s2], gz1[s2], ch, 0, 0, 0);
+            }
+            const int64_t i = base + 16 * g + n;
+            if (i < hi) {
+                float4 *o = reinterpret_cast<float4 *>(g_emb + i * kHin + 4 * q);
+                o[0] = make_float4(cl[0], cl[1], cl[2], cl[3]);
+                o[4] = make_float4(ch[0], ch[1], ch[2], ch[3]);
+            }
+        }
+        head_lds_sync();
+        head_mma<kXPad>(acc0, A, X, lane);            // rows 0..15: gW1 = g_z1^T emb
+    }
+    // one partial per WORKGROUP, as in head_bwd_kernel
+    const int c = lane & 31, hh = lane >> 5;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * hh;
+        X[r * 32 + c] = acc0[e];
+    }
+    // totals over the 16 node lanes of each q group, then lane l of the tail: l < 16 gW2[l], l == 16 gb2, 32 <= l < 48 gb1[l - 32]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            aW2[r] += __shfl_xor(aW2[r], off, 64);
+            ab1[r] += __shfl_xor(ab1[r], off, 64);
+        }
+    const float s2 = wave_sum(ab2);
+    const int rs = lane & 3;
+    const float selW = rs == 0 ? aW2[0] : rs == 1 ? aW2[1] : rs == 2 ? aW2[2] : aW2[3];
+    const float selB = rs == 0 ? ab1[0] : rs == 1 ? ab1[1] : rs == 2 ? ab1[2] : ab1[3];
+    const int o = lane & 15;
+    const float tW = __shfl(selW, 16 * (o >> 2) + (o & 3), 64), tB = __shfl(selB, 16 * (o >> 2) + (o & 3), 64);
+    float mine = 0.0f;
+    if (lane < 16) mine = tW;
+    if (lane == 16) mine = s2;
+    if (lane >= 32 && lane < 48) mine = tB;
+    X[1024 + lane] = mine;
+    __syncthreads();
+    float *out = partial + (int64_t)blockIdx.x * kHeadPartial;
+    for (int i = threadIdx.x; i < kHeadPartial; i += 64 * kHeadWaves) {
+        float t = sX[0][i];
+#pragma unroll
+        for (int w = 1; w < kHeadWaves; ++w) t += sX[w][i];
+        out[i] = t;
+    }
+}
+
 // ordered sum of the wavefront partials (32 thread groups, then 32 group sums) and routing to the four gradients
 __global__ __launch_bounds__(1024) void head_bwd_finalize_kernel(const float *__restrict__ partial, int64_t nwaves,
                                                                   float *__restrict__ gW1, float *__restrict__ gb1,
@@ -340,8 +467,17 @@ extern "C" int dmet_head_bwd_f32(const float *emb, int64_t N, const float *W1, c
     const int64_t npw = head_nodes_per_wave(N, &nw);
     float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)(nw / kHeadWaves)), dim3(64 * kHeadWaves), 0, st, emb, N, W1, b1, W2,
-                       out, g_out, npw, g_emb, partial);
+    static int form = -1;    // DMET_HEAD_BWD=valu: the scalar-weight kernel (experiments, A/B)
+    if (form < 0) {
+        const char *e = getenv("DMET_HEAD_BWD");
+        form = (e && strcmp(e, "valu") == 0) ? 0 : 1;
+    }
+    if (form == 1)
+        hipLaunchKernelGGL(head_bwd_mfma_kernel, dim3((unsigned)(nw / kHeadWaves)), dim3(64 * kHeadWaves), 0, st, emb, N, W1, b1,
+                           W2, out, g_out, npw, g_emb, partial);
+    else
+        hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)(nw / kHeadWaves)), dim3(64 * kHeadWaves), 0, st, emb, N, W1, b1, W2,
+                           out, g_out, npw, g_emb, partial);
     DMET_LAUNCH_CHECK("head_bwd_kernel");
     hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(kHeadPartial / 32), dim3(1024), 0, st, partial, nw / kHeadWaves, gW1, gb1, gW2, gb2);
     DMET_LAUNCH_CHECK("head_bwd_finalize_kernel");
