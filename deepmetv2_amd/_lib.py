@@ -26,6 +26,8 @@ SIGNATURES = {
     "dmet_knn_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "dmet_knn_local_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_adamw_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _vp]),
+    "dmet_bn_knn_local_dense_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i,
+                                         _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_knn_local_dense_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_knn_fallback_stats": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
     "dmet_radius_f32": (_i, [_vp, _vp, _i, _i64, _i, _f, _i, _i, _vp, _vp, _vp]),
@@ -88,6 +90,7 @@ SIGNATURES = {
     "dmet_bn_workspace_bytes": (_sz, [_i64, _i]),
     "dmet_bn_fwd_f32": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _f, _f, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_bn_fwd_tracked_f32": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dmet_bn_stats_f32": (_i, [_vp, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_bn_bwd_f32": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_encode_fwd_f32": (_i, [_vp, _i64, _vp, _i64] + [_vp] * 9 + [_vp, _vp]),
     "dmet_encode_bwd_workspace_bytes": (_sz, [_i64]),

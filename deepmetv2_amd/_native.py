@@ -880,6 +880,82 @@ def bn_fwd(x: torch.Tensor, residual: Optional[torch.Tensor], gamma: torch.Tenso
     return y, stats[0], stats[1]
 
 
+def bn_stats(x: torch.Tensor, eps: float, momentum: float, running_mean: Optional[torch.Tensor],
+             running_var: Optional[torch.Tensor], num_batches_tracked: Optional[torch.Tensor] = None):
+    """(save_mean, save_invstd) of the training-mode BatchNorm1d over the rows of x; running statistics and
+    num_batches_tracked updated like bn_fwd(training=True).  The transform is applied elsewhere (bn_knn_local_dense)."""
+    dev = _require_device(x)
+    L = _lib.load()
+    x = _f32c(x, "x")
+    N, H = x.shape
+    stats = torch.empty((2, H), dtype=torch.float32, device=dev)
+    with _on(dev):
+        ws = _ws(L.dmet_bn_workspace_bytes(N, H), dev)
+        _lib.check(L.dmet_bn_stats_f32(x.data_ptr(), N, H, float(eps), float(momentum),
+                                       running_mean.data_ptr() if running_mean is not None else None,
+                                       running_var.data_ptr() if running_var is not None else None,
+                                       num_batches_tracked.data_ptr() if num_batches_tracked is not None else None,
+                                       stats[0].data_ptr(), stats[1].data_ptr(), ws.data_ptr(), ws.numel(), _stream(dev)),
+                   "dmet_bn_stats_f32")
+    return stats[0], stats[1]
+
+
+def bn_knn_local_dense(raw: torch.Tensor, residual: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                       mean: torch.Tensor, invstd: torch.Tensor, ptr: torch.Tensor, k: int, dense=None):
+    """y = residual + BatchNorm(raw) (statistics given) fused into the prep launch of the kNN build on y
+    (dmet_bn_knn_local_dense_f32).  Returns (y, nbr, dist, loc, pq) -- pq as in knn_local_dense, None without `dense` or
+    when the build could not carry the dense layer -- or None when nothing was launched (the build would not take the
+    matrix-core path): the caller then applies the transform and builds the graph itself."""
+    import ctypes
+    dev = _require_device(raw, ptr)
+    L = _lib.load()
+    raw = _f32c(raw.detach(), "raw")
+    N, D = raw.shape
+    B = ptr.numel() - 1
+    if D != 32 or N == 0 or B == 0 or k > 20:
+        return None
+    if residual is not None:
+        residual = _f32c(residual.detach(), "residual")
+    gamma = _f32c(gamma.detach(), "gamma"); beta = _f32c(beta.detach(), "beta")
+    y = torch.empty_like(raw)
+    nbr = torch.empty((N, k), dtype=torch.int32, device=dev)
+    dist = torch.empty((N, k), dtype=torch.float32, device=dev)
+    loc = torch.empty((N, k), dtype=torch.int16, device=dev)
+    Wp = bp = Pp = Qp = None
+    layout, Pt, Qt, sliced = 0, None, None, False
+    if dense is not None and tuple(dense[0].shape) == (32, 64):
+        W, b, sliced = dense
+        W = _f32c(W.detach(), "W")
+        Wp = W.data_ptr()
+        bp = _f32c(b.detach(), "b").data_ptr() if b is not None else None
+        if sliced == "bf16":
+            Pt = torch.empty((N, 32), dtype=torch.float32, device=dev)
+            Qt = torch.empty((N, 32), dtype=torch.bfloat16, device=dev)
+            layout = 2
+        else:
+            PQ = torch.empty((2, 4, N, 8) if sliced else (2, N, 32), dtype=torch.float32, device=dev)
+            Pt, Qt = PQ[0], PQ[1]
+            layout, sliced = (1 if sliced else 0), bool(sliced)
+        Pp, Qp = Pt.data_ptr(), Qt.data_ptr()
+    nb = L.dmet_knn_workspace_bytes(N, B, D, k)
+    ws = _ws(nb, dev)
+    done, fused = ctypes.c_int(0), ctypes.c_int(0)
+    _t = timer.record('knn', dev)
+    with _on(dev):
+        _lib.check(L.dmet_bn_knn_local_dense_f32(raw.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                                 gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                                 y.data_ptr(), ptr.data_ptr(), B, N, D, k, nbr.data_ptr(), dist.data_ptr(),
+                                                 loc.data_ptr(), Wp, bp, layout, Pp, Qp,
+                                                 ctypes.cast(ctypes.pointer(done), ctypes.c_void_p),
+                                                 ctypes.cast(ctypes.pointer(fused), ctypes.c_void_p), ws.data_ptr(),
+                                                 ws.numel(), _stream(dev)), "dmet_bn_knn_local_dense_f32")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
+    if not fused.value:
+        return None
+    return y, nbr, dist, loc, ((Pt, Qt, sliced) if done.value else None)
+
+
 def bn_bwd(x: torch.Tensor, g_y: torch.Tensor, gamma: torch.Tensor, save_mean: torch.Tensor, save_invstd: torch.Tensor):
     """(g_x, g_gamma, g_beta) of the training-mode BatchNorm1d."""
     dev = _require_device(x, g_y, gamma)

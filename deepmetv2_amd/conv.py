@@ -17,7 +17,7 @@ import torch
 
 from . import _native
 from .cluster import knn_table
-from .graph import EdgeList, NeighborTable, edge_list_from_edge_index, lookup_graph
+from .graph import EdgeList, NeighborTable, batch_info, edge_list_from_edge_index, lookup_graph
 from .scatter import _SegmentMaxRows, _SegmentSumRows
 
 _FUSED_WIDTHS = (32, 64)
@@ -60,6 +60,8 @@ EDGECONV_FORM = os.environ.get("DMET_EDGECONV_FORM", "split")
 _LDS_MAX_EVENT_NODES = int(os.environ.get("DMET_LDS_MAX_NODES", "5119"))
 # the node-level dense layer of a DynamicEdgeConv rides in the kNN build's filter launch (dmet_knn_local_dense_f32)
 KNN_RIDER = os.environ.get("DMET_KNN_RIDER", "1")
+# the BatchNorm transform + residual add that produces a DynamicEdgeConv's input rides in that layer's kNN prep launch
+BN_KNN_FUSE = os.environ.get("DMET_BN_KNN_FUSE", "1")
 
 
 def _lds_eligible(x, weight, table: NeighborTable, any_size: bool = False) -> bool:
@@ -413,15 +415,50 @@ class DynamicEdgeConv(EdgeConv):
             raise ValueError("Static graphs not supported in DynamicEdgeConv")  # upstream's message
         if x.dtype != torch.float32:
             raise TypeError(f"x must be float32, got {x.dtype}")
-        table = knn_table(x, self.k, batch, loop=True, dense=self._dense_request(x))
+        table = self._take_prebuilt(x)
+        if table is None:
+            table = knn_table(x, self.k, batch, loop=True, dense=self._dense_request(x))
         return self._forward_table(x, table)
 
     def forward_with_residual_input(self, x: torch.Tensor, batch: Optional[torch.Tensor] = None):
         """EdgeConv.forward_with_residual_input for the dynamic graph: (conv(x), x')."""
         if x.dim() != 2 or x.dtype != torch.float32:
             return self.forward(x, batch), x
-        table = knn_table(x, self.k, batch, loop=True, dense=self._dense_request(x))
+        table = self._take_prebuilt(x)
+        if table is None:
+            table = knn_table(x, self.k, batch, loop=True, dense=self._dense_request(x))
         return self._forward_table(x, table, passthrough=True)
+
+    # -- BatchNorm transform of the PREVIOUS block fused into this layer's graph build --------------------------------
+    def prebuild_hook(self, batch: Optional[torch.Tensor]):
+        """A callable for dense.batch_norm(..., next_build=...): given the BatchNorm's input, residual, affine parameters
+        and batch statistics it runs this layer's graph build with the transform fused into the prep launch
+        (dmet_bn_knn_local_dense_f32) and returns y = residual + BN(raw); the table is kept for the forward call on that
+        y.  None when this layer cannot use it (DMET_BN_KNN_FUSE=0, k > 20, the matrix-core path switched off)."""
+        if BN_KNN_FUSE == "0" or self.k > 20 or os.environ.get("DMET_KNN_PATH") == "exact":
+            return None
+
+        def build(raw, residual, gamma, beta, mean, invstd):
+            if not raw.is_cuda or raw.dim() != 2 or raw.shape[1] != 32 or raw.dtype != torch.float32:
+                return None
+            info = batch_info(batch, raw.shape[0], raw.device)
+            req = self._dense_request(raw)
+            dense = (req[0], req[1], req[2](info.max_nodes)) if req is not None else None
+            out = _native.bn_knn_local_dense(raw, residual, gamma, beta, mean, invstd, info.ptr, self.k, dense)
+            if out is None:
+                return None
+            y, nbr, dist, loc, pq = out
+            table = NeighborTable(nbr, info.ptr, dense=False, dist=dist, max_nodes=info.max_nodes, nbr_local=loc)
+            table.pq = pq
+            self._prebuilt = (y, table)
+            return y
+        return build
+
+    def _take_prebuilt(self, x: torch.Tensor):
+        pre, self._prebuilt = getattr(self, "_prebuilt", None), None
+        if pre is not None and pre[0].data_ptr() == x.data_ptr() and pre[0].shape == x.shape:
+            return pre[1]
+        return None
 
     def _dense_request(self, x: torch.Tensor):
         """(W, b, sliced_of(max_nodes)) when this layer runs the fused fp32 form on 32 -> 32 features: the graph build

@@ -816,6 +816,16 @@ struct KnnRider {
     bool done = false;
 };
 thread_local KnnRider g_rider;
+
+// BatchNorm transform + residual fused into the prep launch (dmet_bn_knn_local_dense_f32): the build's input y is not
+// there yet -- the prep kernel reads the rows it is made of, raw (the BatchNorm's input) and res, writes
+//   y = (raw - mean) * (gamma * invstd) + beta + res      (the expression of bn_apply_kernel, same bits)
+// and cuts its tile records from the values it just formed: one pass over the rows instead of two, one launch less.
+struct KnnAffine {
+    const float *raw = nullptr, *res = nullptr, *gamma = nullptr, *beta = nullptr, *mean = nullptr, *invstd = nullptr;
+    bool done = false;
+};
+thread_local KnnAffine g_affine;
 // rider workgroups per launch (DMET_KNN_RIDER_GROUPS: experiments; 128..1024 measured within 1 % of each other at
 // 64 x 4500 nodes: the last round leaves ~1150 of the 2048 wavefront slots empty)
 inline int rider_groups()
@@ -878,13 +888,14 @@ __device__ __forceinline__ bool f2_in_domain64(int64_t n) { return n >= kF2MinNo
 // One wavefront per record: lane (col, hh) converts the 16 features of row col it will later feed to the MFMAs.
 // Also writes the flat norm array (certificates) and clears the uncertified-query counters / flags (zero_bytes bytes
 // at `zero`, 4-byte aligned) for the launches that follow, which saves a memset launch per call.
-template <int NH>
+template <int NH, bool AFFINE = false>
 __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__ x, const int64_t *__restrict__ ptr,
                                                         int B, int64_t N, float *__restrict__ nrm,
                                                         uint8_t *__restrict__ rec, int64_t nrec,
                                                         uint32_t *__restrict__ zero, size_t zero_bytes, KnnPlanOut o0,
-                                                        KnnPlanOut o1, int form2)
+                                                        KnnPlanOut o1, int form2, KnnAffine af = KnnAffine{})
 {
+    static_assert(!AFFINE || NH == 1, "the fused BatchNorm transform is built for 32 features");
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     {
         const size_t words = zero_bytes >> 2, total = (size_t)gridDim.x * blockDim.x;
@@ -934,8 +945,33 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__
     for (int half = 0; half < NH; ++half) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            const float4 *g = reinterpret_cast<const float4 *>(x + r * (32 * NH) + 32 * half + 16 * kb + 8 * hh);
-            const float4 v0 = g[0], v1 = g[1];
+            float4 v0, v1;
+            if constexpr (AFFINE) {
+                // x is the OUTPUT here: y = (raw - mean) * (gamma * invstd) + beta (+ res), written for the live rows
+                const int c0 = 16 * kb + 8 * hh;
+                const float4 *g = reinterpret_cast<const float4 *>(af.raw + r * 32 + c0);
+                const float4 a0 = g[0], a1 = g[1];
+                const float4 *mu = reinterpret_cast<const float4 *>(af.mean + c0), *is = reinterpret_cast<const float4 *>(af.invstd + c0);
+                const float4 *ga = reinterpret_cast<const float4 *>(af.gamma + c0), *be = reinterpret_cast<const float4 *>(af.beta + c0);
+                const float4 m0 = mu[0], m1 = mu[1], i0 = is[0], i1 = is[1], g0 = ga[0], g1 = ga[1], b0 = be[0], b1 = be[1];
+                v0.x = (a0.x - m0.x) * (g0.x * i0.x) + b0.x; v0.y = (a0.y - m0.y) * (g0.y * i0.y) + b0.y;
+                v0.z = (a0.z - m0.z) * (g0.z * i0.z) + b0.z; v0.w = (a0.w - m0.w) * (g0.w * i0.w) + b0.w;
+                v1.x = (a1.x - m1.x) * (g1.x * i1.x) + b1.x; v1.y = (a1.y - m1.y) * (g1.y * i1.y) + b1.y;
+                v1.z = (a1.z - m1.z) * (g1.z * i1.z) + b1.z; v1.w = (a1.w - m1.w) * (g1.w * i1.w) + b1.w;
+                if (af.res) {
+                    const float4 *rp = reinterpret_cast<const float4 *>(af.res + r * 32 + c0);
+                    const float4 r0 = rp[0], r1 = rp[1];
+                    v0.x += r0.x; v0.y += r0.y; v0.z += r0.z; v0.w += r0.w;
+                    v1.x += r1.x; v1.y += r1.y; v1.z += r1.z; v1.w += r1.w;
+                }
+                if (live) {
+                    float4 *yo = reinterpret_cast<float4 *>(const_cast<float *>(x) + r * 32 + c0);
+                    yo[0] = v0; yo[1] = v1;
+                }
+            } else {
+                const float4 *g = reinterpret_cast<const float4 *>(x + r * (32 * NH) + 32 * half + 16 * kb + 8 * hh);
+                v0 = g[0]; v1 = g[1];
+            }
             f[half][8 * kb + 0] = v0.x; f[half][8 * kb + 1] = v0.y; f[half][8 * kb + 2] = v0.z; f[half][8 * kb + 3] = v0.w;
             f[half][8 * kb + 4] = v1.x; f[half][8 * kb + 5] = v1.y; f[half][8 * kb + 6] = v1.z; f[half][8 * kb + 7] = v1.w;
         }
@@ -2331,8 +2367,19 @@ int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, cons
                   hipStream_t st)
 {
     const int slots = simds * 2;   // two filter wavefronts per SIMD
-    hipLaunchKernelGGL((knn_prep_kernel<NH>), dim3((unsigned)((w.nrec * kWave + 255) / 256 + 2)), dim3(256), 0, st, f.x,
-                       f.ptr, f.B, f.N, w.nrm, w.rec, w.nrec, reinterpret_cast<uint32_t *>(w.flags), w.zero_bytes, px, pf, f.form2);
+    bool affine = false;
+    if constexpr (NH == 1) affine = g_affine.raw != nullptr && !g_affine.done;
+    if (affine) {
+        if constexpr (NH == 1)
+            hipLaunchKernelGGL((knn_prep_kernel<1, true>), dim3((unsigned)((w.nrec * kWave + 255) / 256 + 2)), dim3(256), 0, st, f.x,
+                               f.ptr, f.B, f.N, w.nrm, w.rec, w.nrec, reinterpret_cast<uint32_t *>(w.flags), w.zero_bytes, px,
+                               pf, f.form2, g_affine);
+        g_affine.done = true;
+    } else {
+        hipLaunchKernelGGL((knn_prep_kernel<NH>), dim3((unsigned)((w.nrec * kWave + 255) / 256 + 2)), dim3(256), 0, st, f.x,
+                           f.ptr, f.B, f.N, w.nrm, w.rec, w.nrec, reinterpret_cast<uint32_t *>(w.flags), w.zero_bytes, px, pf,
+                           f.form2, KnnAffine{});
+    }
     DMET_LAUNCH_CHECK("knn_prep_kernel");
     const int64_t ftiles_max = (f.N + kFQ - 1) / kFQ + f.B;
     const int64_t fblocks = (ftiles_max + slots + kWavesPerGroup - 1) / kWavesPerGroup;
@@ -2812,6 +2859,37 @@ extern "C" int dmet_knn_local_dense_f32(const float *x, const int64_t *ptr, int 
     const int rc = dmet_knn_local_f32(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, ws_bytes, stream);
     *dense_done = (rc == 0 && g_rider.done) ? 1 : 0;
     g_rider = KnnRider{};
+    return rc;
+}
+
+extern "C" int dmet_bn_knn_local_dense_f32(const float *raw, const float *residual, const float *gamma, const float *beta,
+                                           const float *mean, const float *invstd, float *y, const int64_t *ptr, int B,
+                                           int64_t N, int D, int k, int32_t *nbr, float *dist, uint16_t *nbr16,
+                                           const float *W, const float *bias, int layout, float *P, void *Q,
+                                           int *dense_done, int *fused, void *ws, size_t ws_bytes, dmet_stream_t stream)
+{
+    DMET_REQUIRE(fused && dense_done, "dmet_bn_knn_local_dense_f32: fused / dense_done is null");
+    *fused = 0;
+    *dense_done = 0;
+    DMET_REQUIRE(raw && gamma && beta && mean && invstd && y, "dmet_bn_knn_local_dense_f32: null pointer");
+    // only the matrix-core path has the prep launch the transform rides in: any other build leaves everything to the caller
+    const bool eligible = D == 32 && k >= 1 && k <= 20 && N > 0 && B > 0 && filter_mode() != 0 && aligned16(raw) && aligned16(y) &&
+                          aligned16(gamma) && aligned16(beta) && aligned16(mean) && aligned16(invstd) &&
+                          (!residual || aligned16(residual));
+    if (!eligible) return 0;
+    g_affine = KnnAffine{};
+    g_affine.raw = raw; g_affine.res = residual; g_affine.gamma = gamma; g_affine.beta = beta; g_affine.mean = mean;
+    g_affine.invstd = invstd;
+    int rc;
+    if (W) rc = dmet_knn_local_dense_f32(y, ptr, B, N, D, k, nbr, dist, nbr16, W, bias, layout, P, Q, dense_done, ws, ws_bytes, stream);
+    else rc = dmet_knn_local_f32(y, ptr, B, N, D, k, nbr, dist, nbr16, ws, ws_bytes, stream);
+    const bool done = g_affine.done;
+    g_affine = KnnAffine{};
+    if (rc == 0 && !done) {
+        set_error("dmet_bn_knn_local_dense_f32: the build did not take the matrix-core path it was checked for");
+        return -22;
+    }
+    *fused = (rc == 0) ? 1 : 0;
     return rc;
 }
 

@@ -255,6 +255,29 @@ extern "C" int dmet_bn_fwd_tracked_f32(const float *x, const float *residual, in
     return 0;
 }
 
+extern "C" int dmet_bn_stats_f32(const float *x, int64_t N, int H, float eps, float momentum, float *running_mean,
+                                 float *running_var, int64_t *num_batches_tracked, float *save_mean, float *save_invstd,
+                                 void *ws, size_t ws_bytes, dmet_stream_t stream)
+{
+    DMET_REQUIRE(bn_shape_ok(H), "dmet_bn_stats_f32: H=%d must be a multiple of 4 in [4,64]", H);
+    DMET_REQUIRE(N > 0, "dmet_bn_stats_f32: N=%lld", (long long)N);
+    DMET_REQUIRE(x && save_mean && save_invstd && ws, "dmet_bn_stats_f32: null pointer");
+    DMET_REQUIRE(aligned16(x) && aligned16(save_mean) && aligned16(save_invstd), "dmet_bn_stats_f32: pointers must be 16-byte aligned");
+    DMET_REQUIRE(ws_bytes >= dmet_bn_workspace_bytes(N, H), "dmet_bn_stats_f32: workspace too small");
+    DMET_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "dmet_bn_stats_f32: running_mean/var go together");
+    hipStream_t st = as_stream(stream);
+    float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u);
+    int64_t rpb;
+    const int nb = bn_blocks(N, &rpb);
+    hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(nb), dim3(kBnThreads), 0, st, x, (const float *)nullptr, N, H,
+                       (const float *)nullptr, (const float *)nullptr, rpb, partial);
+    DMET_LAUNCH_CHECK("bn_reduce_kernel<0>");
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nb, x, N, H, eps, momentum, running_mean,
+                       running_var, save_mean, save_invstd, num_batches_tracked);
+    DMET_LAUNCH_CHECK("bn_fwd_finalize_kernel");
+    return 0;
+}
+
 extern "C" int dmet_bn_fwd_f32(const float *x, const float *residual, int64_t N, int H, const float *gamma,
                                const float *beta, float eps, float momentum, float *running_mean, float *running_var,
                                int training, float *y, float *save_mean, float *save_invstd, void *ws, size_t ws_bytes,

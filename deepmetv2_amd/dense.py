@@ -85,9 +85,21 @@ class _BatchNorm(torch.autograd.Function):
     """BatchNorm1d over the rows of x[N,H] (+ residual) on the HIP kernels of csrc/norm.hip."""
 
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, tracked=None):
-        y, mean, invstd = _native.bn_fwd(x, residual, weight.detach(), bias.detach(), eps, momentum,
-                                         running_mean, running_var, training, num_batches_tracked=tracked)
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, tracked=None,
+                next_build=None):
+        y = None
+        if next_build is not None and training and x.is_cuda and x.shape[1] == 32:
+            # the transform rides in the prep launch of the NEXT layer's graph build (which consumes y): statistics here,
+            # then one pass that writes y and cuts the build's tile records from it (dmet_bn_knn_local_dense_f32)
+            mean, invstd = _native.bn_stats(x, eps, momentum, running_mean, running_var, tracked)
+            y = next_build(x, residual, weight.detach(), bias.detach(), mean, invstd)
+            if y is None:   # that build takes another path after all: plain transform (the statistics are done)
+                y = (x - mean) * (weight.detach() * invstd) + bias.detach()
+                if residual is not None:
+                    y = y + residual
+        if y is None:
+            y, mean, invstd = _native.bn_fwd(x, residual, weight.detach(), bias.detach(), eps, momentum,
+                                             running_mean, running_var, training, num_batches_tracked=tracked)
         ctx.save_for_backward(x, weight, mean, invstd)
         ctx.training = training
         ctx.has_residual = residual is not None
@@ -104,10 +116,11 @@ class _BatchNorm(torch.autograd.Function):
             g_x = g_y * scale
             g_w = (g_y * (x - mean) * invstd).sum(0)
             g_b = g_y.sum(0)
-        return g_x, (g_y if ctx.has_residual else None), g_w, g_b, None, None, None, None, None, None
+        return g_x, (g_y if ctx.has_residual else None), g_w, g_b, None, None, None, None, None, None, None
 
 
-def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, residual: Optional[torch.Tensor] = None,
+               next_build=None) -> torch.Tensor:
     """residual + bn(x) (residual optional) for a torch.nn.BatchNorm1d module `bn` over x[N,H]: same parameters,
     buffers and train/eval semantics as calling the module (momentum=None, no affine or H not a multiple of 4 up to
     64 take the module itself)."""
@@ -122,7 +135,10 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, residual: Optional[tor
     rv = bn.running_var if bn.track_running_stats else None
     # the statistics kernel bumps num_batches_tracked (torch's own `add_(1)` is one more launch per layer and step)
     tracked = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None
-    return _BatchNorm.apply(x, residual, bn.weight, bn.bias, rm, rv, training, float(bn.momentum), float(bn.eps), tracked)
+    # next_build (DynamicEdgeConv.prebuild of the layer that consumes the result, training mode): the transform is fused
+    # into that layer's graph build
+    return _BatchNorm.apply(x, residual, bn.weight, bn.bias, rm, rv, training, float(bn.momentum), float(bn.eps), tracked,
+                            next_build if bn.training else None)
 
 
 class _Head(torch.autograd.Function):

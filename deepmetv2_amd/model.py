@@ -60,7 +60,15 @@ class GraphMETNetwork(nn.Module):
                 and x_cat.shape[1] == 3 and self.encode_all[0].weight.shape == (32, 32)
                 and list(self.pdgs) == list(PDG_CLASSES) and not x_cont.requires_grad)
 
-    def embed(self, x_cont: torch.Tensor, x_cat: torch.Tensor) -> torch.Tensor:
+    def _next_build(self, layer: int, batch):
+        """The prebuild hook of convolution `layer` when it is a DynamicEdgeConv (its kNN build can carry the BatchNorm
+        transform that produces its input: dense.batch_norm(..., next_build=...)); None otherwise."""
+        if self.graph != "dynamic" or layer >= len(self.conv_continuous):
+            return None
+        hook = getattr(self.conv_continuous[layer][0], "prebuild_hook", None)
+        return hook(batch) if hook is not None else None
+
+    def embed(self, x_cont: torch.Tensor, x_cat: torch.Tensor, batch=None, fuse_next: bool = False) -> torch.Tensor:
         """Per-node encoder (graph_met_network.py:48-58): columns of x_cat are (pdgId, charge, fromPV).
         The standard shape (8 continuous columns, hidden_dim 32) runs as one HIP kernel each way (csrc/encoder.hip);
         anything else takes the layer-by-layer route below."""
@@ -68,7 +76,7 @@ class GraphMETNetwork(nn.Module):
             lc, lk, la = self.embed_continuous[0], self.embed_categorical[0], self.encode_all[0]
             h = dense.encode(x_cont, x_cat, lc.weight, lc.bias, lk.weight, lk.bias, la.weight, la.bias,
                              self.embed_charge.weight, self.embed_pdgid.weight, self.embed_pv.weight)
-            return dense.batch_norm(h, self.bn_all)
+            return dense.batch_norm(h, self.bn_all, next_build=self._next_build(0, batch) if fuse_next else None)
         if x_cat.is_floating_point():      # split_features(x, lazy_cat=True) on the layer-by-layer route
             x_cat = x_cat.long()
         e_cont = _run(self.embed_continuous, x_cont)
@@ -89,11 +97,12 @@ class GraphMETNetwork(nn.Module):
     def forward(self, x_cont, x_cat, edge_index, batch, apply_sigmoid: bool = False):
         """Per-node logit (graph_met_network.py:60-69); apply_sigmoid=True returns sigmoid(logit) instead (what
         Net does), which lets the standard head shape run as one HIP kernel each way (csrc/head.hip)."""
-        emb = self.embed(x_cont, x_cat)
-        for conv, norm in self.conv_continuous:
+        emb = self.embed(x_cont, x_cat, batch, fuse_next=True)
+        for layer, (conv, norm) in enumerate(self.conv_continuous):
             # res is emb routed through the conv's autograd node: both gradients of emb meet in its backward
             msg, res = conv.forward_with_residual_input(emb, batch if self.graph == "dynamic" else edge_index)
-            emb = dense.batch_norm(msg, norm, residual=res)   # emb + norm(msg) in one streaming kernel
+            # emb + norm(msg) in one streaming pass -- inside the next layer's graph build when that is a kNN build
+            emb = dense.batch_norm(msg, norm, residual=res, next_build=self._next_build(layer + 1, batch))
         if apply_sigmoid and self._fused_head_ok(emb):
             l1, l2 = self.output[0], self.output[2]
             return dense.head(emb, l1.weight, l1.bias, l2.weight, l2.bias)

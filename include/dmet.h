@@ -70,6 +70,19 @@ int dmet_knn_local_f32(const float *x, const int64_t *ptr, int B, int64_t N, int
 int dmet_knn_local_dense_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,
                              float *dist, uint16_t *nbr_local, const float *W, const float *bias, int layout,
                              float *P, void *Q, int *dense_done, void *ws, size_t ws_bytes, dmet_stream_t stream);
+/* The block shape of model/graph_met_network.py:64-66, `emb = emb + bn(conv(emb))` followed by the next DynamicEdgeConv
+ * on emb: the BatchNorm transform + residual add that PRODUCES the build's input is fused into the build's prep launch,
+ *   y = (raw - mean) * (gamma * invstd) + beta (+ residual)     (the expression and bits of dmet_bn_fwd_f32's transform;
+ *   mean / invstd from dmet_bn_stats_f32 or the running statistics),
+ * which writes y[N,32] and cuts its tile records from the values it just formed: one pass over the rows instead of two
+ * and one launch less per layer.  Then dmet_knn_local_dense_f32(y, ...) (W == NULL: dmet_knn_local_f32).  *fused = 1:
+ * y, the graph (and P / Q when *dense_done) were written; *fused = 0: NOTHING was launched (the build would not take the
+ * matrix-core path: D != 32, k > 20, switched off, misaligned) and the caller runs the transform and the build itself. */
+int dmet_bn_knn_local_dense_f32(const float *raw, const float *residual, const float *gamma, const float *beta,
+                                const float *mean, const float *invstd, float *y, const int64_t *ptr, int B, int64_t N,
+                                int D, int k, int32_t *nbr, float *dist, uint16_t *nbr_local, const float *W,
+                                const float *bias, int layout, float *P, void *Q, int *dense_done, int *fused, void *ws,
+                                size_t ws_bytes, dmet_stream_t stream);
 
 /* Diagnostics of the matrix-core kNN path (D = 32 or 64, k <= 20): dmet_knn_f32 first ranks candidates with an MFMA
  * filter (fp16 operands for events of 2048..65536 nodes, a bf16 split for smaller ones), re-ranks the kept ones with
@@ -387,6 +400,12 @@ int dmet_bn_fwd_tracked_f32(const float *x, const float *residual, int64_t N, in
                             const float *beta, float eps, float momentum, float *running_mean, float *running_var,
                             int64_t *num_batches_tracked, int training, float *y, float *save_mean, float *save_invstd,
                             void *ws, size_t ws_bytes, dmet_stream_t stream);
+/* The statistics half of dmet_bn_fwd_tracked_f32 in training mode (column sums + finalize: save_mean, save_invstd,
+ * running statistics, num_batches_tracked), for a caller that applies the transform elsewhere
+ * (dmet_bn_knn_local_dense_f32 fuses it into the next layer's graph build). */
+int dmet_bn_stats_f32(const float *x, int64_t N, int H, float eps, float momentum, float *running_mean, float *running_var,
+                      int64_t *num_batches_tracked, float *save_mean, float *save_invstd, void *ws, size_t ws_bytes,
+                      dmet_stream_t stream);
 int dmet_bn_bwd_f32(const float *x, const float *g_y, int64_t N, int H, const float *gamma, const float *save_mean,
                     const float *save_invstd, float *g_x, float *g_gamma, float *g_beta, void *ws, size_t ws_bytes,
                     dmet_stream_t stream);

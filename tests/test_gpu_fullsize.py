@@ -67,6 +67,17 @@ def test_config1_full_train_step_matches_oracle(dev, monkeypatch):
         return t
 
     monkeypatch.setattr(conv_mod, "knn_table", spy)
+    # builds that carried the BatchNorm transform of the block before (dmet_bn_knn_local_dense_f32) hand their table over
+    # through DynamicEdgeConv._take_prebuilt instead of knn_table
+    real_take = conv_mod.DynamicEdgeConv._take_prebuilt
+
+    def spy_take(self, xx):
+        t = real_take(self, xx)
+        if t is not None:
+            captured.append((xx.detach().cpu(), t.nbr.cpu(), t.dist.cpu()))
+        return t
+
+    monkeypatch.setattr(conv_mod.DynamicEdgeConv, "_take_prebuilt", spy_take)
     xd, yd, bd, pd = x.to(dev), y.to(dev), batch.to(dev), ptr.to(dev)
     register_batch(bd, pd, B, max_nodes=n)
     w = model(*split_features(xd), None, bd)

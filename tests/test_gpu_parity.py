@@ -1205,3 +1205,57 @@ def test_flat_adamw_matches_torch_adamw(dev, wd):
     m_ref, v_ref = ob.state[pb]["exp_avg"], ob.state[pb]["exp_avg_sq"]
     torch.testing.assert_close(st["exp_avg"].cpu().double(), m_ref, rtol=1e-5, atol=1e-6 * float(m_ref.abs().max()))
     torch.testing.assert_close(st["exp_avg_sq"].cpu().double(), v_ref, rtol=1e-5, atol=1e-6 * float(v_ref.abs().max()))
+
+
+@pytest.mark.parametrize("sizes,with_res", [([4500, 4500, 300, 2100], True), ([50, 450, 800, 0, 3], True), ([3000, 77], False)])
+def test_batch_norm_transform_rides_in_the_knn_prep(dev, sizes, with_res):
+    """dmet_bn_knn_local_dense_f32: y = residual + BN(raw) written by the build's prep launch has the bits of dmet_bn_fwd_f32,
+    and graph / dense layer are those of a build on that y."""
+    from deepmetv2_amd import _native
+    x, batch, ptr = _ragged(sizes, 32, 21)
+    g = torch.Generator().manual_seed(9)
+    res = torch.randn(x.shape, generator=g) if with_res else None
+    gamma, beta = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
+    W, b = torch.randn(32, 64, generator=g) * 0.2, torch.randn(32, generator=g)
+    xd, pd = x.to(dev), ptr.to(dev)
+    rd = res.to(dev) if with_res else None
+    gd, bd, Wd, bbd = gamma.to(dev), beta.to(dev), W.to(dev), b.to(dev)
+    rm, rv = torch.zeros(32, device=dev), torch.ones(32, device=dev)
+    y_ref, mean_ref, inv_ref = _native.bn_fwd(xd, rd, gd, bd, 1e-5, 0.1, rm.clone(), rv.clone(), True)
+    rm2, rv2 = rm.clone(), rv.clone()
+    mean, invstd = _native.bn_stats(xd, 1e-5, 0.1, rm2, rv2)
+    assert torch.equal(mean, mean_ref) and torch.equal(invstd, inv_ref)
+    out = _native.bn_knn_local_dense(xd, rd, gd, bd, mean, invstd, pd, 16, (Wd, bbd, True))
+    assert out is not None, "a 32-feature build with k <= 20 takes the matrix-core path"
+    y, nbr, dist, loc, pq = out
+    assert torch.equal(y, y_ref)
+    nbr0, dist0, loc0, pq0 = _native.knn_local_dense(y_ref, pd, 16, Wd, bbd, True)
+    assert torch.equal(nbr, nbr0) and torch.equal(dist, dist0) and torch.equal(loc, loc0)
+    assert pq is not None and torch.equal(pq[0], pq0[0]) and torch.equal(pq[1], pq0[1])
+
+
+def test_model_with_fused_transform_matches_unfused(dev, monkeypatch):
+    """The whole model, forward and backward, with the BatchNorm transforms inside the graph builds and without."""
+    from deepmetv2_amd import conv, synth
+    from deepmetv2_amd.model import Net, loss_fn, split_features
+    x, y, batch, ptr = synth.make_events([900, 2500, 64, 300], seed=4)
+    xd, yd, bd = x.to(dev), y.to(dev), batch.to(dev)
+    torch.manual_seed(1)
+    model = Net(8, 3, graph="dynamic", k=16).to(dev).train()
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setattr(conv, "BN_KNN_FUSE", fuse)
+        for bn in [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]:
+            bn.reset_running_stats()
+        model.zero_grad(set_to_none=True)
+        xc, xk = split_features(xd)
+        w = model(xc, xk, None, bd)
+        loss = loss_fn(w, xd, yd, bd)
+        loss.backward()
+        outs.append((w.detach().clone(), [p.grad.clone() for p in model.parameters()],
+                     [b.clone() for b in model.buffers()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)
