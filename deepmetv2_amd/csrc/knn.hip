@@ -941,39 +941,63 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float *__restrict__
     float s = 0.0f;
     uint8_t *recp = rec + tile * rec_bytes(NH);
     float f[NH][16];
+    if constexpr (NH == 1) {
+        // Coalesced tile loads (a wavefront instruction = 1 KB of consecutive bytes: lane l takes float4 64 j + l of the
+        // 4 KB tile, i.e. feature group l & 7 of row 8 j + (l >> 3)), the optional BatchNorm transform applied right there
+        // (one feature group per lane: its constants are loaded once) and y stored the same way; the values then change
+        // to the record layout (lane (col, hh): features 16 kb + 8 hh .. + 7 of row col) through the wavefront's LDS tile.
+        // Until the third session the rows were read as 32-byte pieces in the record layout: 4 instructions that each
+        // touch all 32 cache lines of the tile.
+        __shared__ __attribute__((aligned(16))) float prep_tile[4][32 * 36];
+        float *T = prep_tile[threadIdx.x >> 6];
+        const int fg = lane & 7;
+        float4 mu4, sc4, be4;
+        if constexpr (AFFINE) {
+            mu4 = reinterpret_cast<const float4 *>(af.mean)[fg];
+            const float4 is4 = reinterpret_cast<const float4 *>(af.invstd)[fg], ga4 = reinterpret_cast<const float4 *>(af.gamma)[fg];
+            be4 = reinterpret_cast<const float4 *>(af.beta)[fg];
+            sc4 = make_float4(ga4.x * is4.x, ga4.y * is4.y, ga4.z * is4.z, ga4.w * is4.w);
+        }
 #pragma unroll
-    for (int half = 0; half < NH; ++half) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            float4 v0, v1;
+        for (int jj = 0; jj < 4; ++jj) {
+            const int rowj = 8 * jj + (lane >> 3);
+            const bool livej = li0 + rowj < n;
+            const int64_t rj = ev_lo + (livej ? li0 + rowj : 0);
+            float4 v;
             if constexpr (AFFINE) {
                 // x is the OUTPUT here: y = (raw - mean) * (gamma * invstd) + beta (+ res), written for the live rows
-                const int c0 = 16 * kb + 8 * hh;
-                const float4 *g = reinterpret_cast<const float4 *>(af.raw + r * 32 + c0);
-                const float4 a0 = g[0], a1 = g[1];
-                const float4 *mu = reinterpret_cast<const float4 *>(af.mean + c0), *is = reinterpret_cast<const float4 *>(af.invstd + c0);
-                const float4 *ga = reinterpret_cast<const float4 *>(af.gamma + c0), *be = reinterpret_cast<const float4 *>(af.beta + c0);
-                const float4 m0 = mu[0], m1 = mu[1], i0 = is[0], i1 = is[1], g0 = ga[0], g1 = ga[1], b0 = be[0], b1 = be[1];
-                v0.x = (a0.x - m0.x) * (g0.x * i0.x) + b0.x; v0.y = (a0.y - m0.y) * (g0.y * i0.y) + b0.y;
-                v0.z = (a0.z - m0.z) * (g0.z * i0.z) + b0.z; v0.w = (a0.w - m0.w) * (g0.w * i0.w) + b0.w;
-                v1.x = (a1.x - m1.x) * (g1.x * i1.x) + b1.x; v1.y = (a1.y - m1.y) * (g1.y * i1.y) + b1.y;
-                v1.z = (a1.z - m1.z) * (g1.z * i1.z) + b1.z; v1.w = (a1.w - m1.w) * (g1.w * i1.w) + b1.w;
+                const float4 a = reinterpret_cast<const float4 *>(af.raw + rj * 32)[fg];
+                v.x = (a.x - mu4.x) * sc4.x + be4.x; v.y = (a.y - mu4.y) * sc4.y + be4.y;
+                v.z = (a.z - mu4.z) * sc4.z + be4.z; v.w = (a.w - mu4.w) * sc4.w + be4.w;
                 if (af.res) {
-                    const float4 *rp = reinterpret_cast<const float4 *>(af.res + r * 32 + c0);
-                    const float4 r0 = rp[0], r1 = rp[1];
-                    v0.x += r0.x; v0.y += r0.y; v0.z += r0.z; v0.w += r0.w;
-                    v1.x += r1.x; v1.y += r1.y; v1.z += r1.z; v1.w += r1.w;
+                    const float4 q = reinterpret_cast<const float4 *>(af.res + rj * 32)[fg];
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                 }
-                if (live) {
-                    float4 *yo = reinterpret_cast<float4 *>(const_cast<float *>(x) + r * 32 + c0);
-                    yo[0] = v0; yo[1] = v1;
-                }
+                if (livej) reinterpret_cast<float4 *>(const_cast<float *>(x) + rj * 32)[fg] = v;
             } else {
-                const float4 *g = reinterpret_cast<const float4 *>(x + r * (32 * NH) + 32 * half + 16 * kb + 8 * hh);
-                v0 = g[0]; v1 = g[1];
+                v = reinterpret_cast<const float4 *>(x + rj * 32)[fg];
             }
-            f[half][8 * kb + 0] = v0.x; f[half][8 * kb + 1] = v0.y; f[half][8 * kb + 2] = v0.z; f[half][8 * kb + 3] = v0.w;
-            f[half][8 * kb + 4] = v1.x; f[half][8 * kb + 5] = v1.y; f[half][8 * kb + 6] = v1.z; f[half][8 * kb + 7] = v1.w;
+            *reinterpret_cast<float4 *>(&T[rowj * 36 + 4 * fg]) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wavefront's own LDS writes, in order
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(&T[col * 36 + 16 * kb + 8 * hh]);
+            const float4 v1 = *reinterpret_cast<const float4 *>(&T[col * 36 + 16 * kb + 8 * hh + 4]);
+            f[0][8 * kb + 0] = v0.x; f[0][8 * kb + 1] = v0.y; f[0][8 * kb + 2] = v0.z; f[0][8 * kb + 3] = v0.w;
+            f[0][8 * kb + 4] = v1.x; f[0][8 * kb + 5] = v1.y; f[0][8 * kb + 6] = v1.z; f[0][8 * kb + 7] = v1.w;
+        }
+    } else {
+#pragma unroll
+        for (int half = 0; half < NH; ++half) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const float4 *g = reinterpret_cast<const float4 *>(x + r * (32 * NH) + 32 * half + 16 * kb + 8 * hh);
+                const float4 v0 = g[0], v1 = g[1];
+                f[half][8 * kb + 0] = v0.x; f[half][8 * kb + 1] = v0.y; f[half][8 * kb + 2] = v0.z; f[half][8 * kb + 3] = v0.w;
+                f[half][8 * kb + 4] = v1.x; f[half][8 * kb + 5] = v1.y; f[half][8 * kb + 6] = v1.z; f[half][8 * kb + 7] = v1.w;
+            }
         }
     }
     bool wide = false;
