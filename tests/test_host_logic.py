@@ -103,3 +103,39 @@ def test_edgeconv_api_surface():
         dm.knn_graph(torch.zeros(4, 2), 2, torch.tensor([0, 1, 0, 1]))
     with pytest.raises(ValueError):
         dm.knn_graph(torch.zeros(4, 2), 100)
+
+
+def test_flat_adamw_argument_checks():
+    """deepmetv2_amd.optim.FlatAdamW validates like torch.optim.AdamW and refuses non-GPU parameters (no CPU fallback)."""
+    import pytest
+    import torch
+    from deepmetv2_amd.optim import FlatAdamW
+    p = torch.nn.Parameter(torch.zeros(8))
+    for bad in (dict(lr=-1.0), dict(betas=(1.0, 0.9)), dict(eps=-1e-8), dict(weight_decay=-0.1)):
+        with pytest.raises(ValueError):
+            FlatAdamW([p], **bad)
+    opt = FlatAdamW([p], lr=1e-3)
+    opt.step()                      # no gradient yet: nothing to do
+    p.grad = torch.ones(8)
+    with pytest.raises((TypeError, RuntimeError)):
+        opt.step()                  # a CPU parameter: the HIP library is the only implementation
+
+
+def test_dynamic_edgeconv_rider_requests_follow_the_layer_shape(monkeypatch):
+    """Host-side decisions of the third session: which layers ask the kNN build to carry their dense layer / the
+    BatchNorm transform before them (cuda, fused fp32 or bf16 form on 32 -> 32 features, k <= 20)."""
+    import torch
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import conv
+    x = torch.zeros(10, 32)
+    layer = dm.DynamicEdgeConv(torch.nn.Linear(64, 32), k=16)
+    assert layer._dense_request(x) is None                       # CPU tensor: nothing native to ask
+    assert layer.prebuild_hook(None) is not None
+    assert layer.prebuild_hook(None)(x, None, None, None, None, None) is None    # not on the GPU: the caller keeps the transform
+    assert dm.DynamicEdgeConv(torch.nn.Linear(64, 32), k=24).prebuild_hook(None) is None    # k > 20: exact kernel
+    monkeypatch.setattr(conv, "BN_KNN_FUSE", "0")
+    assert layer.prebuild_hook(None) is None
+    monkeypatch.setenv("DMET_KNN_PATH", "exact")
+    monkeypatch.setattr(conv, "BN_KNN_FUSE", "1")
+    assert layer.prebuild_hook(None) is None
+    assert layer._take_prebuilt(x) is None
