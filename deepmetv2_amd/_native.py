@@ -1072,6 +1072,33 @@ def head_fwd(emb: torch.Tensor, params) -> torch.Tensor:
     return out
 
 
+def bn_head_fwd(raw: torch.Tensor, residual: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                mean: torch.Tensor, invstd: torch.Tensor, params):
+    """(emb, out): emb = residual + BatchNorm(raw) (statistics given) formed inside the head's forward launch and out =
+    head_fwd(emb, params) (dmet_bn_head_fwd_f32); None when nothing was launched (the caller keeps the two steps)."""
+    import ctypes
+    dev = _require_device(raw)
+    L = _lib.load()
+    raw = _f32c(raw.detach(), "raw")
+    if raw.dim() != 2 or raw.shape[1] != 32:
+        return None
+    if residual is not None:
+        residual = _f32c(residual.detach(), "residual")
+    gamma = _f32c(gamma.detach(), "gamma"); beta = _f32c(beta.detach(), "beta")
+    ps = _head_params(params, dev)
+    N = raw.shape[0]
+    emb = torch.empty_like(raw)
+    out = torch.empty((N,), dtype=torch.float32, device=dev)
+    fused = ctypes.c_int(0)
+    with _on(dev):
+        _lib.check(L.dmet_bn_head_fwd_f32(raw.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                          gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                          emb.data_ptr(), N, *[t.data_ptr() for t in ps], out.data_ptr(),
+                                          ctypes.cast(ctypes.pointer(fused), ctypes.c_void_p), _stream(dev)),
+                   "dmet_bn_head_fwd_f32")
+    return (emb, out) if fused.value else None
+
+
 def head_bwd(emb: torch.Tensor, params, out: torch.Tensor, g_out: torch.Tensor):
     """(g_emb, gW1, gb1, gW2, gb2) of head_fwd."""
     dev = _require_device(emb, out, g_out)

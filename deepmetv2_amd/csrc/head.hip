@@ -80,10 +80,19 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
 // scalar weight stream; 64 nodes (four 16-node groups) per wavefront.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// AFFINE (dmet_bn_head_fwd_f32): emb is not there yet -- the kernel forms it from the BatchNorm's input and the residual,
+//   emb = (raw - mean) * (gamma * invstd) + beta (+ res)     (the expression and bits of bn_apply_kernel),
+// stores it (the backward reads it) and feeds the matrix cores from the registers: the last block's transform pass and
+// the head's read of its result become one pass.
+struct HeadAffine {
+    const float *raw, *res, *gamma, *beta, *mean, *invstd;
+};
+
+template <bool AFFINE = false>
 __global__ __launch_bounds__(256) void head_fwd_mfma_kernel(const float *__restrict__ emb, int64_t N,
                                                              const float *__restrict__ W1, const float *__restrict__ b1,
                                                              const float *__restrict__ W2, const float *__restrict__ b2,
-                                                             float *__restrict__ out)
+                                                             float *__restrict__ out, HeadAffine af = HeadAffine{})
 {
     const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
     const int64_t base = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * 64;
@@ -100,8 +109,31 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_kernel(const float *__restr
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int64_t node = min(base + 16 * g + n, N - 1);
-        const float4 *xp = reinterpret_cast<const float4 *>(emb + node * kHin + 8 * q);
-        const float4 a = xp[0], b = xp[1];
+        float4 a, b;
+        if constexpr (AFFINE) {
+            const float4 *rp = reinterpret_cast<const float4 *>(af.raw + node * kHin + 8 * q);
+            const float4 ra = rp[0], rb = rp[1];
+            const float4 *mu = reinterpret_cast<const float4 *>(af.mean + 8 * q), *is = reinterpret_cast<const float4 *>(af.invstd + 8 * q);
+            const float4 *ga = reinterpret_cast<const float4 *>(af.gamma + 8 * q), *be = reinterpret_cast<const float4 *>(af.beta + 8 * q);
+            const float4 m0 = mu[0], m1 = mu[1], i0 = is[0], i1 = is[1], g0 = ga[0], g1 = ga[1], e0 = be[0], e1 = be[1];
+            a.x = (ra.x - m0.x) * (g0.x * i0.x) + e0.x; a.y = (ra.y - m0.y) * (g0.y * i0.y) + e0.y;
+            a.z = (ra.z - m0.z) * (g0.z * i0.z) + e0.z; a.w = (ra.w - m0.w) * (g0.w * i0.w) + e0.w;
+            b.x = (rb.x - m1.x) * (g1.x * i1.x) + e1.x; b.y = (rb.y - m1.y) * (g1.y * i1.y) + e1.y;
+            b.z = (rb.z - m1.z) * (g1.z * i1.z) + e1.z; b.w = (rb.w - m1.w) * (g1.w * i1.w) + e1.w;
+            if (af.res) {
+                const float4 *sp = reinterpret_cast<const float4 *>(af.res + node * kHin + 8 * q);
+                const float4 sa = sp[0], sb = sp[1];
+                a.x += sa.x; a.y += sa.y; a.z += sa.z; a.w += sa.w;
+                b.x += sb.x; b.y += sb.y; b.z += sb.z; b.w += sb.w;
+            }
+            if (base + 16 * g + n < N) {
+                float4 *yo = reinterpret_cast<float4 *>(const_cast<float *>(emb) + node * kHin + 8 * q);
+                yo[0] = a; yo[1] = b;
+            }
+        } else {
+            const float4 *xp = reinterpret_cast<const float4 *>(emb + node * kHin + 8 * q);
+            a = xp[0]; b = xp[1];
+        }
         xin[g][0] = a.x; xin[g][1] = a.y; xin[g][2] = a.z; xin[g][3] = a.w;
         xin[g][4] = b.x; xin[g][5] = b.y; xin[g][6] = b.z; xin[g][7] = b.w;
     }
@@ -437,12 +469,34 @@ extern "C" int dmet_head_fwd_f32(const float *emb, int64_t N, const float *W1, c
         form = (e && strcmp(e, "valu") == 0) ? 0 : 1;
     }
     if (form == 1 && aligned16(W1) && aligned16(b1) && aligned16(W2))
-        hipLaunchKernelGGL(head_fwd_mfma_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), emb, N, W1,
-                           b1, W2, b2, out);
+        hipLaunchKernelGGL(head_fwd_mfma_kernel<false>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), emb, N,
+                           W1, b1, W2, b2, out, HeadAffine{});
     else
         hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), emb, N, W1, b1,
                            W2, b2, out);
     DMET_LAUNCH_CHECK("head_fwd_kernel");
+    return 0;
+}
+
+extern "C" int dmet_bn_head_fwd_f32(const float *raw, const float *residual, const float *gamma, const float *beta,
+                                    const float *mean, const float *invstd, float *emb, int64_t N, const float *W1,
+                                    const float *b1, const float *W2, const float *b2, float *out, int *fused,
+                                    dmet_stream_t stream)
+{
+    DMET_REQUIRE(fused, "dmet_bn_head_fwd_f32: fused is null");
+    *fused = 0;
+    DMET_REQUIRE(N >= 0, "dmet_bn_head_fwd_f32: N=%lld", (long long)N);
+    if (N == 0) { *fused = 1; return 0; }
+    DMET_REQUIRE(raw && gamma && beta && mean && invstd && emb && W1 && b1 && W2 && b2 && out, "dmet_bn_head_fwd_f32: null pointer");
+    const char *e = getenv("DMET_HEAD_FWD");
+    const bool ok = !(e && strcmp(e, "valu") == 0) && aligned16(raw) && aligned16(emb) && aligned16(gamma) && aligned16(beta) &&
+                    aligned16(mean) && aligned16(invstd) && (!residual || aligned16(residual)) && aligned16(W1) &&
+                    aligned16(b1) && aligned16(W2);
+    if (!ok) return 0;    // nothing launched: the caller runs the transform and dmet_head_fwd_f32
+    hipLaunchKernelGGL(head_fwd_mfma_kernel<true>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), emb, N, W1,
+                       b1, W2, b2, out, HeadAffine{raw, residual, gamma, beta, mean, invstd});
+    DMET_LAUNCH_CHECK("head_fwd_mfma_kernel<affine>");
+    *fused = 1;
     return 0;
 }
 

@@ -102,7 +102,11 @@ class GraphMETNetwork(nn.Module):
             # res is emb routed through the conv's autograd node: both gradients of emb meet in its backward
             msg, res = conv.forward_with_residual_input(emb, batch if self.graph == "dynamic" else edge_index)
             # emb + norm(msg) in one streaming pass -- inside the next layer's graph build when that is a kNN build
-            emb = dense.batch_norm(msg, norm, residual=res, next_build=self._next_build(layer + 1, batch))
+            nb = self._next_build(layer + 1, batch)
+            if nb is None and layer + 1 == len(self.conv_continuous) and apply_sigmoid and self._fused_head_ok(res):
+                l1, l2 = self.output[0], self.output[2]     # last block: the transform rides in the head's forward launch
+                nb = dense.head_prebuild_hook(l1.weight, l1.bias, l2.weight, l2.bias)
+            emb = dense.batch_norm(msg, norm, residual=res, next_build=nb)
         if apply_sigmoid and self._fused_head_ok(emb):
             l1, l2 = self.output[0], self.output[2]
             return dense.head(emb, l1.weight, l1.bias, l2.weight, l2.bias)

@@ -416,6 +416,14 @@ int dmet_bn_bwd_f32(const float *x, const float *g_y, int64_t N, int H, const fl
  * writes g_emb[N,32] and the four parameter gradients (reduced over the nodes deterministically). */
 int dmet_head_fwd_f32(const float *emb, int64_t N, const float *W1, const float *b1, const float *W2, const float *b2,
                       float *out, dmet_stream_t stream);
+/* The last block of the model, `emb = emb + bn(conv(emb))` followed by the head (model/graph_met_network.py:66-67): the
+ * BatchNorm transform + residual add is formed inside the head's forward launch (expression and bits of
+ * dmet_bn_fwd_f32's transform; statistics from dmet_bn_stats_f32), emb[N,32] is written for the backward.  *fused = 0:
+ * nothing was launched (misaligned operands, DMET_HEAD_FWD=valu) and the caller keeps the two steps. */
+int dmet_bn_head_fwd_f32(const float *raw, const float *residual, const float *gamma, const float *beta,
+                         const float *mean, const float *invstd, float *emb, int64_t N, const float *W1,
+                         const float *b1, const float *W2, const float *b2, float *out, int *fused,
+                         dmet_stream_t stream);
 size_t dmet_head_bwd_workspace_bytes(int64_t N);
 int dmet_head_bwd_f32(const float *emb, int64_t N, const float *W1, const float *b1, const float *W2, const float *out,
                       const float *g_out, float *g_emb, float *gW1, float *gb1, float *gW2, float *gb2, void *ws,
