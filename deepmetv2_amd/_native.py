@@ -844,6 +844,40 @@ def encode_bwd(x_cont: torch.Tensor, x_cat: torch.Tensor, params, h: torch.Tenso
     return grads
 
 
+def encode_bn_bwd(x_cont: torch.Tensor, x_cat: torch.Tensor, params, h: torch.Tensor, g_y: torch.Tensor,
+                  gamma: torch.Tensor, mean: torch.Tensor, invstd: torch.Tensor):
+    """Backward of bn_all(encode(...)) given dL/d(bn output): (encoder grads [9], g_gamma, g_beta), the BatchNorm's
+    backward transform applied inside the encoder's backward kernel (dmet_bn_bwd_stats_f32 + dmet_encode_bn_bwd_f32);
+    None when nothing was launched beyond the statistics (the caller keeps the separate steps)."""
+    import ctypes
+    dev = _require_device(x_cont, x_cat, h, g_y)
+    L = _lib.load()
+    x, xc = _encode_x(x_cont, x_cat)
+    ps = _encode_params(params, dev)
+    h = _f32c(h, "h"); g_y = _f32c(g_y, "g_y"); gamma = _f32c(gamma.detach(), "gamma")
+    N, H = h.shape
+    if N == 0 or H != 32:
+        return None
+    grads = [torch.empty_like(t) for t in ps]
+    st = torch.empty((4, H), dtype=torch.float32, device=dev)     # g_gamma, g_beta, mean_g, mean_gx
+    fused = ctypes.c_int(0)
+    with _on(dev):
+        ws = _ws(L.dmet_bn_workspace_bytes(N, H), dev)
+        _lib.check(L.dmet_bn_bwd_stats_f32(h.data_ptr(), g_y.data_ptr(), N, H, mean.data_ptr(), invstd.data_ptr(),
+                                           st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
+                                           ws.data_ptr(), ws.numel(), _stream(dev)), "dmet_bn_bwd_stats_f32")
+        ws2 = _ws(L.dmet_encode_bwd_workspace_bytes(N), dev)
+        _lib.check(L.dmet_encode_bn_bwd_f32(x.data_ptr(), x.stride(0), xc.data_ptr() if xc is not None else None, N,
+                                            *[t.data_ptr() for t in ps], h.data_ptr(), g_y.data_ptr(), gamma.data_ptr(),
+                                            mean.data_ptr(), invstd.data_ptr(), st[2].data_ptr(), st[3].data_ptr(),
+                                            *[g.data_ptr() for g in grads],
+                                            ctypes.cast(ctypes.pointer(fused), ctypes.c_void_p), ws2.data_ptr(), ws2.numel(),
+                                            _stream(dev)), "dmet_encode_bn_bwd_f32")
+    if not fused.value:
+        return None
+    return grads, st[0], st[1]
+
+
 def bn_fwd(x: torch.Tensor, residual: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, eps: float,
            momentum: float, running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor], training: bool,
            num_batches_tracked: Optional[torch.Tensor] = None):

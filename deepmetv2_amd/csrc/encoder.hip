@@ -444,12 +444,22 @@ __device__ __forceinline__ float column_half_sum32(const float *__restrict__ A, 
     return s;
 }
 
+// BNB (dmet_encode_bn_bwd_f32): `gh` is the gradient with respect to bn_all's OUTPUT; the BatchNorm's backward
+// transform  g = gamma * invstd * (g_y - mean_g - (h - mean) * invstd * mean_gx)  (expression of bn_bwd_apply_kernel) is
+// applied to the values as they are loaded -- h, the BatchNorm's input, is the encoder's own output, which this kernel
+// reads anyway: the transform pass (17 us, 111 MB) disappears.
+struct EncBnBwd {
+    const float *gamma, *mean, *invstd, *mean_g, *mean_gx;
+};
+
+template <bool BNB = false>
 __global__ __launch_bounds__(64 * kEncBwdWaves, 2) void encode_bwd_mfma_kernel(const float *__restrict__ x, int64_t x_stride,
                                                                                const int64_t *__restrict__ xcat, int64_t N,
                                                                                ENC_PARAMS, const float *__restrict__ gh,
                                                                                const float *__restrict__ hout,
                                                                                int64_t /*nodes_per_wave: tiles are dealt round-robin*/,
-                                                                               float *__restrict__ partial)
+                                                                               float *__restrict__ partial,
+                                                                               EncBnBwd bnb = EncBnBwd{})
 {
     __shared__ float bufA[kEncBwdWaves][64 * 33];
     __shared__ float bufB[kEncBwdWaves][64 * 33];
@@ -537,7 +547,18 @@ __global__ __launch_bounds__(64 * kEncBwdWaves, 2) void encode_bwd_mfma_kernel(c
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 gv = gp[2 * g], hv = hp[2 * g];
-                const float gg[4] = {gv.x, gv.y, gv.z, gv.w}, hh4[4] = {hv.x, hv.y, hv.z, hv.w};
+                float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+                const float hh4[4] = {hv.x, hv.y, hv.z, hv.w};
+                if constexpr (BNB) {
+                    const int c0 = 8 * g + 4 * hh;      // this lane's channels of group g
+                    const float4 ga = *reinterpret_cast<const float4 *>(bnb.gamma + c0), mu = *reinterpret_cast<const float4 *>(bnb.mean + c0);
+                    const float4 is = *reinterpret_cast<const float4 *>(bnb.invstd + c0), mg = *reinterpret_cast<const float4 *>(bnb.mean_g + c0);
+                    const float4 mx = *reinterpret_cast<const float4 *>(bnb.mean_gx + c0);
+                    gg[0] = ga.x * is.x * (gg[0] - mg.x - (hh4[0] - mu.x) * is.x * mx.x);
+                    gg[1] = ga.y * is.y * (gg[1] - mg.y - (hh4[1] - mu.y) * is.y * mx.y);
+                    gg[2] = ga.z * is.z * (gg[2] - mg.z - (hh4[2] - mu.z) * is.z * mx.z);
+                    gg[3] = ga.w * is.w * (gg[3] - mg.w - (hh4[3] - mu.w) * is.w * mx.w);
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float d = hh4[u] > 0.0f ? 1.0f : (hh4[u] + 1.0f);
@@ -673,6 +694,10 @@ inline int64_t enc_nodes_per_wave(int64_t N, int64_t *nwaves)
     return npw;
 }
 
+// set by dmet_encode_bn_bwd_f32 around its call of dmet_encode_bwd_f32 on this thread
+thread_local EncBnBwd g_enc_bnb{nullptr, nullptr, nullptr, nullptr, nullptr};
+thread_local bool g_enc_bnb_done = false;
+
 }  // namespace
 }  // namespace dmet
 
@@ -750,8 +775,13 @@ extern "C" int dmet_encode_bwd_f32(const float *x, int64_t x_stride, const int64
         if (grid > 512) grid = 512;
         if (grid > nparts) grid = nparts;
         nparts = grid;
-        hipLaunchKernelGGL(encode_bwd_mfma_kernel, dim3((unsigned)grid), dim3(64 * kEncBwdWaves), 0, st, x, x_stride, xcat, N,
-                           ENC_ARGS, g_h, h, npw, partial);
+        if (g_enc_bnb.gamma)
+            hipLaunchKernelGGL(encode_bwd_mfma_kernel<true>, dim3((unsigned)grid), dim3(64 * kEncBwdWaves), 0, st, x, x_stride, xcat,
+                               N, ENC_ARGS, g_h, h, npw, partial, g_enc_bnb);
+        else
+            hipLaunchKernelGGL(encode_bwd_mfma_kernel<false>, dim3((unsigned)grid), dim3(64 * kEncBwdWaves), 0, st, x, x_stride,
+                               xcat, N, ENC_ARGS, g_h, h, npw, partial, EncBnBwd{});
+        g_enc_bnb_done = g_enc_bnb.gamma != nullptr;
     } else {
         hipLaunchKernelGGL(encode_bwd_kernel, dim3((unsigned)(nw / kEncBwdWaves)), dim3(64 * kEncBwdWaves), 0, st, x, x_stride,
                            xcat, N, ENC_ARGS, g_h, h, npw, partial);
@@ -762,4 +792,35 @@ extern "C" int dmet_encode_bwd_f32(const float *x, int64_t x_stride, const int64
     hipLaunchKernelGGL(encode_bwd_finalize_kernel, dim3(kEncPartial / 32), dim3(1024), 0, st, partial, nparts, gr);
     DMET_LAUNCH_CHECK("encode_bwd_finalize_kernel");
     return 0;
+}
+
+extern "C" int dmet_encode_bn_bwd_f32(const float *x, int64_t x_stride, const int64_t *xcat, int64_t N, const float *Wc,
+                                      const float *bc, const float *Wk, const float *bk, const float *Wa, const float *ba,
+                                      const float *Echg, const float *Epdg, const float *Epv, const float *h,
+                                      const float *g_y, const float *bn_gamma, const float *bn_mean, const float *bn_invstd,
+                                      const float *bn_mean_g, const float *bn_mean_gx, float *gWc, float *gbc, float *gWk,
+                                      float *gbk, float *gWa, float *gba, float *gEchg, float *gEpdg, float *gEpv,
+                                      int *fused, void *ws, size_t ws_bytes, dmet_stream_t stream)
+{
+    DMET_REQUIRE(fused, "dmet_encode_bn_bwd_f32: fused is null");
+    *fused = 0;
+    DMET_REQUIRE(bn_gamma && bn_mean && bn_invstd && bn_mean_g && bn_mean_gx, "dmet_encode_bn_bwd_f32: null pointer");
+    const char *e = getenv("DMET_ENCODER_BWD");
+    const bool ok = !(e && strcmp(e, "valu") == 0) && N > 0 && aligned16(Echg) && aligned16(Epdg) && aligned16(Epv) && aligned16(g_y) &&
+                    aligned16(h) && aligned16(bn_gamma) && aligned16(bn_mean) && aligned16(bn_invstd) && aligned16(bn_mean_g) &&
+                    aligned16(bn_mean_gx);
+    if (!ok) return 0;     // nothing launched: the caller applies the BatchNorm's backward transform and calls dmet_encode_bwd_f32
+    g_enc_bnb = EncBnBwd{bn_gamma, bn_mean, bn_invstd, bn_mean_g, bn_mean_gx};
+    g_enc_bnb_done = false;
+    const int rc = dmet_encode_bwd_f32(x, x_stride, xcat, N, Wc, bc, Wk, bk, Wa, ba, Echg, Epdg, Epv, h, g_y, gWc, gbc, gWk, gbk, gWa,
+                                       gba, gEchg, gEpdg, gEpv, ws, ws_bytes, stream);
+    const bool done = g_enc_bnb_done;
+    g_enc_bnb = EncBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr};
+    g_enc_bnb_done = false;
+    if (rc == 0 && !done) {
+        set_error("dmet_encode_bn_bwd_f32: the matrix-core backward it was checked for did not run");
+        return -22;
+    }
+    *fused = rc == 0 ? 1 : 0;
+    return rc;
 }

@@ -318,3 +318,27 @@ extern "C" int dmet_bn_bwd_f32(const float *x, const float *g_y, int64_t N, int 
     DMET_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return 0;
 }
+
+extern "C" int dmet_bn_bwd_stats_f32(const float *x, const float *g_y, int64_t N, int H, const float *save_mean,
+                                     const float *save_invstd, float *g_gamma, float *g_beta, float *mean_g,
+                                     float *mean_gx, void *ws, size_t ws_bytes, dmet_stream_t stream)
+{
+    DMET_REQUIRE(bn_shape_ok(H), "dmet_bn_bwd_stats_f32: H=%d must be a multiple of 4 in [4,64]", H);
+    DMET_REQUIRE(N > 0, "dmet_bn_bwd_stats_f32: N=%lld", (long long)N);
+    DMET_REQUIRE(x && g_y && save_mean && save_invstd && g_gamma && g_beta && mean_g && mean_gx && ws,
+                 "dmet_bn_bwd_stats_f32: null pointer");
+    DMET_REQUIRE(aligned16(x) && aligned16(g_y) && aligned16(save_mean) && aligned16(save_invstd),
+                 "dmet_bn_bwd_stats_f32: pointers must be 16-byte aligned");
+    DMET_REQUIRE(ws_bytes >= dmet_bn_workspace_bytes(N, H), "dmet_bn_bwd_stats_f32: workspace too small");
+    hipStream_t st = as_stream(stream);
+    float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u);
+    int64_t rpb;
+    const int nb = bn_blocks(N, &rpb);
+    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(nb), dim3(kBnThreads), 0, st, x, g_y, N, H, save_mean, save_invstd,
+                       rpb, partial);
+    DMET_LAUNCH_CHECK("bn_reduce_kernel<1>");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nb, N, H, g_gamma, g_beta, mean_g,
+                       mean_gx);
+    DMET_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+    return 0;
+}

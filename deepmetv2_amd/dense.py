@@ -121,6 +121,56 @@ class _BatchNorm(torch.autograd.Function):
         return g_x, (g_y if ctx.has_residual else None), g_w, g_b, None, None, None, None, None, None, None
 
 
+ENC_BN_FUSE = os.environ.get("DMET_ENC_BN_FUSE", "1")
+
+
+class _EncodeBN(torch.autograd.Function):
+    """bn_all(encode(x)) of graph_met_network.py:48-58 in training mode as ONE autograd node: forward = _Encode's and
+    _BatchNorm's (the transform inside the next graph build when `next_build` says so); backward = the BatchNorm's column
+    sums, then the encoder's backward kernel with the BatchNorm's backward transform applied to the rows as it loads them
+    (dmet_encode_bn_bwd_f32) -- h, the BatchNorm's input, is the encoder's own output, which that kernel reads anyway."""
+
+    @staticmethod
+    def forward(ctx, x_cont, x_cat, weight, bias, running_mean, running_var, momentum, eps, tracked, next_build, *params):
+        h = _native.encode_fwd(x_cont, x_cat, [p.detach() for p in params])
+        y = None
+        if next_build is not None:
+            mean, invstd = _native.bn_stats(h, eps, momentum, running_mean, running_var, tracked)
+            y = next_build(h, None, weight.detach(), bias.detach(), mean, invstd)
+            if y is None:
+                y = (h - mean) * (weight.detach() * invstd) + bias.detach()
+        if y is None:
+            y, mean, invstd = _native.bn_fwd(h, None, weight.detach(), bias.detach(), eps, momentum, running_mean,
+                                             running_var, True, num_batches_tracked=tracked)
+        ctx.save_for_backward(x_cont, x_cat, h, weight, mean, invstd, *params)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        x_cont, x_cat, h, weight, mean, invstd, *params = ctx.saved_tensors
+        g_y = g_y.contiguous()
+        ps = [p.detach() for p in params]
+        res = _native.encode_bn_bwd(x_cont, x_cat, ps, h, g_y, weight.detach(), mean, invstd)
+        if res is None:     # the fused backward is not available for these operands: the two separate steps
+            g_h, g_w, g_b = _native.bn_bwd(h, g_y, weight.detach(), mean, invstd)
+            grads = _native.encode_bwd(x_cont, x_cat, ps, h, g_h)
+        else:
+            grads, g_w, g_b = res
+        return (None, None, g_w, g_b, None, None, None, None, None, None, *grads)
+
+
+def encode_bn(x_cont: torch.Tensor, x_cat: torch.Tensor, bn: torch.nn.BatchNorm1d, next_build, *params: torch.Tensor):
+    """bn(encode(x_cont, x_cat, *params)) -- batch_norm(encode(...), bn, next_build=next_build) with the BatchNorm's
+    backward transform inside the encoder's backward kernel when bn is a plain training-mode BatchNorm1d(32) on the GPU
+    (DMET_ENC_BN_FUSE=0: always the two nodes)."""
+    ok = (ENC_BN_FUSE != "0" and x_cont.is_cuda and bn.training and bn.affine and bn.momentum is not None
+          and bn.track_running_stats and bn.num_features == 32 and x_cont.shape[0] > 1)
+    if not ok:
+        return batch_norm(encode(x_cont, x_cat, *params), bn, next_build=next_build)
+    return _EncodeBN.apply(x_cont, x_cat, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.momentum),
+                           float(bn.eps), bn.num_batches_tracked, next_build, *params)
+
+
 def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, residual: Optional[torch.Tensor] = None,
                next_build=None) -> torch.Tensor:
     """residual + bn(x) (residual optional) for a torch.nn.BatchNorm1d module `bn` over x[N,H]: same parameters,

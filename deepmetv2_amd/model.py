@@ -74,9 +74,9 @@ class GraphMETNetwork(nn.Module):
         anything else takes the layer-by-layer route below."""
         if self._fused_encoder_ok(x_cont, x_cat):
             lc, lk, la = self.embed_continuous[0], self.embed_categorical[0], self.encode_all[0]
-            h = dense.encode(x_cont, x_cat, lc.weight, lc.bias, lk.weight, lk.bias, la.weight, la.bias,
-                             self.embed_charge.weight, self.embed_pdgid.weight, self.embed_pv.weight)
-            return dense.batch_norm(h, self.bn_all, next_build=self._next_build(0, batch) if fuse_next else None)
+            return dense.encode_bn(x_cont, x_cat, self.bn_all, self._next_build(0, batch) if fuse_next else None,
+                                   lc.weight, lc.bias, lk.weight, lk.bias, la.weight, la.bias,
+                                   self.embed_charge.weight, self.embed_pdgid.weight, self.embed_pv.weight)
         if x_cat.is_floating_point():      # split_features(x, lazy_cat=True) on the layer-by-layer route
             x_cat = x_cat.long()
         e_cont = _run(self.embed_continuous, x_cont)

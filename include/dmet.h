@@ -365,6 +365,18 @@ int dmet_encode_bwd_f32(const float *x, int64_t x_stride, const int64_t *x_cat, 
                         const float *Epdg, const float *Epv, const float *h, const float *g_h, float *gWc,
                         float *gbc, float *gWk, float *gbk, float *gWa, float *gba, float *gEchg, float *gEpdg,
                         float *gEpv, void *ws, size_t ws_bytes, dmet_stream_t stream);
+/* dmet_encode_bwd_f32 behind bn_all (model/graph_met_network.py:58): g_y is the gradient with respect to the
+ * BatchNorm's OUTPUT and the BatchNorm's backward transform g = gamma * invstd * (g_y - mean_g - (h - mean) * invstd *
+ * mean_gx) (statistics from dmet_bn_bwd_stats_f32; h, the BatchNorm's input, is the encoder's own output) is applied
+ * as the rows are loaded: the transform pass of dmet_bn_bwd_f32 disappears.  *fused = 0: nothing was launched
+ * (DMET_ENCODER_BWD=valu, misaligned operands) and the caller keeps the two steps. */
+int dmet_encode_bn_bwd_f32(const float *x, int64_t x_stride, const int64_t *xcat, int64_t N, const float *Wc,
+                           const float *bc, const float *Wk, const float *bk, const float *Wa, const float *ba,
+                           const float *Echg, const float *Epdg, const float *Epv, const float *h, const float *g_y,
+                           const float *bn_gamma, const float *bn_mean, const float *bn_invstd, const float *bn_mean_g,
+                           const float *bn_mean_gx, float *gWc, float *gbc, float *gWk, float *gbk, float *gWa,
+                           float *gba, float *gEchg, float *gEpdg, float *gEpv, int *fused, void *ws, size_t ws_bytes,
+                           dmet_stream_t stream);
 
 /* ---- K5 (node level): backward of the fused EdgeConv dense layer, H = 32 -------------------------------------
  * With P = x (W1-W2)^T + b, Q = x W2^T, out_i = P_i + max_s Q[nbr[i,s]] (dmet_node_linear_split_f32 +
@@ -400,6 +412,11 @@ int dmet_bn_fwd_tracked_f32(const float *x, const float *residual, int64_t N, in
                             const float *beta, float eps, float momentum, float *running_mean, float *running_var,
                             int64_t *num_batches_tracked, int training, float *y, float *save_mean, float *save_invstd,
                             void *ws, size_t ws_bytes, dmet_stream_t stream);
+/* The statistics half of dmet_bn_bwd_f32 (column sums + finalize): g_gamma, g_beta and the two means the element
+ * transform needs, for a caller that applies the transform elsewhere (dmet_encode_bn_bwd_f32). */
+int dmet_bn_bwd_stats_f32(const float *x, const float *g_y, int64_t N, int H, const float *save_mean,
+                          const float *save_invstd, float *g_gamma, float *g_beta, float *mean_g, float *mean_gx,
+                          void *ws, size_t ws_bytes, dmet_stream_t stream);
 /* The statistics half of dmet_bn_fwd_tracked_f32 in training mode (column sums + finalize: save_mean, save_invstd,
  * running statistics, num_batches_tracked), for a caller that applies the transform elsewhere
  * (dmet_bn_knn_local_dense_f32 fuses it into the next layer's graph build). */

@@ -1250,6 +1250,7 @@ def test_model_with_fused_transform_matches_unfused(dev, monkeypatch):
     for fuse in ("1", "0"):
         monkeypatch.setattr(conv, "BN_KNN_FUSE", fuse)
         monkeypatch.setattr(dense, "HEAD_FUSE", fuse)      # the last block's transform inside the head's forward launch
+        monkeypatch.setattr(dense, "ENC_BN_FUSE", fuse)    # bn_all's backward transform inside the encoder's backward kernel
         for bn in [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]:
             bn.reset_running_stats()
         model.zero_grad(set_to_none=True)
