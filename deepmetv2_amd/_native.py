@@ -934,6 +934,19 @@ def bn_stats(x: torch.Tensor, eps: float, momentum: float, running_mean: Optiona
     return stats[0], stats[1]
 
 
+def bn_eval_stats(running_mean: torch.Tensor, running_var: torch.Tensor, eps: float):
+    """(mean, invstd) of an eval-mode BatchNorm1d: running_mean and 1 / sqrt(running_var + eps), as bn_fwd(training=False)
+    forms them."""
+    dev = _require_device(running_mean, running_var)
+    L = _lib.load()
+    H = running_mean.numel()
+    stats = torch.empty((2, H), dtype=torch.float32, device=dev)
+    with _on(dev):
+        _lib.check(L.dmet_bn_eval_stats_f32(running_mean.data_ptr(), running_var.data_ptr(), H, float(eps),
+                                            stats[0].data_ptr(), stats[1].data_ptr(), _stream(dev)), "dmet_bn_eval_stats_f32")
+    return stats[0], stats[1]
+
+
 def bn_knn_local_dense(raw: torch.Tensor, residual: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
                        mean: torch.Tensor, invstd: torch.Tensor, ptr: torch.Tensor, k: int, dense=None):
     """y = residual + BatchNorm(raw) (statistics given) fused into the prep launch of the kNN build on y

@@ -342,3 +342,14 @@ extern "C" int dmet_bn_bwd_stats_f32(const float *x, const float *g_y, int64_t N
     DMET_LAUNCH_CHECK("bn_bwd_finalize_kernel");
     return 0;
 }
+
+extern "C" int dmet_bn_eval_stats_f32(const float *running_mean, const float *running_var, int H, float eps,
+                                      float *save_mean, float *save_invstd, dmet_stream_t stream)
+{
+    DMET_REQUIRE(bn_shape_ok(H), "dmet_bn_eval_stats_f32: H=%d must be a multiple of 4 in [4,64]", H);
+    DMET_REQUIRE(running_mean && running_var && save_mean && save_invstd, "dmet_bn_eval_stats_f32: null pointer");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(1), dim3(64), 0, as_stream(stream), running_mean, running_var, H, eps,
+                       save_mean, save_invstd);
+    DMET_LAUNCH_CHECK("bn_eval_stats_kernel");
+    return 0;
+}

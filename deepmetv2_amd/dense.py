@@ -90,10 +90,14 @@ class _BatchNorm(torch.autograd.Function):
     def forward(ctx, x, residual, weight, bias, running_mean, running_var, training, momentum, eps, tracked=None,
                 next_build=None):
         y = None
-        if next_build is not None and training and x.is_cuda and x.shape[1] == 32:
-            # the transform rides in the prep launch of the NEXT layer's graph build (which consumes y): statistics here,
-            # then one pass that writes y and cuts the build's tile records from it (dmet_bn_knn_local_dense_f32)
-            mean, invstd = _native.bn_stats(x, eps, momentum, running_mean, running_var, tracked)
+        if next_build is not None and x.is_cuda and x.shape[1] == 32 and (training or running_mean is not None):
+            # the transform rides in the prep launch of the NEXT layer's graph build (which consumes y): statistics here
+            # (eval mode: the running ones), then one pass that writes y and cuts the build's tile records from it
+            # (dmet_bn_knn_local_dense_f32; before the head: dmet_bn_head_fwd_f32)
+            if training:
+                mean, invstd = _native.bn_stats(x, eps, momentum, running_mean, running_var, tracked)
+            else:
+                mean, invstd = _native.bn_eval_stats(running_mean, running_var, eps)
             y = next_build(x, residual, weight.detach(), bias.detach(), mean, invstd)
             if y is None:   # that build takes another path after all: plain transform (the statistics are done)
                 y = (x - mean) * (weight.detach() * invstd) + bias.detach()
@@ -190,7 +194,7 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, residual: Optional[tor
     # next_build (DynamicEdgeConv.prebuild of the layer that consumes the result, training mode): the transform is fused
     # into that layer's graph build
     return _BatchNorm.apply(x, residual, bn.weight, bn.bias, rm, rv, training, float(bn.momentum), float(bn.eps), tracked,
-                            next_build if bn.training else None)
+                            next_build)
 
 
 # (emb, out) of the last dmet_bn_head_fwd_f32 call, until the head that consumes emb asks for it

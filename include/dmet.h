@@ -417,6 +417,10 @@ int dmet_bn_fwd_tracked_f32(const float *x, const float *residual, int64_t N, in
 int dmet_bn_bwd_stats_f32(const float *x, const float *g_y, int64_t N, int H, const float *save_mean,
                           const float *save_invstd, float *g_gamma, float *g_beta, float *mean_g, float *mean_gx,
                           void *ws, size_t ws_bytes, dmet_stream_t stream);
+/* Eval mode: save_mean = running_mean, save_invstd = 1 / sqrt(running_var + eps) (the constants dmet_bn_fwd_f32 uses with
+ * training == 0), for callers that apply the transform elsewhere (dmet_bn_knn_local_dense_f32, dmet_bn_head_fwd_f32). */
+int dmet_bn_eval_stats_f32(const float *running_mean, const float *running_var, int H, float eps, float *save_mean,
+                           float *save_invstd, dmet_stream_t stream);
 /* The statistics half of dmet_bn_fwd_tracked_f32 in training mode (column sums + finalize: save_mean, save_invstd,
  * running statistics, num_batches_tracked), for a caller that applies the transform elsewhere
  * (dmet_bn_knn_local_dense_f32 fuses it into the next layer's graph build). */

@@ -1265,3 +1265,12 @@ def test_model_with_fused_transform_matches_unfused(dev, monkeypatch):
         assert torch.equal(a, b)
     for a, b in zip(outs[0][2], outs[1][2]):
         assert torch.equal(a, b)
+    # eval mode (evaluate.py): the transforms use the running statistics, fused or not
+    model.eval()
+    ev = []
+    with torch.no_grad():
+        for fuse in ("1", "0"):
+            monkeypatch.setattr(conv, "BN_KNN_FUSE", fuse)
+            monkeypatch.setattr(dense, "HEAD_FUSE", fuse)
+            ev.append(model(*split_features(xd), None, bd).clone())
+    assert torch.equal(ev[0], ev[1])
