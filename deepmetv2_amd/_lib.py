@@ -26,6 +26,7 @@ SIGNATURES = {
     "dmet_knn_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "dmet_knn_local_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_adamw_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _d, _d, _d, _d, _d, _vp]),
+    "dmet_adamw_lr_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _d, _d, _d, _d, _vp]),
     "dmet_bn_knn_local_dense_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i,
                                          _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_knn_local_dense_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     "dmet_edgeconv_linear_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "dmet_edgeconv_linear_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_edgeconv_linear_bwd_add_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dmet_edgeconv_linear_bwd_add_j16_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_head_fwd_f32": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dmet_head_bwd_workspace_bytes": (_sz, [_i64]),
     "dmet_head_bwd_f32": (_i, [_vp, _i64] + [_vp] * 10 + [_vp, _sz, _vp]),

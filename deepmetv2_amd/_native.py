@@ -1022,15 +1022,18 @@ def bn_bwd(x: torch.Tensor, g_y: torch.Tensor, gamma: torch.Tensor, save_mean: t
 def edgeconv_linear_bwd(x: torch.Tensor, weight: torch.Tensor, g_out: torch.Tensor, arg: Optional[torch.Tensor],
                         gQ: torch.Tensor, want_bias: bool = True, g_add: Optional[torch.Tensor] = None):
     """(gx[N,32], gW[32,64], gb[32] or None) of the fused EdgeConv dense layer (H = 32) from g_out, arg and gQ;
-    g_add[N,32] (optional) is added to gx inside the kernel (the residual branch's gradient)."""
+    g_add[N,32] (optional) is added to gx inside the kernel (the residual branch's gradient).  arg: uint8 winning slots
+    (255 = none) or uint16 winner ids (0xFFFF = none): g_out is masked to 0 there (R3: such a node produced 0)."""
     dev = _require_device(x, weight, g_out, gQ)
     L = _lib.load()
     x = _f32c(x, "x"); weight = _f32c(weight, "weight"); g_out = _f32c(g_out, "g_out"); gQ = _f32c(gQ, "gQ")
     N, H = x.shape
     if H != 32 or tuple(weight.shape) != (32, 64) or g_out.shape != x.shape or gQ.shape != x.shape:
         raise ValueError("edgeconv_linear_bwd: built for x[N,32], weight[32,64]")
-    if arg is not None and (arg.dtype != torch.uint8 or arg.shape != x.shape or not arg.is_contiguous()):
-        raise ValueError("edgeconv_linear_bwd: arg must be contiguous uint8 [N,32]")
+    if arg is not None and (arg.dtype not in (torch.uint8, torch.uint16, torch.int16) or arg.shape != x.shape
+                            or not arg.is_contiguous()):
+        raise ValueError("edgeconv_linear_bwd: arg must be contiguous uint8 (slots) or uint16 (winner ids) [N,32]")
+    j16 = arg is not None and arg.dtype != torch.uint8
     gx = torch.empty_like(x)
     gW = torch.empty_like(weight)
     gb = torch.empty((H,), dtype=torch.float32, device=dev) if want_bias else None
@@ -1040,13 +1043,14 @@ def edgeconv_linear_bwd(x: torch.Tensor, weight: torch.Tensor, g_out: torch.Tens
             g_add = _f32c(g_add, "g_add")
             if g_add.shape != x.shape:
                 raise ValueError("edgeconv_linear_bwd: g_add must have the shape of x")
-        _lib.check(L.dmet_edgeconv_linear_bwd_add_f32(x.data_ptr(), weight.data_ptr(), g_out.data_ptr(),
-                                                      arg.data_ptr() if arg is not None else None, gQ.data_ptr(),
-                                                      g_add.data_ptr() if g_add is not None else None, N, H,
-                                                      gx.data_ptr(), gW.data_ptr(),
-                                                      gb.data_ptr() if gb is not None else None,
-                                                      ws.data_ptr(), ws.numel(), _stream(dev)),
-                   "dmet_edgeconv_linear_bwd_add_f32")
+        entry = L.dmet_edgeconv_linear_bwd_add_j16_f32 if j16 else L.dmet_edgeconv_linear_bwd_add_f32
+        _lib.check(entry(x.data_ptr(), weight.data_ptr(), g_out.data_ptr(),
+                         arg.data_ptr() if arg is not None else None, gQ.data_ptr(),
+                         g_add.data_ptr() if g_add is not None else None, N, H,
+                         gx.data_ptr(), gW.data_ptr(),
+                         gb.data_ptr() if gb is not None else None,
+                         ws.data_ptr(), ws.numel(), _stream(dev)),
+                   "dmet_edgeconv_linear_bwd_add_j16_f32" if j16 else "dmet_edgeconv_linear_bwd_add_f32")
     return gx, gW, gb
 
 

@@ -145,9 +145,10 @@ class _EdgeConvLinearMax(torch.autograd.Function):
         H = x.shape[1]
         g_out = g_out.contiguous()
         if ctx.j16:
-            # arg holds the winners' event-local ids (every row is non-empty: no mask needed further down)
+            # arg holds the winners' event-local ids.  A row can still be empty although the table has self loops: a
+            # query with a NaN / inf coordinate finds nobody, not even itself (0xFFFF, output 0 by R3) -- the node-level
+            # kernel masks g_out there from the same ids (dmet_edgeconv_linear_bwd_add_j16_f32)
             gQ = _native.gather_max_bwd_j16(g_out, arg, table.ptr)
-            arg = None
         elif H == 32 and g_out.dtype == torch.float32 and table.ptr is not None and GATHER_BWD_FORM != "reverse":
             # per-event LDS scatter with exact integer sums: no reverse index (radix sort) needed
             gQ = _native.gather_max_bwd_lds(g_out, arg, table.nbr, table.ptr, nbr_local=table.nbr_local)
@@ -157,12 +158,13 @@ class _EdgeConvLinearMax(torch.autograd.Function):
         if H == 32 and tuple(weight.shape) == (32, 64) and g_out.dtype == torch.float32:
             # one pass over the rows: gx, gW and gb on the fp32 matrix cores (csrc/edgeconv_bwd.hip)
             gx, gW, gb = _native.edgeconv_linear_bwd(x, weight.detach(), g_out,
-                                                     None if (table.dense or ctx.j16) else arg, gQ,
+                                                     None if table.dense else arg, gQ,
                                                      want_bias=ctx.has_bias, g_add=g_pass)
             return (gx if ctx.needs_input_grad[0] else None, gW if ctx.needs_input_grad[1] else None,
                     gb if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None, None, None)
         # nodes without any neighbour produced 0 (R3): no gradient reaches P there
-        gP = g_out if table.dense else g_out * (arg != 255).to(g_out.dtype)
+        none = 0xFFFF if ctx.j16 else 255
+        gP = g_out if table.dense else g_out * ((arg.long() & 0xFFFF) != none).to(g_out.dtype)
         Wd = weight[:, :H] - weight[:, H:]
         W2 = weight[:, H:]
         gx = gW = gb = None

@@ -34,6 +34,9 @@ __device__ __forceinline__ void ecb_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ARG16: `arg` holds uint16 winner ids per (node, channel) (0xFFFF = no winner: the counted radius gather's form,
+// dmet_gather_max_local_j16_f32) instead of uint8 winning slots (255 = none); the mask is the same.
+template <bool ARG16>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd_kernel(
     const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ g_out,
     const uint8_t *__restrict__ arg, const float *__restrict__ gQ, int64_t N, int64_t nodes_per_wave,
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd
     // software pipeline: the rows of the NEXT chunk are loaded into registers while the matrix products of the
     // current one run (two wavefronts per SIMD do not hide a global round trip per chunk by themselves)
     float4 np[kChunk / 8], nq[kChunk / 8], nx[kChunk / 8];
-    unsigned na[kChunk / 8];    // the four winning-slot bytes that go with np[g] (0: keep every channel)
+    uint2 na[kChunk / 8];       // the four winning-slot bytes (.x; ARG16: four 16-bit ids in .x, .y) that go with np[g]
     // The slot bytes are only LOADED here; the mask is applied when the rows go to LDS.  (Round 2, second session:
     // masking inside the prefetch consumed the loaded values on the spot -- s_waitcnt vmcnt(0) after each of the four
     // row groups, i.e. four exposed memory round trips per 32-node chunk: 8 us per chunk, matrix pipe 28 % busy.)
@@ -76,12 +79,15 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd
         for (int g = 0; g < kChunk / 8; ++g) {
             const int64_t i = base + g * 8 + lr;
             float4 vp = make_float4(0.f, 0.f, 0.f, 0.f), vq = vp, vx = vp;
-            unsigned va = 0u;
+            uint2 va = make_uint2(0u, 0u);
             if (i < hi) {
                 vp = reinterpret_cast<const float4 *>(g_out + i * kH)[lp];
                 vq = reinterpret_cast<const float4 *>(gQ + i * kH)[lp];
                 vx = reinterpret_cast<const float4 *>(x + i * kH)[lp];
-                if (arg) va = reinterpret_cast<const unsigned *>(arg + i * kH)[lp];
+                if (arg) {
+                    if (ARG16) va = reinterpret_cast<const uint2 *>(arg + i * kH * 2)[lp];
+                    else va.x = reinterpret_cast<const unsigned *>(arg + i * kH)[lp];
+                }
             }
             np[g] = vp; nq[g] = vq; nx[g] = vx; na[g] = va;
         }
@@ -93,10 +99,17 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd
         for (int g = 0; g < kChunk / 8; ++g) {
             const int r = g * 8 + lr;
             // nodes without any neighbour produced 0 (R3): no gradient reaches P there (slot byte 255)
-            if ((na[g] & 0xFFu) == 0xFFu) np[g].x = 0.f;
-            if (((na[g] >> 8) & 0xFFu) == 0xFFu) np[g].y = 0.f;
-            if (((na[g] >> 16) & 0xFFu) == 0xFFu) np[g].z = 0.f;
-            if ((na[g] >> 24) == 0xFFu) np[g].w = 0.f;
+            if (ARG16) {
+                if ((na[g].x & 0xFFFFu) == 0xFFFFu) np[g].x = 0.f;
+                if ((na[g].x >> 16) == 0xFFFFu) np[g].y = 0.f;
+                if ((na[g].y & 0xFFFFu) == 0xFFFFu) np[g].z = 0.f;
+                if ((na[g].y >> 16) == 0xFFFFu) np[g].w = 0.f;
+            } else {
+                if ((na[g].x & 0xFFu) == 0xFFu) np[g].x = 0.f;
+                if (((na[g].x >> 8) & 0xFFu) == 0xFFu) np[g].y = 0.f;
+                if (((na[g].x >> 16) & 0xFFu) == 0xFFu) np[g].z = 0.f;
+                if ((na[g].x >> 24) == 0xFFu) np[g].w = 0.f;
+            }
             *reinterpret_cast<float4 *>(&P[r * kPad + 4 * lp]) = np[g];
             *reinterpret_cast<float4 *>(&Q[r * kPad + 4 * lp]) = nq[g];
             *reinterpret_cast<float4 *>(&X[r * kPad + 4 * lp]) = nx[g];
@@ -379,16 +392,15 @@ extern "C" size_t dmet_edgeconv_linear_bwd_workspace_bytes(int64_t N, int H)
     return sizeof(float) * ((size_t)nw + kFinChunks) * kPartial + sizeof(int) * 64 + 512;
 }
 
-extern "C" int dmet_edgeconv_linear_bwd_add_f32(const float *x, const float *W, const float *g_out,
-                                                const uint8_t *arg, const float *gQ, const float *g_add, int64_t N,
-                                                int H, float *gx, float *gW, float *gb, void *ws, size_t ws_bytes,
-                                                dmet_stream_t stream)
+static int ecb_launch(const float *x, const float *W, const float *g_out, const uint8_t *arg, bool arg16, const float *gQ,
+                      const float *g_add, int64_t N, int H, float *gx, float *gW, float *gb, void *ws, size_t ws_bytes,
+                      dmet_stream_t stream)
 {
     DMET_REQUIRE(H == kH, "dmet_edgeconv_linear_bwd_f32: H=%d (only 32 is built)", H);
     DMET_REQUIRE(N > 0, "dmet_edgeconv_linear_bwd_f32: N=%lld", (long long)N);
     DMET_REQUIRE(x && W && g_out && gQ && gx && gW && ws, "dmet_edgeconv_linear_bwd_f32: null pointer");
     DMET_REQUIRE(aligned16(x) && aligned16(g_out) && aligned16(gQ) && aligned16(gx) && aligned16(g_add) &&
-                     (!arg || (reinterpret_cast<uintptr_t>(arg) & 3u) == 0),
+                     (!arg || (reinterpret_cast<uintptr_t>(arg) & (arg16 ? 7u : 3u)) == 0),
                  "dmet_edgeconv_linear_bwd_f32: rows must be 16-byte aligned");
     DMET_REQUIRE(ws_bytes >= dmet_edgeconv_linear_bwd_workspace_bytes(N, H), "dmet_edgeconv_linear_bwd_f32: workspace too small");
     int64_t nw;
@@ -397,13 +409,34 @@ extern "C" int dmet_edgeconv_linear_bwd_add_f32(const float *x, const float *W, 
     float *chunk_sums = partial + (size_t)nw * kPartial;
     int *fin_counters = reinterpret_cast<int *>(chunk_sums + (size_t)kFinChunks * kPartial);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(edgeconv_linear_bwd_kernel, dim3((unsigned)(nw / kWavesPerBlock)), dim3(kWave * kWavesPerBlock), 0, st,
-                       x, W, g_out, arg, gQ, N, npw, g_add, gx, partial, fin_counters);
+    if (arg16)
+        hipLaunchKernelGGL(edgeconv_linear_bwd_kernel<true>, dim3((unsigned)(nw / kWavesPerBlock)), dim3(kWave * kWavesPerBlock),
+                           0, st, x, W, g_out, arg, gQ, N, npw, g_add, gx, partial, fin_counters);
+    else
+        hipLaunchKernelGGL(edgeconv_linear_bwd_kernel<false>, dim3((unsigned)(nw / kWavesPerBlock)), dim3(kWave * kWavesPerBlock),
+                           0, st, x, W, g_out, arg, gQ, N, npw, g_add, gx, partial, fin_counters);
     DMET_LAUNCH_CHECK("edgeconv_linear_bwd_kernel");
     hipLaunchKernelGGL(edgeconv_linear_bwd_finalize_kernel, dim3(kFinGroups), dim3(1024), 0, st, partial, nw / kWavesPerBlock,
                        gW, gb);
     DMET_LAUNCH_CHECK("edgeconv_linear_bwd_finalize_kernel");
     return 0;
+}
+
+extern "C" int dmet_edgeconv_linear_bwd_add_f32(const float *x, const float *W, const float *g_out,
+                                                const uint8_t *arg, const float *gQ, const float *g_add, int64_t N,
+                                                int H, float *gx, float *gW, float *gb, void *ws, size_t ws_bytes,
+                                                dmet_stream_t stream)
+{
+    return ecb_launch(x, W, g_out, arg, false, gQ, g_add, N, H, gx, gW, gb, ws, ws_bytes, stream);
+}
+
+extern "C" int dmet_edgeconv_linear_bwd_add_j16_f32(const float *x, const float *W, const float *g_out,
+                                                    const uint16_t *argj, const float *gQ, const float *g_add, int64_t N,
+                                                    int H, float *gx, float *gW, float *gb, void *ws, size_t ws_bytes,
+                                                    dmet_stream_t stream)
+{
+    return ecb_launch(x, W, g_out, reinterpret_cast<const uint8_t *>(argj), true, gQ, g_add, N, H, gx, gW, gb, ws, ws_bytes,
+                      stream);
 }
 
 extern "C" int dmet_edgeconv_linear_bwd_f32(const float *x, const float *W, const float *g_out, const uint8_t *arg,

@@ -130,8 +130,12 @@ inline unsigned bit_length(uint64_t v)
 __global__ __launch_bounds__(1024) void adamw_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                      float *__restrict__ m, float *__restrict__ v,
                                                      float *__restrict__ step, double *__restrict__ bias_pow, int64_t n,
-                                                     double lr, double beta1, double beta2, double eps, double weight_decay)
+                                                     double lr, double beta1, double beta2, double eps, double weight_decay,
+                                                     const double *__restrict__ lr_dev)
 {
+    // the learning rate may live on the device (a scheduler such as train.py:76's ReduceLROnPlateau changes it between
+    // steps; a launch replayed from a hipGraph must see the new value): a wave-uniform (scalar) load
+    if (lr_dev) lr = lr_dev[0];
     __shared__ float sh[2];
     int64_t i = threadIdx.x;
     float gi = 0.f, pi = 0.f, mi = 0.f, vi = 0.f;
@@ -267,7 +271,20 @@ extern "C" int dmet_adamw_f32(float *param, const float *grad, float *exp_avg, f
     if (n == 0) return 0;
     DMET_REQUIRE(param && grad && exp_avg && exp_avg_sq && step && bias_pow, "dmet_adamw_f32: null pointer");
     hipLaunchKernelGGL(adamw_kernel, dim3(1), dim3(1024), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, step,
-                       bias_pow, n, lr, beta1, beta2, eps, weight_decay);
+                       bias_pow, n, lr, beta1, beta2, eps, weight_decay, (const double *)nullptr);
+    DMET_LAUNCH_CHECK("adamw_kernel");
+    return 0;
+}
+
+extern "C" int dmet_adamw_lr_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step,
+                                 double *bias_pow, int64_t n, const double *lr_dev, double beta1, double beta2, double eps,
+                                 double weight_decay, dmet_stream_t stream)
+{
+    DMET_REQUIRE(n >= 0, "dmet_adamw_lr_f32: n=%lld", (long long)n);
+    if (n == 0) return 0;
+    DMET_REQUIRE(param && grad && exp_avg && exp_avg_sq && step && bias_pow && lr_dev, "dmet_adamw_lr_f32: null pointer");
+    hipLaunchKernelGGL(adamw_kernel, dim3(1), dim3(1024), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, step,
+                       bias_pow, n, 0.0, beta1, beta2, eps, weight_decay, lr_dev);
     DMET_LAUNCH_CHECK("adamw_kernel");
     return 0;
 }

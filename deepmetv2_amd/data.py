@@ -32,6 +32,9 @@ class Batch:
     batch: torch.Tensor    # [N] int64, sorted
     ptr: torch.Tensor      # [B+1] int64
     max_nodes: int
+    # events of the GLOBAL batch this one is a rank's shard of (None: not sharded); parallel.train_step weights the
+    # rank's gradient by num_graphs / global_graphs
+    global_graphs: Optional[int] = None
 
     @property
     def num_graphs(self) -> int:
@@ -44,13 +47,13 @@ class Batch:
     def to(self, device, non_blocking: bool = False) -> "Batch":
         b = Batch(self.x.to(device, non_blocking=non_blocking), self.y.to(device, non_blocking=non_blocking),
                   self.batch.to(device, non_blocking=non_blocking), self.ptr.to(device, non_blocking=non_blocking),
-                  self.max_nodes)
+                  self.max_nodes, self.global_graphs)
         register_batch(b.batch, b.ptr, b.num_graphs, max_nodes=b.max_nodes)
         return b
 
     def pin_memory(self) -> "Batch":
         return Batch(self.x.pin_memory(), self.y.pin_memory(), self.batch.pin_memory(), self.ptr.pin_memory(),
-                     self.max_nodes)
+                     self.max_nodes, self.global_graphs)
 
 
 def collate(events: Sequence[Tuple[torch.Tensor, torch.Tensor]]) -> Batch:
@@ -89,32 +92,72 @@ def events_from_padded(x_pad, y) -> List[Tuple[torch.Tensor, torch.Tensor]]:
 
 class EventLoader:
     """Minimal stand-in for `DataLoader(subset, batch_size, shuffle=False)` (data_loader.py:107-110): yields Batches
-    of consecutive events; `split()` reproduces the reference's seeded random train/validation split (:95-104)."""
+    of consecutive events; `split()` reproduces the reference's seeded random train/validation split (:95-104).
+
+    Data parallel (the role a `DistributedSampler` would play next to data_loader.py:107-110; the reference itself is
+    single-process): with `world > 1` every rank walks the SAME sequence of global batches of `batch_size` events and
+    yields its own shard of each -- `balance="count"`: contiguous blocks whose sizes differ by at most one
+    (`parallel.shard_range`); `balance="cost"`: greedy longest-first by n^2, the kNN build's cost, for ragged batches
+    (`parallel.balanced_shards`; ranks then hold unequal event counts).  Every shard carries `global_graphs`, from which
+    `parallel.train_step(..., global_events=b.global_graphs)` weights the rank's gradient, so N ranks walk the gradient
+    trajectory of the single-process global batch (up to per-rank BatchNorm statistics).  A trailing global batch with
+    fewer events than ranks is dropped (a rank without events has no step to run)."""
 
     def __init__(self, events: Sequence[Tuple[torch.Tensor, torch.Tensor]], batch_size: int,
-                 indices: Optional[Sequence[int]] = None, device: Optional[torch.device] = None):
+                 indices: Optional[Sequence[int]] = None, device: Optional[torch.device] = None,
+                 rank: int = 0, world: int = 1, balance: str = "count"):
+        if balance not in ("count", "cost"):
+            raise ValueError(f"balance must be 'count' or 'cost', got {balance!r}")
+        if world < 1 or not 0 <= rank < world:
+            raise ValueError(f"bad rank / world: {rank} / {world}")
+        if world > int(batch_size):
+            raise ValueError(f"a global batch of {batch_size} events cannot be sharded over {world} ranks")
         self.events = events
         self.batch_size = int(batch_size)
         self.indices = list(range(len(events))) if indices is None else list(indices)
         self.device = device
+        self.rank, self.world, self.balance = int(rank), int(world), balance
+
+    def _global_batches(self) -> List[List[int]]:
+        out = [self.indices[s:s + self.batch_size] for s in range(0, len(self.indices), self.batch_size)]
+        if self.world > 1 and out and len(out[-1]) < self.world:
+            out.pop()
+        return out
 
     def __len__(self) -> int:
-        return (len(self.indices) + self.batch_size - 1) // self.batch_size
+        return len(self._global_batches())
+
+    def shard(self, ids: Sequence[int]) -> List[int]:
+        """The events of one global batch that this rank computes (in the batch's order)."""
+        if self.world == 1:
+            return list(ids)
+        from .parallel import balanced_shards, shard_range
+        if self.balance == "count":
+            return [ids[i] for i in shard_range(len(ids), self.rank, self.world)]
+        costs = [float(self.events[i][0].shape[0]) ** 2 for i in ids]
+        return [ids[i] for i in balanced_shards(costs, self.world)[self.rank]]
 
     def __iter__(self) -> Iterator[Batch]:
-        for s in range(0, len(self.indices), self.batch_size):
-            b = collate([self.events[i] for i in self.indices[s:s + self.batch_size]])
+        for ids in self._global_batches():
+            mine = self.shard(ids)
+            if not mine:
+                # cost balancing can leave a rank empty only if the batch has fewer events than ranks (dropped above)
+                raise RuntimeError("a rank received no events of a global batch")
+            b = collate([self.events[i] for i in mine])
+            if self.world > 1:
+                b.global_graphs = len(ids)
             yield b.to(self.device) if self.device is not None else b
 
     @staticmethod
-    def split(events, batch_size: int, validation_split: float = 0.2, seed: int = 42, device=None):
+    def split(events, batch_size: int, validation_split: float = 0.2, seed: int = 42, device=None, rank: int = 0,
+              world: int = 1, balance: str = "count"):
         n = len(events)
         n_val = int(np.floor(validation_split * n))
         g = torch.Generator().manual_seed(seed)
         perm = torch.randperm(n, generator=g).tolist()
         train, val = perm[: n - n_val], perm[n - n_val:]
-        return {"train": EventLoader(events, batch_size, train, device),
-                "test": EventLoader(events, batch_size, val, device)}
+        return {"train": EventLoader(events, batch_size, train, device, rank, world, balance),
+                "test": EventLoader(events, batch_size, val, device, rank, world, balance)}
 
 
 class DeviceLoader:
@@ -145,7 +188,8 @@ class DeviceLoader:
             pinned = hb if hb.x.is_pinned() else hb.pin_memory()     # torch's caching host allocator reuses the blocks
             with torch.cuda.stream(copy_stream):
                 db = Batch(pinned.x.to(dev, non_blocking=True), pinned.y.to(dev, non_blocking=True),
-                           pinned.batch.to(dev, non_blocking=True), pinned.ptr.to(dev, non_blocking=True), hb.max_nodes)
+                           pinned.batch.to(dev, non_blocking=True), pinned.ptr.to(dev, non_blocking=True), hb.max_nodes,
+                           hb.global_graphs)
                 done = torch.cuda.Event()
                 done.record(copy_stream)
             inflight.append((pinned, db, done))

@@ -86,7 +86,13 @@ class FlatModule:
 
 
 class GradSync:
-    """DDP semantics for a FlatModule: broadcast parameters+buffers from rank 0 once, then average gradients."""
+    """DDP semantics for a FlatModule: broadcast parameters+buffers from rank 0 once, then combine the gradients.
+
+    The loss is a MEAN over events (model/net.py:60), so the gradient of the global batch is
+    sum_r (B_r / B) grad_r with B_r the events of rank r and grad_r the gradient of that rank's own mean.  Each rank
+    therefore seeds its backward pass with its share B_r / B (`loss_seed`; 1 / world unless `set_share` says otherwise:
+    shards balanced by cost hold unequal event counts) and the collective is a plain SUM -- no division kernel after
+    the all-reduce, and unequal shards are weighted correctly."""
 
     def __init__(self, flat: FlatModule, group: Optional[dist.ProcessGroup] = None):
         self.flat = flat
@@ -95,6 +101,24 @@ class GradSync:
         # same RCCL calls as N ranks do); without any group the step has no collective at all
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.active else 1
+        self._share = 1.0 / self.world
+        self._seed: Optional[torch.Tensor] = None
+
+    def set_share(self, local_events: int, global_events: int) -> None:
+        """This rank holds `local_events` of the `global_events` events of the step's global batch."""
+        if local_events < 0 or global_events <= 0 or local_events > global_events:
+            raise ValueError(f"bad shares: {local_events} of {global_events} events")
+        share = local_events / global_events
+        if share != self._share:
+            self._share = share
+            if self._seed is not None:
+                self._seed.fill_(share)      # in place: a captured backward pass reads this tensor
+
+    def loss_seed(self, loss: torch.Tensor) -> torch.Tensor:
+        """d(global loss) / d(this rank's loss): the gradient `loss.backward` starts from (a cached device scalar)."""
+        if self._seed is None or self._seed.device != loss.device or self._seed.dtype != loss.dtype:
+            self._seed = torch.full((), self._share, device=loss.device, dtype=loss.dtype)
+        return self._seed
 
     def broadcast_state(self, src: int = 0) -> None:
         if not self.active:
@@ -104,39 +128,29 @@ class GradSync:
             dist.broadcast(b, src=src, group=self.group)
 
     def average_gradients(self) -> None:
-        """Loss is a mean over the rank's events; with equal events per rank the mean of rank-gradients is the
-        gradient of the global mean (model/net.py:60).  One all-reduce of the flat fp32 gradient (26.6 KB)."""
+        """One all-reduce(SUM) of the flat fp32 gradient (26.6 KB).  The ranks' backward passes were seeded with their
+        shares of the global batch (`loss_seed`), so the sum IS the gradient of the global mean."""
         if not self.active:
             return
         dist.all_reduce(self.flat.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-        if self.world > 1:
-            self.flat.flat_grad.div_(self.world)
-
-
-_ONES = {}
-
-
-def _one_like(loss: torch.Tensor) -> torch.Tensor:
-    """A cached 1.0 of the loss's device and dtype: `loss.backward()` would fill a fresh one with a kernel every step."""
-    key = (loss.device, loss.dtype)
-    t = _ONES.get(key)
-    if t is None:
-        t = _ONES[key] = torch.ones((), device=loss.device, dtype=loss.dtype)
-    return t
 
 
 def train_step(model: torch.nn.Module, flat: FlatModule, sync: GradSync, optimizer: torch.optim.Optimizer,
                x: torch.Tensor, y: torch.Tensor, batch: torch.Tensor, ptr: Optional[torch.Tensor] = None,
-               edge_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+               edge_index: Optional[torch.Tensor] = None, global_events: Optional[int] = None) -> torch.Tensor:
     """One training step, the sequence of /root/reference/train.py:40-52:
-    zero_grad -> split features -> model -> loss_fn -> backward -> (all-reduce) -> optimizer.step."""
+    zero_grad -> split features -> model -> loss_fn -> backward -> (all-reduce) -> optimizer.step.
+    `global_events`: events of the step's global batch over all ranks when the ranks hold unequal numbers of them
+    (`data.EventLoader(..., rank, world, balance="cost")` reports it as `Batch.global_graphs`); None: equal shares."""
     from .model import loss_fn, split_features
 
+    if global_events is not None:
+        sync.set_share(int(y.shape[0]), int(global_events))
     flat.zero_grad()
     x_cont, x_cat = split_features(x, lazy_cat=True)
     weights = model(x_cont, x_cat, edge_index, batch)
     loss = loss_fn(weights, x, y, batch, ptr=ptr)
-    loss.backward(_one_like(loss))
+    loss.backward(sync.loss_seed(loss))
     flat.gather_grads()
     sync.average_gradients()
     optimizer.step()
@@ -164,7 +178,7 @@ class GraphedTrainStep:
             x_cont, x_cat = split_features(self.x, lazy_cat=True)
             graph = graph_fn(self.x) if graph_fn is not None else None
             loss = loss_fn(model(x_cont, x_cat, graph, self.batch), self.x, self.y, self.batch, ptr=self.ptr)
-            loss.backward(_one_like(loss))
+            loss.backward(sync.loss_seed(loss))
             flat.gather_grads()
             return loss.detach()
 
@@ -190,5 +204,10 @@ class GraphedTrainStep:
     def __call__(self) -> torch.Tensor:
         self.graph_a.replay()
         self.sync.average_gradients()
+        # a scheduler may have changed the learning rate since the last replay (train.py:58,76): optimizers that keep
+        # it on the device (optim.FlatAdamW) push the new value before the captured step runs
+        push = getattr(self.opt, "sync_hyper", None)
+        if push is not None:
+            push()
         self.graph_b.replay()
         return self.loss

@@ -312,6 +312,11 @@ int dmet_met_reduce_bwd_f32(const float *g_met, const float *x, int64_t x_stride
 int dmet_adamw_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, double *bias_pow,
                    int64_t n, double lr, double beta1, double beta2, double eps, double weight_decay,
                    dmet_stream_t stream);
+/* Same with the learning rate read from device memory (lr_dev[0], double): the reference drives it with
+ * ReduceLROnPlateau (train.py:76, stepped at train.py:58), and a launch captured in a hipGraph must see the change. */
+int dmet_adamw_lr_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float *step, double *bias_pow,
+                      int64_t n, const double *lr_dev, double beta1, double beta2, double eps, double weight_decay,
+                      dmet_stream_t stream);
 /* loss[0] = 0.5 * mean_b((met[b,0] + truth[b,0])^2 + (met[b,1] + truth[b,1])^2)  (model/net.py:58-61) and
  * g_met[B,2] = d loss / d met, one launch, fixed summation order. */
 int dmet_met_loss_f32(const float *met, const float *truth, int B, float *loss, float *g_met, dmet_stream_t stream);
@@ -394,6 +399,13 @@ int dmet_edgeconv_linear_bwd_f32(const float *x, const float *W, const float *g_
 int dmet_edgeconv_linear_bwd_add_f32(const float *x, const float *W, const float *g_out, const uint8_t *arg,
                                      const float *gQ, const float *g_add, int64_t N, int H, float *gx, float *gW,
                                      float *gb, void *ws, size_t ws_bytes, dmet_stream_t stream);
+/* Same for the winner-id form of the counted radius gather (dmet_gather_max_local_j16_f32 / _counted_lds_j16_f32:
+ * train.py:48's radius graph feeding model/graph_met_network.py:65): argj[N,H] uint16 event-local winner ids,
+ * 0xFFFF = the node had no neighbour at all (a query with a NaN / inf coordinate finds nobody, not even itself);
+ * gP is masked to 0 there exactly as for arg == 255 above.  argj may be NULL (no masking). */
+int dmet_edgeconv_linear_bwd_add_j16_f32(const float *x, const float *W, const float *g_out, const uint16_t *argj,
+                                         const float *gQ, const float *g_add, int64_t N, int H, float *gx, float *gW,
+                                         float *gb, void *ws, size_t ws_bytes, dmet_stream_t stream);
 
 /* ---- N3 (third piece): BatchNorm1d over the nodes, optionally fused with the residual add ---------------
  * model/graph_met_network.py:32,39,58,66: bn_all(...) and emb + bn(conv(...)).  x[N,H] row-major, H a multiple of 4

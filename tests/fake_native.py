@@ -253,7 +253,8 @@ def bn_bwd(x, g_y, gamma, mean, invstd):
 
 def edgeconv_linear_bwd(x, weight, g_out, arg, gQ, want_bias=True, g_add=None):
     H = x.shape[1]
-    gP = g_out if arg is None else g_out * (arg != 255).to(g_out.dtype)
+    none = 255 if (arg is not None and arg.dtype == torch.uint8) else 0xFFFF
+    gP = g_out if arg is None else g_out * ((arg.long() & 0xFFFF) != none).to(g_out.dtype)
     Wd, W2 = weight[:, :H] - weight[:, H:], weight[:, H:]
     gx = gP @ Wd + gQ @ W2
     if g_add is not None:

@@ -458,6 +458,43 @@ def test_edgeconv_static_graph_from_radius(dev):
     assert torch.equal(table.edge_index("source_to_target"), ei)
 
 
+def test_edgeconv_radius_backward_with_nonfinite_coordinates(dev):
+    """Round 3 (advisor finding): a query with a NaN / inf coordinate finds nobody, not even itself, although the table
+    was built with self loops -- its row is empty, its output 0 (R3) and NO gradient may reach the dense layer through
+    it.  The winner-id form of the counted gather (the default of the static flow) used to skip that mask."""
+    import deepmetv2_amd as dm
+    from oracle import ref_ops
+    g = torch.Generator().manual_seed(14)
+    sizes = [220, 300]
+    N = sum(sizes)
+    etaphi = torch.rand(N, 2, generator=g) * 3
+    etaphi[5, 0] = float("nan")
+    etaphi[17, 1] = float("inf")
+    etaphi[250, 0] = float("-inf")
+    etaphi[N - 1] = float("nan")
+    emb = torch.randn(N, 32, generator=g)
+    gup = torch.randn(N, 32, generator=g)
+    batch = torch.repeat_interleave(torch.arange(2), torch.tensor(sizes))
+    lin = torch.nn.Sequential(torch.nn.Linear(64, 32))
+    ei_ref = ref_ops.radius_graph(etaphi, 0.4, batch, loop=True, max_num_neighbors=255)
+    xr = emb.clone().requires_grad_(True)
+    ref = ref_ops.edge_conv(xr, ei_ref, lin)
+    ref.backward(gup)
+    gw_ref, gb_ref, gx_ref = lin[0].weight.grad.clone(), lin[0].bias.grad.clone(), xr.grad.clone()
+    lin.zero_grad()
+    assert bool((ref[[5, 17, 250, N - 1]] == 0).all())
+    conv = dm.EdgeConv(nn=lin).to(dev)
+    table = dm.radius_table(etaphi.to(dev), 0.4, batch.to(dev), loop=True, max_num_neighbors=255)
+    assert torch.equal(table.edge_index("source_to_target").cpu(), ei_ref)
+    xd = emb.to(dev).requires_grad_(True)
+    out = conv(xd, table)
+    out.backward(gup.to(dev))
+    _close(out.detach().cpu(), ref.detach())
+    _close(xd.grad.cpu(), gx_ref, rtol=1e-4, atol=1e-5 * max(1.0, float(gx_ref.abs().max())))
+    _close(lin[0].weight.grad.cpu(), gw_ref, rtol=1e-4, atol=1e-5 * max(1.0, float(gw_ref.abs().max())))
+    _close(lin[0].bias.grad.cpu(), gb_ref, rtol=1e-4, atol=1e-5 * max(1.0, float(gb_ref.abs().max())))
+
+
 @pytest.mark.parametrize("reverse_route", [False, True])
 def test_counted_radius_table_consumers_go_by_cnt(dev, monkeypatch, reverse_route):
     """N1: radius tables are built WITHOUT the -1 fill of their unused slots (dmet_radius_counted_f32).  Every consumer
@@ -885,14 +922,17 @@ def test_training_trajectory_matches_oracle(dev):
             torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-4, msg=lambda m, n=name: f"{n}: {m}")
 
 
-@pytest.mark.parametrize("flow", ["dynamic", "static-table"])
-def test_graphed_train_step_matches_eager(dev, flow):
+@pytest.mark.parametrize("flow,optimizer", [("dynamic", "torch"), ("static-table", "torch"), ("dynamic", "flat")])
+def test_graphed_train_step_matches_eager(dev, flow, optimizer):
     """H1: the step replayed as two hipGraphs (parallel.GraphedTrainStep) walks the same parameter trajectory as the
     eager step (every kernel on the path is deterministic, so the comparison is bitwise) -- for the kNN flow and for
-    the reference's active flow with the radius table built inside the captured step (train.py:45-48)."""
+    the reference's active flow with the radius table built inside the captured step (train.py:45-48); with torch's
+    capturable AdamW and with optim.FlatAdamW, whose learning rate is changed between replays the way
+    ReduceLROnPlateau (train.py:58,76) would."""
     import deepmetv2_amd as dm
     from deepmetv2_amd import synth
     from deepmetv2_amd.model import Net
+    from deepmetv2_amd.optim import FlatAdamW
     from deepmetv2_amd.parallel import FlatModule, GradSync, GraphedTrainStep, train_step
     sizes = [700, 90, 1300]
     x, y, batch, ptr = synth.make_events(sizes, seed=5, device=dev)
@@ -908,7 +948,10 @@ def test_graphed_train_step_matches_eager(dev, flow):
         torch.manual_seed(1)
         model = Net(8, 3, graph="dynamic" if flow == "dynamic" else "static", k=16).to(dev).train()
         flat = FlatModule(model); sync = GradSync(flat)
-        opt = torch.optim.AdamW([flat.flat_param], lr=1e-3, capturable=True)
+        if optimizer == "flat":
+            opt = FlatAdamW([flat.flat_param], lr=1e-3)
+        else:
+            opt = torch.optim.AdamW([flat.flat_param], lr=1e-3, capturable=True)
         if graphed:
             p0 = flat.flat_param.detach().clone()
             bufs0 = [b.detach().clone() for b in model.buffers()]
@@ -919,13 +962,17 @@ def test_graphed_train_step_matches_eager(dev, flow):
                 for b, b0 in zip(model.buffers(), bufs0):
                     b.copy_(b0)
                 for st in opt.state.values():
-                    for v in st.values():
-                        if torch.is_tensor(v):
+                    for name, v in st.items():
+                        if name == "bias_pow":
+                            v.fill_(1.0)          # beta^0
+                        elif torch.is_tensor(v) and name != "lr_dev":
                             v.zero_()
-            for _ in range(3):
+        for it in range(4):
+            if it == 2 and optimizer == "flat":
+                opt.param_groups[0]["lr"] = 2.5e-4     # a scheduler steps between two training steps
+            if graphed:
                 loss = step()
-        else:
-            for _ in range(3):
+            else:
                 loss = train_step(model, flat, sync, opt, x, y, batch, ptr,
                                   edge_index=graph_fn(x) if graph_fn is not None else None)
         torch.cuda.synchronize()
@@ -1205,6 +1252,40 @@ def test_flat_adamw_matches_torch_adamw(dev, wd):
     m_ref, v_ref = ob.state[pb]["exp_avg"], ob.state[pb]["exp_avg_sq"]
     torch.testing.assert_close(st["exp_avg"].cpu().double(), m_ref, rtol=1e-5, atol=1e-6 * float(m_ref.abs().max()))
     torch.testing.assert_close(st["exp_avg_sq"].cpu().double(), v_ref, rtol=1e-5, atol=1e-6 * float(v_ref.abs().max()))
+
+
+def test_flat_adamw_continues_a_torch_adamw_state(dev):
+    """A checkpoint written with torch.optim.AdamW (utils.py:59-77 saves `optim_dict`; state keys step / exp_avg /
+    exp_avg_sq only) loads into FlatAdamW: beta^step and the device learning rate are rebuilt, the run continues on the
+    trajectory of the fp64 reference; FlatAdamW's own state_dict round-trips too."""
+    from deepmetv2_amd.optim import FlatAdamW
+    g = torch.Generator().manual_seed(9)
+    p0 = torch.randn(6641, generator=g)
+    pt = torch.nn.Parameter(p0.clone().to(dev))
+    pb = torch.nn.Parameter(p0.clone().double())
+    ot = torch.optim.AdamW([pt], lr=1e-3)
+    ob = torch.optim.AdamW([pb], lr=1e-3)
+    grads = [torch.randn(6641, generator=g) * (10.0 ** ((it % 4) - 2)) for it in range(14)]
+    for it in range(5):
+        pt.grad = grads[it].to(dev); pb.grad = grads[it].double()
+        ot.step(); ob.step()
+    pa = torch.nn.Parameter(pt.detach().clone())
+    oa = FlatAdamW([pa], lr=1e-3)
+    oa.load_state_dict(ot.state_dict())
+    for it in range(5, 10):
+        pa.grad = grads[it].to(dev); pb.grad = grads[it].double()
+        oa.step(); ob.step()
+    assert float(oa.state[pa]["step"]) == 10.0
+    torch.testing.assert_close(pa.detach().cpu().double(), pb.detach(), rtol=2e-6, atol=4e-7)
+    # round trip of its own state (load_state_dict casts the double state tensors to fp32: they are rebuilt)
+    pc = torch.nn.Parameter(pa.detach().clone())
+    oc = FlatAdamW([pc], lr=1e-3)
+    oc.load_state_dict(oa.state_dict())
+    for it in range(10, 14):
+        pa.grad = grads[it].to(dev); pc.grad = grads[it].to(dev); pb.grad = grads[it].double()
+        oa.step(); oc.step(); ob.step()
+    torch.testing.assert_close(pc.detach().cpu().double(), pb.detach(), rtol=2e-6, atol=6e-7)
+    torch.testing.assert_close(pc.detach(), pa.detach(), rtol=1e-6, atol=1e-7)
 
 
 @pytest.mark.parametrize("sizes,with_res", [([4500, 4500, 300, 2100], True), ([50, 450, 800, 0, 3], True), ([3000, 77], False)])
