@@ -66,7 +66,6 @@ class FlatAdamW(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = _lib.load()
-        capturing = torch.cuda.is_current_stream_capturing()
         for group in self.param_groups:
             b1, b2 = group["betas"]
             for p in group["params"]:
@@ -77,7 +76,7 @@ class FlatAdamW(torch.optim.Optimizer):
                         and g.dtype == torch.float32):
                     raise TypeError("FlatAdamW: parameters and gradients must be contiguous float32 GPU tensors")
                 st = self._state_of(p, group)
-                if not capturing and st["lr_host"] != float(group["lr"]):
+                if st["lr_host"] != float(group["lr"]) and not torch.cuda.is_current_stream_capturing():
                     st["lr_dev"].fill_(float(group["lr"]))
                     st["lr_host"] = float(group["lr"])
                 with _native._on(p.device):
