@@ -46,9 +46,18 @@ def parse_args():
     ap.add_argument("--ragged", type=int, nargs=2, metavar=("LO", "HI"), default=None,
                     help="BASELINE configs[4]: event sizes drawn uniformly from [LO, HI] (seeded) instead of --nodes")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
-    ap.add_argument("--hip-graph", action="store_true",
-                    help="replay the step as two hipGraphs around the gradient all-reduce (launch-bound small batches; "
-                         "per-kernel HIP-event timing, hence the roofline block, is not available in this mode)")
+    ap.add_argument("--hip-graph", dest="hip_graph", action="store_true", default=None,
+                    help="replay the step as two hipGraphs around the gradient all-reduce (per-kernel HIP-event figures "
+                         "then come from a few eager steps after the timed region).  Default: on for --gpus N > 1 (the "
+                         "eager step costs the launch thread ~0.8 of the GPU time: N ranks on one host plus the RCCL "
+                         "proxy threads have no headroom for it), off at N = 1")
+    ap.add_argument("--no-hip-graph", dest="hip_graph", action="store_false")
+    ap.add_argument("--model", choices=["fused", "stock-knn-graph", "stock-dynamic"], default="fused",
+                    help="fused: this repo's model.Net (fused encoder / head kernels, BatchNorm riders, FlatAdamW); "
+                         "stock-*: deepmetv2_amd/stock_model.py -- stock torch.nn layers around ONLY the public operators, "
+                         "torch.optim.AdamW on model.parameters(): what the reference's training loop gets with three "
+                         "import lines changed (stock-knn-graph: EdgeConv over knn_graph(...), graph_met_network.py:63; "
+                         "stock-dynamic: DynamicEdgeConv; with --graph static: EdgeConv over radius_graph, :65)")
     ap.add_argument("--optimizer", choices=["dmet", "torch"], default="dmet",
                     help="AdamW as one HIP launch on the flat parameter tensor (default) or torch.optim.AdamW(fused=True)")
     ap.add_argument("--input", choices=["device", "host"], default="device",
@@ -227,7 +236,7 @@ def gather_roofline(args, ksum, ev_overhead_ms, model, x, batch, ptr, sizes, sta
     # [+ arg: one byte per channel when training].  ids: k*4 per node for the fixed-k kNN table (int32, the API's
     # internal width; the LDS kernel reads a uint16 copy, not credited), cnt_i*4 for a counted radius table.
     with torch.no_grad():
-        emb = g.embed(*split_features(x)).contiguous()
+        emb = (g.embed if hasattr(g, "embed") else g.encode)(*split_features(x)).contiguous()
         if args.graph == "dynamic":
             table = dm.knn_table(emb, k, batch, loop=True)
             id_bytes = float(N) * k * 4
@@ -335,6 +344,15 @@ def main():
     from deepmetv2_amd.model import Net, loss_fn, split_features
     from deepmetv2_amd.parallel import FlatModule, GradSync, train_step
 
+    stock = args.model != "fused"
+    if stock and (world > 1 or args.mode != "train" or args.input != "device" or args.dtype != "f32"
+                  or args.graph == "static-table"):
+        raise SystemExit("--model stock-* times the reference's own single-process training loop: N = 1, train, fp32, "
+                         "--graph dynamic | static")
+    if args.hip_graph is None:
+        args.hip_graph = bool(world > 1 and args.mode == "train" and args.input == "device" and args.graph != "static"
+                              and not stock)
+    hip_graph_note = None
     B, n, k = args.events_per_gpu, args.nodes, args.k
     sizes = [n] * B if args.ragged is None else synth.ragged_sizes(B, args.ragged[0], args.ragged[1], seed=1234 + rank)
     x, y, batch, ptr = synth.make_events(sizes, seed=1234 + rank, device=dev)
@@ -342,17 +360,28 @@ def main():
     N = x.shape[0]
 
     torch.manual_seed(0)
-    model = Net(8, 3, graph="dynamic" if args.graph == "dynamic" else "static", k=k, edge_dtype=torch.bfloat16 if args.dtype == "bf16" else None).to(dev)
-    flat = FlatModule(model)
-    sync = GradSync(flat)
-    sync.broadcast_state(0)
-    # AdamW (train.py:75) on the flat parameter vector: one launch (deepmetv2_amd.optim.FlatAdamW = dmet_adamw_f32, device-side
-    # step counter: capturable); --optimizer torch: torch.optim.AdamW(fused=True), two launches, 16 us more per step
-    if args.optimizer == "torch":
-        opt = torch.optim.AdamW([flat.flat_param], lr=1e-3, fused=True, capturable=args.hip_graph)
+    if stock:
+        from deepmetv2_amd import stock_model
+        variant = "static" if args.graph == "static" else args.model[len("stock-"):].replace("-", "_")
+        model = stock_model.StockNet(dm, 8, 3, variant=variant, k=k).to(dev)
+        flat = sync = None
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)          # train.py:75 as written
+        optimizer_name = "torch.optim.AdamW(model.parameters(), lr=1e-3)"
     else:
-        from deepmetv2_amd.optim import FlatAdamW
-        opt = FlatAdamW([flat.flat_param], lr=1e-3)
+        model = Net(8, 3, graph="dynamic" if args.graph == "dynamic" else "static", k=k, edge_dtype=torch.bfloat16 if args.dtype == "bf16" else None).to(dev)
+        flat = FlatModule(model)
+        sync = GradSync(flat)
+        sync.broadcast_state(0)
+        # AdamW (train.py:75) on the flat parameter vector: one launch (deepmetv2_amd.optim.FlatAdamW = dmet_adamw_lr_f32,
+        # device-side step counter and learning rate: capturable); --optimizer torch: torch.optim.AdamW(fused=True), two
+        # launches, 16 us more per step
+        if args.optimizer == "torch":
+            opt = torch.optim.AdamW([flat.flat_param], lr=1e-3, fused=True, capturable=args.hip_graph)
+            optimizer_name = "torch.optim.AdamW(fused=True) on the flat parameter tensor"
+        else:
+            from deepmetv2_amd.optim import FlatAdamW
+            opt = FlatAdamW([flat.flat_param], lr=1e-3)
+            optimizer_name = "deepmetv2_amd.optim.FlatAdamW (one HIP launch) on the flat parameter tensor"
 
     if args.mode == "train":
         model.train()
@@ -366,7 +395,11 @@ def main():
                 return dm.radius_table(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255)
             return dm.radius_graph(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255)
 
-        if args.input == "host":
+        if stock:
+            def step():
+                return stock_model.stock_train_step(dm, model, opt, x, y, batch,
+                                                    graph_fn=(lambda _x: static_graph()) if args.graph == "static" else None)
+        elif args.input == "host":
             if args.hip_graph or args.graph != "dynamic":
                 raise SystemExit("--input host is built for the eager dynamic flow")
             import itertools
@@ -382,8 +415,15 @@ def main():
                 raise SystemExit("--hip-graph: radius_graph sizes its [2,E] result on the host (one sync per step); "
                                  "use --graph static-table")
             from deepmetv2_amd.parallel import GraphedTrainStep
-            step = GraphedTrainStep(model, flat, sync, opt, x, y, batch, ptr,
-                                    graph_fn=(lambda _x: static_graph()) if args.graph == "static-table" else None)
+            try:
+                step = GraphedTrainStep(model, flat, sync, opt, x, y, batch, ptr,
+                                        graph_fn=(lambda _x: static_graph()) if args.graph == "static-table" else None)
+            except Exception as e:      # never lose a scaling point over the capture: fall back to the eager step, say so
+                hip_graph_note = f"capture failed ({type(e).__name__}: {e}); eager step timed instead"
+                args.hip_graph = False
+
+                def step():
+                    return train_step(model, flat, sync, opt, x, y, batch, ptr, edge_index=static_graph())
         else:
             def step():
                 return train_step(model, flat, sync, opt, x, y, batch, ptr, edge_index=static_graph())
@@ -437,6 +477,18 @@ def main():
     _native.timer.enabled = False
     ksum = _native.timer.summary()
     roof_leg = None
+    # host side: the launch thread's time to ENQUEUE one step with nothing queued in front of it (synchronise, then time
+    # one call).  Eager: ~55 launches through Python; --hip-graph: two graph replays + the collective.  When this is
+    # close to ms_per_step the run is host-bound and N ranks on one host will not scale.
+    host_ts = []
+    for _ in range(10):
+        torch.cuda.synchronize(dev)
+        th = time.perf_counter()
+        step()
+        host_ts.append(time.perf_counter() - th)
+    torch.cuda.synchronize(dev)
+    host_ts.sort()
+    host_ms = host_ts[len(host_ts) // 2] * 1e3
     if args.hip_graph and args.mode == "train":
         # kernels inside a replayed hipGraph cannot be bracketed with events: the per-kernel figures of a --hip-graph run
         # come from a few eager steps of the same training step after the timed region (said so in the roofline block)
@@ -470,6 +522,8 @@ def main():
     if rank == 0:
         events = B * world * args.steps
         roof = gather_roofline(args, ksum, ev_overhead_ms, model, x, batch, ptr, sizes, static_graph if args.mode == "train" else None, dev)
+        if roof is not None and stock and args.graph == "static":
+            roof.pop("standalone_warm", None)
         if roof is not None and roof_leg is not None:
             roof["measured_in"] = roof_leg
         kernels = {}
@@ -482,7 +536,10 @@ def main():
             fl = knn_floor(sizes)
             kernels["knn"].update({"path": os.environ.get("DMET_KNN_PATH", "mfma_filter+exact_rerank"),
                                    "pairs_per_s": round(pairs / (ksum["knn"][1] * 1e-3), 1), **fl,
-                                   "frac_of_floor_sum": round((fl["mfma_floor_us"] + fl["valu_floor_us"]) / (ksum["knn"][1] * 1e3), 3)})
+                                   "floor_us": max(fl["mfma_floor_us"], fl["valu_floor_us"]),
+                                   "floor_note": "max(mfma, valu): the two pipes overlap once the matrix share is small "
+                                                 "(profiles/r02_knn_filter2_budget.md section 4)",
+                                   "frac_of_floor": round(max(fl["mfma_floor_us"], fl["valu_floor_us"]) / (ksum["knn"][1] * 1e3), 3)})
             from deepmetv2_amd import conv as _conv
             riders = []
             if _conv.KNN_RIDER != "0" and args.graph == "dynamic":
@@ -494,17 +551,21 @@ def main():
         out = {
             "metric": "events/sec (4.5k PF cands, k=16)", "value": round(events / elapsed, 1), "unit": "events/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": prewarm_steps,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "host_ms_per_step": round(host_ms, 3),
+            "host_over_gpu": round(host_ms / (elapsed / args.steps * 1e3), 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload_label(args, B, n, k), "events_per_gpu": B,
                        "nodes_per_event": n if args.ragged is None else f"U[{args.ragged[0]},{args.ragged[1]}]", "k": k,
                        "global_batch": B * world, "mode": args.mode, "graph": args.graph, "parallelism": f"dp{world}",
-                       "hip_graph": bool(args.hip_graph), "input": args.input},
+                       "hip_graph": bool(args.hip_graph), "input": args.input, "model": args.model,
+                       "optimizer": optimizer_name, "prewarm_ms": args.prewarm_ms, "gc_disabled": True},
             "roofline": roof, "kernels": kernels,
         }
+        if hip_graph_note:
+            out["config"]["hip_graph_note"] = hip_graph_note
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, seed=1234)
-            if args.graph == "dynamic" and args.dtype == "f32":
+            if args.graph == "dynamic" and args.dtype == "f32" and not stock:
                 out["parity"] = parity_sample(args, model, dev, seed=4321)
         print(json.dumps(out), flush=True)
     if use_group:

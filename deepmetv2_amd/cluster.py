@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _native
-from .graph import NeighborTable, batch_info
+from .graph import NeighborTable, _deferred, batch_info
 
 MAX_K = 64  # DMET_MAX_K
 
@@ -50,13 +50,19 @@ def knn_table(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loo
         nbr, dist, loc = _native.knn_local(x, info.ptr, kk)
     else:
         nbr, dist = _native.knn(x, info.ptr, kk)
-    # dense <=> no -1 entry: needs every event to have >= kk nodes; unknown without a sync, so only the
-    # no-batch single-event case and registered batches with known sizes could claim it.  Stay conservative.
+    # dense <=> no -1 entry anywhere.  Sizes alone cannot promise that (a NaN query, or candidates beyond the 1e10
+    # sentinel distance, leave a row short), so no table claims it.  What sizes DO give is the expectation `full_rows`:
+    # self loops kept and every event >= kk nodes (batch_info / register_batch(min_nodes=...)).  The [2,E] view of such a
+    # table is sized E = N kk on the host, so the reference's call shape `conv(emb, knn_graph(emb, k, batch, loop=True))`
+    # (graph_met_network.py:63) enqueues without a device->host sync; the expectation is verified by a deferred check
+    # (a short row would appear as -1 in the edge list, and the next operator call raises).
     dense = False
+    full_rows = bool(loop and info.min_nodes is not None and info.min_nodes >= kk and x.shape[0] > 0)
     if not loop:
         self_id = torch.arange(x.shape[0], dtype=torch.int32, device=x.device).view(-1, 1)
         nbr = torch.where(nbr == self_id, torch.full_like(nbr, -1), nbr)
-    table = NeighborTable(nbr, info.ptr, dense=dense, dist=dist, max_nodes=info.max_nodes, nbr_local=loc)
+    table = NeighborTable(nbr, info.ptr, dense=dense, dist=dist, max_nodes=info.max_nodes, nbr_local=loc,
+                          full_rows=full_rows)
     table.pq = pq
     return table
 
@@ -70,7 +76,14 @@ def knn_graph(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loo
         raise NotImplementedError("cosine=True is not on the DeepMETv2 hot path")
     if flow not in ("source_to_target", "target_to_source"):
         raise ValueError(f"flow must be 'source_to_target' or 'target_to_source', got {flow!r}")
+    _deferred.poll()
     table = knn_table(x, k, batch, loop=loop, num_events=batch_size)
+    if table.full_rows and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+        # rows are sorted by (d, j) with the empty slots last: the last column tells whether any row is short
+        _deferred.post((table.nbr[:, -1].min() < 0).to(torch.int32),
+                       "knn_graph: a neighbour row came out short although every event holds at least k nodes (non-finite "
+                       "coordinates, or candidates beyond the 1e10 sentinel distance): the [2,E] edge index handed out "
+                       "for it carries -1 entries")
     return table.edge_index(flow)
 
 

@@ -393,12 +393,16 @@ __global__ __launch_bounds__(256) void table_edges_kernel(const int32_t *__restr
     const int m = live ? (cnt ? min(k, cnt[ii]) : k) : 0;
     const int32_t *row = nbr + ii * k;
     int64_t e = rowptr[ii];
+    // a row the caller sized at the table's full width is copied slot for slot: a table ASSUMED to have no empty slot
+    // (kNN with self loops over events of at least k nodes: no edge count is fetched from the device) whose row is short
+    // after all (a non-finite query) hands out -1 there -- a defined, loudly invalid index, never uninitialised memory
+    const bool verbatim = live && (rowptr[ii + 1] - e) == k;
     for (int s0 = 0; __any(s0 < m); s0 += 8) {
         const int s = s0 + l;
         const int32_t j = (s < m) ? row[s] : -1;
-        const unsigned long long ball = __ballot(j >= 0);
+        const unsigned long long ball = __ballot(j >= 0 || (verbatim && s < m));
         const unsigned grp = (unsigned)(ball >> (lane & ~7)) & 0xffu;      // the row's 8 lanes
-        if (j >= 0) {
+        if (j >= 0 || (verbatim && s < m)) {
             const int64_t pos = e + __popc(grp & ((1u << l) - 1u));
             if (first) { first[pos] = swap ? ii : (int64_t)j; second[pos] = swap ? (int64_t)j : ii; }
             if (src32) { src32[pos] = j; tgt32[pos] = (int32_t)ii; }

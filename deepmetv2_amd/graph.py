@@ -20,13 +20,15 @@ from . import _native
 # batch vector -> (ptr, B)
 # ---------------------------------------------------------------------------------------------------------------
 class BatchInfo:
-    __slots__ = ("ptr", "num_events", "num_nodes", "max_nodes")
+    __slots__ = ("ptr", "num_events", "num_nodes", "max_nodes", "min_nodes")
 
-    def __init__(self, ptr: torch.Tensor, num_events: int, num_nodes: int, max_nodes: Optional[int] = None):
+    def __init__(self, ptr: torch.Tensor, num_events: int, num_nodes: int, max_nodes: Optional[int] = None,
+                 min_nodes: Optional[int] = None):
         self.ptr = ptr
         self.num_events = num_events
         self.num_nodes = num_nodes
         self.max_nodes = max_nodes      # largest event (None = unknown): picks the LDS-resident EdgeConv kernel
+        self.min_nodes = min_nodes      # smallest event (None = unknown): >= k means a kNN table without empty slots
 
 
 _batch_registry: Dict[int, Tuple[weakref.ref, int, BatchInfo]] = {}
@@ -55,13 +57,15 @@ def _registry_put(reg, t: torch.Tensor, val) -> None:
 
 
 def register_batch(batch: torch.Tensor, ptr: torch.Tensor, num_events: int,
-                   max_nodes: Optional[int] = None) -> BatchInfo:
-    """Tell the operators the ptr / event count (/ largest event) of a batch vector up front (avoids a device->host
-    sync on first use; without `max_nodes` one sync happens here)."""
+                   max_nodes: Optional[int] = None, min_nodes: Optional[int] = None) -> BatchInfo:
+    """Tell the operators the ptr / event count (/ largest and smallest event) of a batch vector up front (avoids a
+    device->host sync on first use; without `max_nodes` one sync happens here, which then also yields `min_nodes`)."""
     ptr = ptr.to(torch.int64).contiguous()
     if max_nodes is None and ptr.numel() > 1:
-        max_nodes = int(ptr.diff().max())
-    info = BatchInfo(ptr, int(num_events), int(batch.numel()), max_nodes)
+        d = ptr.diff()
+        max_nodes, mn = (int(v) for v in torch.stack([d.max(), d.min()]).tolist())
+        min_nodes = mn if min_nodes is None else min_nodes
+    info = BatchInfo(ptr, int(num_events), int(batch.numel()), max_nodes, min_nodes)
     _registry_put(_batch_registry, batch, info)
     return info
 
@@ -70,7 +74,7 @@ def batch_info(batch: Optional[torch.Tensor], num_nodes: int, device: torch.devi
                num_events: Optional[int] = None) -> BatchInfo:
     if batch is None:
         ptr = torch.tensor([0, num_nodes], dtype=torch.int64, device=device)
-        return BatchInfo(ptr, 1, num_nodes, num_nodes)
+        return BatchInfo(ptr, 1, num_nodes, num_nodes, num_nodes)
     if batch.dim() != 1 or batch.numel() != num_nodes:
         raise ValueError(f"batch must be 1-D with {num_nodes} entries, got {tuple(batch.shape)}")
     info = _registry_get(_batch_registry, batch)
@@ -87,9 +91,63 @@ def batch_info(batch: Optional[torch.Tensor], num_nodes: int, device: torch.devi
             raise ValueError("batch vector must be sorted (torch_cluster / PyG precondition)")
         num_events = int(last) + 1
     ptr = _native.batch_to_ptr(batch, num_events)
-    info = BatchInfo(ptr, num_events, num_nodes, int(ptr.diff().max()) if num_events > 0 else 0)
+    mx = mn = 0
+    if num_events > 0:
+        d = ptr.diff()
+        mx, mn = (int(v) for v in torch.stack([d.max(), d.min()]).tolist())
+    info = BatchInfo(ptr, num_events, num_nodes, mx, mn)
     _registry_put(_batch_registry, batch, info)
     return info
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# deferred device-side checks (the CUDA convention: an error found on the device surfaces at a later host call)
+# ---------------------------------------------------------------------------------------------------------------
+class _DeferredChecks:
+    """Conditions that hold for every sane input but can only be verified on the device are checked WITHOUT stalling the
+    launch thread: the device writes a flag, a non-blocking copy brings it to pinned host memory, and a later call of the
+    operators (or `deepmetv2_amd.raise_deferred_errors()`, which waits) looks at the copies that have completed."""
+    SLOTS = 64
+
+    def __init__(self):
+        self.host = None
+        self.pending = []       # (event, slot, message)
+        self.next = 0
+
+    def post(self, flag: torch.Tensor, message: str) -> None:
+        """flag: 0-d / 1-element int32 device tensor, non-zero = the condition was violated."""
+        if self.host is None:
+            self.host = torch.zeros(self.SLOTS, dtype=torch.int32).pin_memory()
+        slot = self.next % self.SLOTS
+        self.next += 1
+        for ent in [p for p in self.pending if p[1] == slot]:     # the ring came round: this copy is 64 builds old
+            ent[0].synchronize()
+            self._settle(ent)
+        self.host[slot:slot + 1].copy_(flag.reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((ev, slot, message))
+
+    def _settle(self, ent) -> None:
+        self.pending.remove(ent)
+        if int(self.host[ent[1]]) != 0:
+            raise RuntimeError(ent[2])
+
+    def poll(self, wait: bool = False) -> None:
+        for ent in list(self.pending):
+            if wait:
+                ent[0].synchronize()
+            if wait or ent[0].query():
+                self._settle(ent)
+
+
+_deferred = _DeferredChecks()
+
+
+def raise_deferred_errors() -> None:
+    """Wait for every outstanding device-side check and raise if one failed (call it where the training loop
+    synchronises anyway, e.g. next to `loss.item()`, train.py:54)."""
+    _deferred.poll(wait=True)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -161,8 +219,12 @@ class NeighborTable:
     def __init__(self, nbr: torch.Tensor, ptr: Optional[torch.Tensor], dense: bool, dist: Optional[torch.Tensor] = None,
                  max_nodes: Optional[int] = None, cnt: Optional[torch.Tensor] = None,
                  nbr_local: Optional[torch.Tensor] = None, nonempty: bool = False,
-                 rows16: Optional[torch.Tensor] = None):
+                 rows16: Optional[torch.Tensor] = None, full_rows: bool = False):
         self.nbr = nbr
+        # True: every row is EXPECTED to hold k entries (kNN with self loops, every event >= k nodes): the [2,E] view is
+        # sized E = N k without asking the device; the expectation is verified by a deferred check (knn_table).  Unlike
+        # `dense` it is not relied upon for masking: a short row (non-finite query) still yields 0 and no gradient.
+        self.full_rows = full_rows
         self.pq = None              # (P, Q, sliced) of the consuming EdgeConv's dense layer when the kNN build carried it
         self.rows16 = rows16        # counted tables: the rows again as event-local uint16 ids (_native.radius(local=True))
         self.nonempty = nonempty    # True: every row holds at least one entry (tables built with self loops)
@@ -203,7 +265,7 @@ class NeighborTable:
     def _rowptr(self):
         """(rowptr[N+1] int32, E): one host sync to learn the edge count (upstream returns exact-size tensors too)."""
         if self._rp is None:
-            if self.dense:
+            if self.dense or self.full_rows:
                 N, k = self.num_nodes, self.k
                 self._rp = (torch.arange(0, (N + 1) * k, k, dtype=torch.int32, device=self.nbr.device), N * k)
             else:

@@ -476,6 +476,7 @@ def test_edgeconv_radius_backward_with_nonfinite_coordinates(dev):
     gup = torch.randn(N, 32, generator=g)
     batch = torch.repeat_interleave(torch.arange(2), torch.tensor(sizes))
     lin = torch.nn.Sequential(torch.nn.Linear(64, 32))
+    conv = dm.EdgeConv(nn=lin)          # (the constructor resets the parameters of nn, like PyG's: build it first)
     ei_ref = ref_ops.radius_graph(etaphi, 0.4, batch, loop=True, max_num_neighbors=255)
     xr = emb.clone().requires_grad_(True)
     ref = ref_ops.edge_conv(xr, ei_ref, lin)
@@ -483,7 +484,7 @@ def test_edgeconv_radius_backward_with_nonfinite_coordinates(dev):
     gw_ref, gb_ref, gx_ref = lin[0].weight.grad.clone(), lin[0].bias.grad.clone(), xr.grad.clone()
     lin.zero_grad()
     assert bool((ref[[5, 17, 250, N - 1]] == 0).all())
-    conv = dm.EdgeConv(nn=lin).to(dev)
+    conv = conv.to(dev)
     table = dm.radius_table(etaphi.to(dev), 0.4, batch.to(dev), loop=True, max_num_neighbors=255)
     assert torch.equal(table.edge_index("source_to_target").cpu(), ei_ref)
     xd = emb.to(dev).requires_grad_(True)
