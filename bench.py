@@ -356,7 +356,7 @@ def main():
     B, n, k = args.events_per_gpu, args.nodes, args.k
     sizes = [n] * B if args.ragged is None else synth.ragged_sizes(B, args.ragged[0], args.ragged[1], seed=1234 + rank)
     x, y, batch, ptr = synth.make_events(sizes, seed=1234 + rank, device=dev)
-    dm.register_batch(batch, ptr, B, max_nodes=max(sizes))
+    dm.register_batch(batch, ptr, B, max_nodes=max(sizes), min_nodes=min(sizes))
     N = x.shape[0]
 
     torch.manual_seed(0)
@@ -404,7 +404,7 @@ def main():
                 raise SystemExit("--input host is built for the eager dynamic flow")
             import itertools
             from deepmetv2_amd.data import Batch, DeviceLoader
-            hb = Batch(x.cpu(), y.cpu(), batch.cpu(), ptr.cpu(), max(sizes)).pin_memory()
+            hb = Batch(x.cpu(), y.cpu(), batch.cpu(), ptr.cpu(), max(sizes), min_nodes=min(sizes)).pin_memory()
             feed = iter(DeviceLoader(itertools.repeat(hb), dev, depth=2))     # the same batch every step: rate only
 
             def step():

@@ -35,6 +35,7 @@ class Batch:
     # events of the GLOBAL batch this one is a rank's shard of (None: not sharded); parallel.train_step weights the
     # rank's gradient by num_graphs / global_graphs
     global_graphs: Optional[int] = None
+    min_nodes: Optional[int] = None     # smallest event (>= k: kNN tables of this batch have no empty slot to look for)
 
     @property
     def num_graphs(self) -> int:
@@ -47,13 +48,13 @@ class Batch:
     def to(self, device, non_blocking: bool = False) -> "Batch":
         b = Batch(self.x.to(device, non_blocking=non_blocking), self.y.to(device, non_blocking=non_blocking),
                   self.batch.to(device, non_blocking=non_blocking), self.ptr.to(device, non_blocking=non_blocking),
-                  self.max_nodes, self.global_graphs)
-        register_batch(b.batch, b.ptr, b.num_graphs, max_nodes=b.max_nodes)
+                  self.max_nodes, self.global_graphs, self.min_nodes)
+        register_batch(b.batch, b.ptr, b.num_graphs, max_nodes=b.max_nodes, min_nodes=b.min_nodes)
         return b
 
     def pin_memory(self) -> "Batch":
         return Batch(self.x.pin_memory(), self.y.pin_memory(), self.batch.pin_memory(), self.ptr.pin_memory(),
-                     self.max_nodes, self.global_graphs)
+                     self.max_nodes, self.global_graphs, self.min_nodes)
 
 
 def collate(events: Sequence[Tuple[torch.Tensor, torch.Tensor]]) -> Batch:
@@ -66,7 +67,8 @@ def collate(events: Sequence[Tuple[torch.Tensor, torch.Tensor]]) -> Batch:
     ptr = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)])
     batch = torch.repeat_interleave(torch.arange(len(xs), dtype=torch.int64), counts)
     x = torch.cat(xs, 0).to(torch.float32).contiguous()
-    return Batch(x, torch.cat(ys, 0).to(torch.float32).contiguous(), batch, ptr, int(counts.max()))
+    return Batch(x, torch.cat(ys, 0).to(torch.float32).contiguous(), batch, ptr, int(counts.max()),
+                 min_nodes=int(counts.min()))
 
 
 def events_from_padded(x_pad, y) -> List[Tuple[torch.Tensor, torch.Tensor]]:
@@ -189,7 +191,7 @@ class DeviceLoader:
             with torch.cuda.stream(copy_stream):
                 db = Batch(pinned.x.to(dev, non_blocking=True), pinned.y.to(dev, non_blocking=True),
                            pinned.batch.to(dev, non_blocking=True), pinned.ptr.to(dev, non_blocking=True), hb.max_nodes,
-                           hb.global_graphs)
+                           hb.global_graphs, hb.min_nodes)
                 done = torch.cuda.Event()
                 done.record(copy_stream)
             inflight.append((pinned, db, done))
@@ -209,5 +211,5 @@ class DeviceLoader:
         cur.wait_event(done)                       # device-side wait: the host does not block
         for t in (db.x, db.y, db.batch, db.ptr):
             t.record_stream(cur)                   # allocated on the copy stream, used on the compute stream
-        register_batch(db.batch, db.ptr, db.num_graphs, max_nodes=db.max_nodes)
+        register_batch(db.batch, db.ptr, db.num_graphs, max_nodes=db.max_nodes, min_nodes=db.min_nodes)
         return db

@@ -1259,6 +1259,7 @@ def test_flat_adamw_continues_a_torch_adamw_state(dev):
     """A checkpoint written with torch.optim.AdamW (utils.py:59-77 saves `optim_dict`; state keys step / exp_avg /
     exp_avg_sq only) loads into FlatAdamW: beta^step and the device learning rate are rebuilt, the run continues on the
     trajectory of the fp64 reference; FlatAdamW's own state_dict round-trips too."""
+    import copy
     from deepmetv2_amd.optim import FlatAdamW
     g = torch.Generator().manual_seed(9)
     p0 = torch.randn(6641, generator=g)
@@ -1272,7 +1273,7 @@ def test_flat_adamw_continues_a_torch_adamw_state(dev):
         ot.step(); ob.step()
     pa = torch.nn.Parameter(pt.detach().clone())
     oa = FlatAdamW([pa], lr=1e-3)
-    oa.load_state_dict(ot.state_dict())
+    oa.load_state_dict(copy.deepcopy(ot.state_dict()))     # (as from a file: load_state_dict itself keeps references)
     for it in range(5, 10):
         pa.grad = grads[it].to(dev); pb.grad = grads[it].double()
         oa.step(); ob.step()
@@ -1281,7 +1282,7 @@ def test_flat_adamw_continues_a_torch_adamw_state(dev):
     # round trip of its own state (load_state_dict casts the double state tensors to fp32: they are rebuilt)
     pc = torch.nn.Parameter(pa.detach().clone())
     oc = FlatAdamW([pc], lr=1e-3)
-    oc.load_state_dict(oa.state_dict())
+    oc.load_state_dict(copy.deepcopy(oa.state_dict()))
     for it in range(10, 14):
         pa.grad = grads[it].to(dev); pc.grad = grads[it].to(dev); pb.grad = grads[it].double()
         oa.step(); oc.step(); ob.step()
@@ -1309,8 +1310,16 @@ def test_batch_norm_transform_rides_in_the_knn_prep(dev, sizes, with_res):
     assert torch.equal(mean, mean_ref) and torch.equal(invstd, inv_ref)
     out = _native.bn_knn_local_dense(xd, rd, gd, bd, mean, invstd, pd, 16, (Wd, bbd, True))
     import os
-    if os.environ.get("DMET_KNN_PATH") or os.environ.get("DMET_KNN_FILTER"):
-        pytest.skip("diagnostic switch: the build is off the default matrix-core path (tools/toggle_sweep.sh)")
+    if os.environ.get("DMET_KNN_PATH") == "exact":
+        # documented property, not a silenced failure: the exact kernel has no prep launch for the transform to ride in,
+        # dmet_bn_knn_local_dense_f32 then launches NOTHING (*fused = 0, _native returns None) and dense.batch_norm takes
+        # the separate pass -- whose bits are the reference of this test anyway; the build on its output must agree
+        assert out is None
+        nbr0, dist0, loc0 = _native.knn_local(y_ref, pd, 16)
+        nbr_ref, dist_ref = __import__("oracle.ref_ops", fromlist=["x"]).knn_table(y_ref.cpu(), ptr, 16)
+        assert torch.equal(nbr0.cpu(), nbr_ref) and torch.equal(dist0.cpu(), dist_ref)
+        return
+    # (DMET_KNN_FILTER=1, the first filter form for every event, shares the prep launch: the test runs unchanged)
     assert out is not None, "a 32-feature build with k <= 20 takes the matrix-core path"
     y, nbr, dist, loc, pq = out
     assert torch.equal(y, y_ref)
