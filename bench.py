@@ -64,6 +64,13 @@ def parse_args():
                     help="device: the batch is resident in HBM when the timed region starts (the metric's definition); "
                          "host: every step takes its batch from pinned host memory through deepmetv2_amd.DeviceLoader "
                          "(copied on a side stream two batches ahead), i.e. the PCIe-inclusive rate")
+    ap.add_argument("--accelerate", choices=["none", "layers", "fuse"], default="none",
+                    help="--model stock-* only: what ONE extra line in the training script buys -- layers: "
+                         "deepmetv2_amd.accelerate(model, fuse=False) (torch.nn.Linear / Embedding / BatchNorm1d become the "
+                         "HIP-backed subclasses of deepmetv2_amd.nn, the same as a fourth import line `import "
+                         "deepmetv2_amd.nn as nn`); fuse: model = deepmetv2_amd.accelerate(model): the graph-MET wiring is "
+                         "recognised and replaced by this repo's fused Net sharing the parameters; the loop, the loss with its "
+                         "two scatter_add calls and torch.optim.AdamW stay the reference's")
     ap.add_argument("--prewarm-ms", type=float, default=200.0,
                     help="untimed run-in before the W warm-up steps: the same step repeated for this long, so that the "
                          "module loads, the allocator's growth and the GPU's clock ramp are over when warm-up starts "
@@ -364,6 +371,10 @@ def main():
         from deepmetv2_amd import stock_model
         variant = "static" if args.graph == "static" else args.model[len("stock-"):].replace("-", "_")
         model = stock_model.StockNet(dm, 8, 3, variant=variant, k=k).to(dev)
+        if args.accelerate == "layers":
+            model = dm.accelerate(model, fuse=False)
+        elif args.accelerate == "fuse":
+            model = dm.accelerate(model, graph="static" if variant == "static" else "dynamic", k=k)
         flat = sync = None
         opt = torch.optim.AdamW(model.parameters(), lr=1e-3)          # train.py:75 as written
         optimizer_name = "torch.optim.AdamW(model.parameters(), lr=1e-3)"
@@ -557,7 +568,8 @@ def main():
             "config": {"workload": workload_label(args, B, n, k), "events_per_gpu": B,
                        "nodes_per_event": n if args.ragged is None else f"U[{args.ragged[0]},{args.ragged[1]}]", "k": k,
                        "global_batch": B * world, "mode": args.mode, "graph": args.graph, "parallelism": f"dp{world}",
-                       "hip_graph": bool(args.hip_graph), "input": args.input, "model": args.model,
+                       "hip_graph": bool(args.hip_graph), "input": args.input,
+                       "model": args.model + ("" if args.accelerate == "none" else f" + accelerate({args.accelerate})"),
                        "optimizer": optimizer_name, "prewarm_ms": args.prewarm_ms, "gc_disabled": True},
             "roofline": roof, "kernels": kernels,
         }

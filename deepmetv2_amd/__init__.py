@@ -17,10 +17,11 @@ from .data import Batch, DeviceLoader, EventLoader, collate, events_from_padded
 from .graph import NeighborTable, raise_deferred_errors, register_batch, to_undirected
 from .metrics import metrics, resolution, u_perp_par_loss
 from .scatter import met_reduce, scatter_add, scatter_max
+from .nn import accelerate
 
 __all__ = [
     "EdgeConv", "DynamicEdgeConv", "knn", "knn_graph", "knn_table", "radius_graph", "radius_table",
     "scatter_add", "scatter_max", "met_reduce", "NeighborTable", "register_batch", "metrics", "resolution",
-    "u_perp_par_loss", "to_undirected", "raise_deferred_errors", "Batch", "EventLoader", "DeviceLoader", "collate", "events_from_padded",
+    "u_perp_par_loss", "to_undirected", "raise_deferred_errors", "accelerate", "Batch", "EventLoader", "DeviceLoader", "collate", "events_from_padded",
 ]
 __version__ = "0.1.0"

@@ -184,7 +184,9 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, residual: Optional[tor
     ok = (x.dim() == 2 and x.dtype == torch.float32 and H % 4 == 0 and 4 <= H <= 64 and bn.affine
           and bn.momentum is not None and x.shape[0] > 1 and (bn.training or bn.track_running_stats))
     if not ok:
-        y = bn(x)
+        # (deepmetv2_amd.nn.BatchNorm1d calls this function from its own forward: take torch's forward then)
+        own = getattr(bn, "_torch_forward", None)
+        y = own(x) if own is not None else bn(x)
         return y if residual is None else residual + y
     training = bn.training or not bn.track_running_stats
     rm = bn.running_mean if bn.track_running_stats else None

@@ -110,3 +110,46 @@ def test_knn_graph_of_full_events_needs_no_host_sync(dev):
     assert ei.shape == (2, sum(sizes) * 16) and out.shape == (sum(sizes), 32)
     from oracle import ref_ops
     assert torch.equal(ei.cpu(), ref_ops.knn_graph(emb.cpu(), 16, batch.cpu(), loop=True))
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+def test_accelerate_one_line_matches_oracle(dev, fuse):
+    """`model = deepmetv2_amd.accelerate(model)` on the drop-in model: the layer swap alone (fuse=False: deepmetv2_amd.nn
+    subclasses in place) and the recognised graph-MET wiring (fuse=True: this repo's fused Net on the SAME parameter
+    objects) both reproduce the oracle's forward, loss and gradients, keep the state_dict keys, and an optimizer built on
+    the original model's parameters trains the accelerated one."""
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import stock_model, synth
+    from deepmetv2_amd.model import Net
+    from oracle import ref_model, ref_ops
+    torch.manual_seed(8)
+    sizes = [600, 40, 1100, 17]
+    x, y, batch, ptr = synth.make_events(sizes, seed=29)
+    stock = stock_model.StockNet(dm, 8, 3, variant="dynamic", k=16)
+    ref = ref_model.RefNet(8, 3, graph="dynamic", k=16)
+    ref.load_state_dict(stock.state_dict())
+    stock.to(dev).train(); ref.train()
+    keys = list(stock.state_dict().keys())
+    model = dm.accelerate(stock, fuse=fuse)
+    assert isinstance(model, Net) == fuse and (fuse or model is stock)
+    assert list(model.state_dict().keys()) == keys
+    assert all(a is b for a, b in zip(model.parameters(), stock.parameters()))
+    assert type(stock.graphnet.bn_all).__module__ == "deepmetv2_amd.nn" and isinstance(stock.graphnet.bn_all, torch.nn.BatchNorm1d)
+    xd, yd, bd = x.to(dev), y.to(dev), batch.to(dev)
+    opt = torch.optim.AdamW(stock.parameters(), lr=1e-3)           # built on the ORIGINAL model's parameters
+    opt.zero_grad()
+    w = model(xd[:, :8], xd[:, 8:].long(), None, bd)
+    loss = stock_model.stock_loss_fn(dm, w, xd, yd, bd)
+    loss.backward()
+    w_ref = ref(x[:, :8], x[:, 8:].long(), None, batch)
+    loss_ref = ref_ops.loss_fn(w_ref, x, y, batch)
+    loss_ref.backward()
+    torch.testing.assert_close(w.detach().cpu(), w_ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(loss.detach().cpu(), loss_ref.detach(), rtol=1e-4, atol=1e-3)
+    _grad_bars(model, ref)
+    before = [p.detach().clone() for p in model.parameters()]
+    opt.step()
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
+    # running statistics moved exactly once, in the shared buffers
+    torch.testing.assert_close(stock.graphnet.bn_all.running_mean.cpu(), ref.graphnet.bn_all.running_mean, rtol=1e-4, atol=1e-5)
+    assert int(stock.graphnet.bn_all.num_batches_tracked) == 1

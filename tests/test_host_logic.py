@@ -139,3 +139,38 @@ def test_dynamic_edgeconv_rider_requests_follow_the_layer_shape(monkeypatch):
     monkeypatch.setattr(conv, "BN_KNN_FUSE", "1")
     assert layer.prebuild_hook(None) is None
     assert layer._take_prebuilt(x) is None
+
+
+def test_nn_shim_and_accelerate_structure(monkeypatch):
+    """deepmetv2_amd.nn re-exports torch.nn with three subclasses; accelerate() swaps classes in place, recognises the
+    graph-MET wiring (and only that) and shares parameter objects with the fused Net it returns."""
+    import torch
+    from tests import fake_native
+    fake_native.install(monkeypatch)
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import nn as dnn, stock_model
+    from deepmetv2_amd.model import Net
+    assert dnn.ELU is torch.nn.ELU and dnn.Sequential is torch.nn.Sequential and dnn.Module is torch.nn.Module
+    for name in ("Linear", "Embedding", "BatchNorm1d"):
+        assert issubclass(getattr(dnn, name), getattr(torch.nn, name)) and getattr(dnn, name) is not getattr(torch.nn, name)
+    lin = dnn.Linear(5, 3)
+    assert torch.equal(lin(torch.ones(2, 5)), torch.nn.functional.linear(torch.ones(2, 5), lin.weight, lin.bias))   # CPU: parent
+    bn = dnn.BatchNorm1d(6)                                  # 6 is not a multiple of 4: torch's forward, no recursion
+    assert bn(torch.randn(10, 6)).shape == (10, 6)
+    stock = stock_model.StockNet(dm, 8, 3, variant="knn_graph", k=4)
+    keys = list(stock.state_dict().keys())
+    fused = dm.accelerate(stock, graph="dynamic", k=4)
+    assert isinstance(fused, Net) and fused.graphnet.graph == "dynamic" and fused.graphnet.k == 4
+    assert list(fused.state_dict().keys()) == keys
+    assert all(a is b for a, b in zip(fused.parameters(), stock.parameters()))
+    assert all(a is b for a, b in zip(fused.buffers(), stock.buffers()))
+    assert type(stock.graphnet.encode_all[0]) is dnn.Linear and type(stock.graphnet.embed_pv) is dnn.Embedding
+    # auto: EdgeConv blocks mean the caller's static graph, DynamicEdgeConv blocks a kNN graph with the module's k
+    assert dm.accelerate(stock_model.StockNet(dm, 8, 3, variant="static")).graphnet.graph == "static"
+    dyn = dm.accelerate(stock_model.StockNet(dm, 8, 3, variant="dynamic", k=7))
+    assert dyn.graphnet.graph == "dynamic" and dyn.graphnet.k == 7
+    # anything that is not wired like the reference's Net comes back as it is (layers swapped)
+    other = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.BatchNorm1d(4))
+    assert dm.accelerate(other) is other and type(other[0]) is dnn.Linear
+    with pytest.raises(ValueError):
+        dm.accelerate(stock_model.StockNet(dm, 8, 3), graph="sometimes")
