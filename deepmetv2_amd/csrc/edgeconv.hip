@@ -459,23 +459,33 @@ __device__ __forceinline__ void gather_max_lds_segment(
                 asm("v_max3_f32 %0, %0, %1, %2" : "+v"(bz) : "v"(v[u].z), "v"(v[u + 1].z));
                 asm("v_max3_f32 %0, %0, %1, %2" : "+v"(bw) : "v"(v[u].w), "v"(v[u + 1].w));
             }
-#define DMET_EQ_ARG(best, a, val, slot)                                                                           \
-    asm("v_cmp_eq_f32 vcc, %1, %2\n\tv_cndmask_b32_e64 %0, %0, %3, vcc" : "+v"(a) : "v"(val), "v"(best), "n"(slot) : "vcc")
-#define DMET_EQ_CASE(S_) case S_: DMET_EQ_ARG(bx, a0, v[S_].x, S_); DMET_EQ_ARG(by, a1, v[S_].y, S_); \
-                                  DMET_EQ_ARG(bz, a2, v[S_].z, S_); DMET_EQ_ARG(bw, a3, v[S_].w, S_); break;
-#pragma unroll
-            for (int u = 4 * K4 - 1; u >= 0; --u) {
-                switch (u) {   // the slot must be an immediate
-                    DMET_EQ_CASE(0) DMET_EQ_CASE(1) DMET_EQ_CASE(2) DMET_EQ_CASE(3) DMET_EQ_CASE(4) DMET_EQ_CASE(5)
-                    DMET_EQ_CASE(6) DMET_EQ_CASE(7) DMET_EQ_CASE(8) DMET_EQ_CASE(9) DMET_EQ_CASE(10) DMET_EQ_CASE(11)
-                    DMET_EQ_CASE(12) DMET_EQ_CASE(13) DMET_EQ_CASE(14) DMET_EQ_CASE(15) DMET_EQ_CASE(16)
-                    DMET_EQ_CASE(17) DMET_EQ_CASE(18) DMET_EQ_CASE(19) DMET_EQ_CASE(20) DMET_EQ_CASE(21)
-                    DMET_EQ_CASE(22) DMET_EQ_CASE(23) DMET_EQ_CASE(24) DMET_EQ_CASE(25) DMET_EQ_CASE(26)
-                    DMET_EQ_CASE(27) DMET_EQ_CASE(28) DMET_EQ_CASE(29) DMET_EQ_CASE(30) DMET_EQ_CASE(31)
-                }
+            // FOUR slots x four channels per asm statement (32 instructions): hipcc puts an `s_nop 0` behind every asm
+            // statement that clobbers vcc -- with one statement per (slot, channel) that was 64 s_nops next to 333 useful
+            // instructions in this loop body (round 3, found in the ISA: 19 % of the wavefront's issue slots).
+            // The scan runs from the last slot down, so the LOWEST slot among equal maxima is written last (R4).
+#define DMET_EQ1(V_, B_, A_, S_) "v_cmp_eq_f32 vcc, " V_ ", " B_ "\n\tv_cndmask_b32_e64 " A_ ", " A_ ", " S_ ", vcc\n\t"
+#define DMET_EQ_SLOT(X_, Y_, Z_, W_, S_) DMET_EQ1(X_, "%[bx]", "%[a0]", S_) DMET_EQ1(Y_, "%[by]", "%[a1]", S_) \
+                                         DMET_EQ1(Z_, "%[bz]", "%[a2]", S_) DMET_EQ1(W_, "%[bw]", "%[a3]", S_)
+#define DMET_EQ_GROUP(G_)                                                                                          \
+    asm(DMET_EQ_SLOT("%[x3]", "%[y3]", "%[z3]", "%[w3]", "%[s3]") DMET_EQ_SLOT("%[x2]", "%[y2]", "%[z2]", "%[w2]", "%[s2]") \
+        DMET_EQ_SLOT("%[x1]", "%[y1]", "%[z1]", "%[w1]", "%[s1]") DMET_EQ_SLOT("%[x0]", "%[y0]", "%[z0]", "%[w0]", "%[s0]") \
+        : [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3)                                                \
+        : [bx] "v"(bx), [by] "v"(by), [bz] "v"(bz), [bw] "v"(bw),                                                   \
+          [x0] "v"(v[4 * (G_)].x), [y0] "v"(v[4 * (G_)].y), [z0] "v"(v[4 * (G_)].z), [w0] "v"(v[4 * (G_)].w),       \
+          [x1] "v"(v[4 * (G_) + 1].x), [y1] "v"(v[4 * (G_) + 1].y), [z1] "v"(v[4 * (G_) + 1].z), [w1] "v"(v[4 * (G_) + 1].w), \
+          [x2] "v"(v[4 * (G_) + 2].x), [y2] "v"(v[4 * (G_) + 2].y), [z2] "v"(v[4 * (G_) + 2].z), [w2] "v"(v[4 * (G_) + 2].w), \
+          [x3] "v"(v[4 * (G_) + 3].x), [y3] "v"(v[4 * (G_) + 3].y), [z3] "v"(v[4 * (G_) + 3].z), [w3] "v"(v[4 * (G_) + 3].w), \
+          [s0] "n"(4 * (G_)), [s1] "n"(4 * (G_) + 1), [s2] "n"(4 * (G_) + 2), [s3] "n"(4 * (G_) + 3)               \
+        : "vcc")
+            if constexpr (K4 <= 4) {      // (this branch is taken for K4 <= 4 only; wider tables never instantiate the asm)
+                if constexpr (K4 >= 4) DMET_EQ_GROUP(3);
+                if constexpr (K4 >= 3) DMET_EQ_GROUP(2);
+                if constexpr (K4 >= 2) DMET_EQ_GROUP(1);
+                DMET_EQ_GROUP(0);
             }
-#undef DMET_EQ_CASE
-#undef DMET_EQ_ARG
+#undef DMET_EQ_GROUP
+#undef DMET_EQ_SLOT
+#undef DMET_EQ1
             // a channel whose maximum is still -inf had no valid neighbour (all of them then): slot 255
             if (!(bx > ninf)) a0 = 255;
             if (!(by > ninf)) a1 = 255;
