@@ -356,9 +356,13 @@ def main():
                   or args.graph == "static-table"):
         raise SystemExit("--model stock-* times the reference's own single-process training loop: N = 1, train, fp32, "
                          "--graph dynamic | static")
+    # --hip-graph unset: "auto" -- on for N > 1; at N = 1 decided after the run-in from the measured host / GPU ratio (the
+    # eager step costs the launch thread 0.9-1.3 ms box to box against 1.46 ms of GPU time: on a slow host the eager loop is
+    # host-bound and the same kernels read 7 % slower)
+    graph_capable = bool(args.mode == "train" and args.input == "device" and args.graph != "static" and not stock)
+    hip_graph_auto = args.hip_graph is None and graph_capable
     if args.hip_graph is None:
-        args.hip_graph = bool(world > 1 and args.mode == "train" and args.input == "device" and args.graph != "static"
-                              and not stock)
+        args.hip_graph = bool(world > 1 and graph_capable)
     hip_graph_note = None
     B, n, k = args.events_per_gpu, args.nodes, args.k
     sizes = [n] * B if args.ragged is None else synth.ragged_sizes(B, args.ragged[0], args.ragged[1], seed=1234 + rank)
@@ -421,23 +425,30 @@ def main():
             def step():
                 b = next(feed)
                 return train_step(model, flat, sync, opt, b.x, b.y, b.batch, b.ptr)
-        elif args.hip_graph:
-            if args.graph == "static":
+        else:
+            if args.hip_graph and args.graph == "static":
                 raise SystemExit("--hip-graph: radius_graph sizes its [2,E] result on the host (one sync per step); "
                                  "use --graph static-table")
-            from deepmetv2_amd.parallel import GraphedTrainStep
-            try:
-                step = GraphedTrainStep(model, flat, sync, opt, x, y, batch, ptr,
-                                        graph_fn=(lambda _x: static_graph()) if args.graph == "static-table" else None)
-            except Exception as e:      # never lose a scaling point over the capture: fall back to the eager step, say so
-                hip_graph_note = f"capture failed ({type(e).__name__}: {e}); eager step timed instead"
-                args.hip_graph = False
 
-                def step():
-                    return train_step(model, flat, sync, opt, x, y, batch, ptr, edge_index=static_graph())
-        else:
-            def step():
+            def eager_train_step():
                 return train_step(model, flat, sync, opt, x, y, batch, ptr, edge_index=static_graph())
+
+            def graphed_train_step():
+                """The step as two hipGraphs around the collective, or None (with a note) when the capture fails: a
+                scaling point is never lost over it."""
+                nonlocal hip_graph_note
+                from deepmetv2_amd.parallel import GraphedTrainStep
+                try:
+                    return GraphedTrainStep(model, flat, sync, opt, x, y, batch, ptr,
+                                            graph_fn=(lambda _x: static_graph()) if args.graph == "static-table" else None)
+                except Exception as e:
+                    hip_graph_note = f"capture failed ({type(e).__name__}: {e}); eager step timed instead"
+                    return None
+
+            step = eager_train_step
+            if args.hip_graph:
+                step = graphed_train_step() or eager_train_step
+                args.hip_graph = step is not eager_train_step
     else:
         model.eval()
 
@@ -460,6 +471,32 @@ def main():
                 step()
             torch.cuda.synchronize(dev)
             prewarm_steps += 8
+    if hip_graph_auto and not args.hip_graph:
+        # host-bound?  time the launch thread's enqueue of one eager step from an idle stream against the GPU's time per
+        # step over a short burst; above 0.8 the timed region replays hipGraphs instead (all ranks decide alike)
+        hts = []
+        for _ in range(7):
+            torch.cuda.synchronize(dev)
+            th = time.perf_counter(); step(); hts.append(time.perf_counter() - th)
+        torch.cuda.synchronize(dev)
+        tg = time.perf_counter()
+        for _ in range(24):
+            step()
+        torch.cuda.synchronize(dev)
+        ratio = sorted(hts)[3] / ((time.perf_counter() - tg) / 24)
+        want = ratio > 0.8
+        if use_group:
+            flag = torch.tensor([1.0 if want else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            want = bool(flag.item() > 0)
+        hip_graph_note = f"auto: host enqueue / step time of the eager loop = {ratio:.2f} ({'>' if want else '<='} 0.8)"
+        if want:
+            g = graphed_train_step()
+            if g is not None:
+                step, args.hip_graph = g, True
+                for _ in range(8):
+                    step()
+                torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     ev_overhead_ms = _native.timer.calibrate(dev)
