@@ -71,6 +71,9 @@ def parse_args():
                          "deepmetv2_amd.nn as nn`); fuse: model = deepmetv2_amd.accelerate(model): the graph-MET wiring is "
                          "recognised and replaced by this repo's fused Net sharing the parameters; the loop, the loss with its "
                          "two scatter_add calls and torch.optim.AdamW stay the reference's")
+    ap.add_argument("--no-graph-async", dest="graph_async", action="store_false", default=True,
+                    help="--graph static-table: build the radius table on the caller's stream (as train.py:48-49 orders it) "
+                         "instead of on a side stream beside the encoder")
     ap.add_argument("--prewarm-ms", type=float, default=200.0,
                     help="untimed run-in before the W warm-up steps: the same step repeated for this long, so that the "
                          "module loads, the allocator's growth and the GPU's clock ramp are over when warm-up starts "
@@ -250,6 +253,8 @@ def gather_roofline(args, ksum, ev_overhead_ms, model, x, batch, ptr, sizes, sta
             id_note = f"{k} int32 ids per node"
         else:
             table = static_graph() if args.graph == "static-table" else None
+            if isinstance(table, dm.GraphFuture):
+                table = table.result()
             if table is None:
                 phi = torch.atan2(x[:, 1], x[:, 0])
                 table = dm.radius_table(torch.stack([x[:, 3], phi], 1), r=0.4, batch=batch, loop=True, max_num_neighbors=255)
@@ -409,6 +414,12 @@ def main():
             if args.graph == "static-table":
                 return dm.radius_table(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255)
             return dm.radius_graph(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255)
+
+        static_graph_sync = static_graph
+        if args.graph == "static-table" and args.graph_async:
+            # the table is built on a side stream beside the model's encoder (which does not need it); EdgeConv joins it
+            def static_graph():
+                return dm.build_async(static_graph_sync)
 
         if stock:
             def step():

@@ -14,7 +14,7 @@ calling an operator without the library or with non-GPU tensors raises.
 from .cluster import knn, knn_graph, knn_table, radius_graph, radius_table
 from .conv import DynamicEdgeConv, EdgeConv
 from .data import Batch, DeviceLoader, EventLoader, collate, events_from_padded
-from .graph import NeighborTable, raise_deferred_errors, register_batch, to_undirected
+from .graph import GraphFuture, NeighborTable, build_async, raise_deferred_errors, register_batch, to_undirected
 from .metrics import metrics, resolution, u_perp_par_loss
 from .scatter import met_reduce, scatter_add, scatter_max
 from .nn import accelerate
@@ -22,6 +22,6 @@ from .nn import accelerate
 __all__ = [
     "EdgeConv", "DynamicEdgeConv", "knn", "knn_graph", "knn_table", "radius_graph", "radius_table",
     "scatter_add", "scatter_max", "met_reduce", "NeighborTable", "register_batch", "metrics", "resolution",
-    "u_perp_par_loss", "to_undirected", "raise_deferred_errors", "accelerate", "Batch", "EventLoader", "DeviceLoader", "collate", "events_from_padded",
+    "u_perp_par_loss", "to_undirected", "raise_deferred_errors", "accelerate", "build_async", "GraphFuture", "Batch", "EventLoader", "DeviceLoader", "collate", "events_from_padded",
 ]
 __version__ = "0.1.0"

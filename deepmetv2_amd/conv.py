@@ -17,7 +17,7 @@ import torch
 
 from . import _native
 from .cluster import knn_table
-from .graph import EdgeList, NeighborTable, batch_info, edge_list_from_edge_index, lookup_graph
+from .graph import EdgeList, GraphFuture, NeighborTable, batch_info, edge_list_from_edge_index, lookup_graph
 from .scatter import _SegmentMaxRows, _SegmentSumRows
 
 _FUSED_WIDTHS = (32, 64)
@@ -78,6 +78,8 @@ class _EdgeConvLinearMax(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:3])
         ctx.passthrough = passthrough
         ctx.j16 = False
+        if bf16 or table.cnt is None:
+            table.join()
         if bf16:
             # BASELINE configs[2]: dense layer on the bf16 matrix cores, bf16 Q table (half the gathered bytes);
             # max / add / backward stay fp32 (straight-through over the bf16 roundings)
@@ -93,6 +95,7 @@ class _EdgeConvLinearMax(torch.autograd.Function):
                    and table.max_nodes is not None and table.max_nodes <= _LDS_MAX_EVENT_NODES)
             sliced = lds and _native.GATHER_MAX_FORM != "l2-only" and os.environ.get("DMET_PQ_SLICED", "1") != "0"
             P, Q = _native.node_linear_split(x, weight, bias, sliced=sliced)
+            table.join()    # a table still being built on a side stream (graph.build_async): the dense layer ran beside it
             # radius tables with self loops (train.py:48): remember the winner's id, not its slot, so that the backward
             # needs no look-up in the 255-wide table, and walk the rows in order of their depth
             ctx.j16 = (lds and need_grad and table.nonempty and _native.GATHER_MAX_FORM == "auto"
@@ -314,6 +317,7 @@ class EdgeConv(torch.nn.Module):
         lin = _as_fusable_linear(self.nn) if self.aggr == "max" else None
         if lin is not None and x.shape[1] * 2 == lin.in_features and table.k <= 255:  # arg slot is uint8
             return _EdgeConvLinearMax.apply(x, lin.weight, lin.bias, table, self._use_bf16(lin, table), passthrough)
+        table.join()
         mlp = _as_mlp2(self.nn) if self.aggr in ("max", "add", "sum") else None
         if (mlp is not None and table.cnt is None and self._wants_bf16()
                 and mlp[0].in_features == 2 * x.shape[1]
@@ -369,6 +373,9 @@ class EdgeConv(torch.nn.Module):
             raise ValueError(f"x must be [N, F], got {tuple(x.shape)}")
         if x.dtype != torch.float32:
             raise TypeError(f"x must be float32, got {x.dtype}")
+        if isinstance(edge_index, GraphFuture):
+            # built on a side stream (graph.build_async): the consumer joins as late as it can (NeighborTable.join)
+            edge_index = edge_index.peek() if isinstance(edge_index.peek(), NeighborTable) else edge_index.result()
         if isinstance(edge_index, NeighborTable):
             # the table itself (dm.radius_table / dm.knn_table) instead of an edge_index tensor: same graph, but no
             # [2,E] tensor is ever sized on the host (radius_graph's exact-size result costs one sync per call)
@@ -382,6 +389,8 @@ class EdgeConv(torch.nn.Module):
         """(conv(x), x'): x' is x routed through this operator's autograd node, for blocks of the form
         `x + f(conv(x))` (graph_met_network.py:66).  Using x' for the residual branch makes both gradients of x meet
         in this operator's backward kernel, which adds them while storing gx (no separate elementwise add)."""
+        if isinstance(edge_index, GraphFuture):
+            edge_index = edge_index.peek() if isinstance(edge_index.peek(), NeighborTable) else edge_index.result()
         if torch.is_tensor(x) and x.dim() == 2 and x.dtype == torch.float32:
             if isinstance(edge_index, NeighborTable):
                 return self._forward_table(x, edge_index, passthrough=True)

@@ -17,6 +17,8 @@
 //   B[k = 8 hh + j][col r], j = 0..7;  C/D: col = r, row = (reg & 3) + 8 (reg >> 2) + 4 hh.
 // Numerics: inputs and weights rounded to bf16 (RNE), products exact, fp32 accumulation, ELU / max / sum in fp32:
 // the R6 bf16 bar (rtol 2e-2) against the fp32 oracle.
+#include <type_traits>
+
 #include "common.h"
 
 namespace dmet {
@@ -117,13 +119,13 @@ __global__ __launch_bounds__(256, 2) void edge_mlp2_kernel(const float *__restri
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
     const float ninf = -__builtin_inff();
-    // BN: this lane's sums of m and m^2 over its valid edges, for its 16 channels of each 32-channel block, + edge count
-    float st1[BN ? MB2 : 1][16], st2[BN ? MB2 : 1][16], stc = 0.0f;
+    // BN: this lane's sums of m and m^2 over the valid edges it holds, for channel r of each 32-channel block, + edge count
+    // (round 3: the channel sits on the lane now, so ONE running sum per 32-channel block and lane -- over the edges the lane
+    // holds: half of every tile's; the two halves meet at the end)
+    float st1[BN ? MB2 : 1], st2[BN ? MB2 : 1], stc = 0.0f;
     if (BN) {
 #pragma unroll
-        for (int mb2 = 0; mb2 < MB2; ++mb2)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { st1[mb2][e] = 0.0f; st2[mb2][e] = 0.0f; }
+        for (int mb2 = 0; mb2 < MB2; ++mb2) { st1[mb2] = 0.0f; st2[mb2] = 0.0f; }
     }
 
     for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
@@ -166,71 +168,107 @@ __global__ __launch_bounds__(256, 2) void edge_mlp2_kernel(const float *__restri
                 for (int u = 0; u < 8; ++u) h1f[mb][s][u] = (short)bf16_rne(elu1(acc[8 * s + u]));
         }
         // ---- second layer + aggregation, 32 output channels at a time ---------------------------------------------
+        // Round 3: the second product is computed UN-transposed, z2 = h1 . W2^T (rows = edges, columns = channels) -- the
+        // converted accumulators of the first product are the A operand just as well as the B operand (lane (r, hh) holds
+        // edge r, hidden channels 8 hh + j either way), and the W2 fragments staged as "A of W2" are "B of W2^T" register
+        // for register.  The accumulator then has the CHANNEL on the lane and the 32 edges in the registers (edge
+        // (e & 3) + 8 (e >> 2) + 4 hh), so the reduction over a node's k edges is a v_max3 / add chain over k / 2 registers
+        // of the lane plus one exchange between the two lane halves (v_permlane32_swap) -- ~12 vector instructions per 32
+        // channels where the transposed form needed a DPP butterfly per accumulator register (16 x 8 = 128).
+        const unsigned vmask = (unsigned)__ballot(valid);          // bit r: edge r of the tile is valid (lanes 0..31)
+        const bool all_valid = vmask == 0xFFFFFFFFu;               // wave-uniform: every table without empty slots
+        const unsigned vsh = vmask >> (4 * hh);
 #pragma unroll
         for (int mb2 = 0; mb2 < MB2; ++mb2) {
             f32x16 acc;
+            const float bv = S.b2[32 * mb2 + r];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bv = *reinterpret_cast<const float4 *>(&S.b2[32 * mb2 + 8 * q + 4 * hh]);
-                acc[4 * q] = bv.x; acc[4 * q + 1] = bv.y; acc[4 * q + 2] = bv.z; acc[4 * q + 3] = bv.w;
-            }
+            for (int e = 0; e < 16; ++e) acc[e] = bv;
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S.w2[mb2][ks][lane], h1f[ks >> 1][ks & 1], acc, 0, 0, 0);
-            // messages of this lane's edge for channels 32 mb2 + (e & 3) + 8 (e >> 2) + 4 hh; reduce over the node's k edges
-            float res[16], res2[16];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h1f[ks >> 1][ks & 1], S.w2[mb2][ks][lane], acc, 0, 0, 0);
+            // messages of channel 32 mb2 + r for the edges this lane holds
+            float m[16], mn[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float m0 = act2 ? elu1(acc[e]) : acc[e];
+                const bool ve = all_valid || ((vsh >> ((e & 3) + 8 * (e >> 2))) & 1u);
                 if (BN && partial) {
-                    const float mv = valid ? m0 : 0.0f;
-                    st1[mb2][e] += mv;
-                    st2[mb2][e] = __builtin_fmaf(mv, mv, st2[mb2][e]);
+                    const float mv = ve ? m0 : 0.0f;
+                    st1[mb2] += mv;
+                    st2[mb2] = __builtin_fmaf(mv, mv, st2[mb2]);
                 }
-                float m = valid ? m0 : (ADD ? 0.0f : ninf);
-                m = group_reduce<ADD>(m, k);
-                if (BN) {
-                    res[e] = m;                                // sum, or max with -inf for "no neighbour"
-                    if (!ADD) res2[e] = group_reduce<false>(valid ? -m0 : ninf, k);   // -min
-                } else {
-                    res[e] = (!ADD && m == ninf) ? 0.0f : m;   // a node without any neighbour aggregates to 0 (R3)
-                }
+                m[e] = ve ? m0 : (ADD ? 0.0f : ninf);
+                if (BN && !ADD) mn[e] = ve ? -m0 : ninf;
             }
-            if (live && slot == 0) {
-                float4 *dst = reinterpret_cast<float4 *>(out + node * H2 + 32 * mb2 + 4 * hh);
+            // per node: registers [n k/2, (n+1) k/2) of both lane halves (k is wave-uniform: three straight-line forms)
+            float tot[4], tot2[4];
+            auto fold = [&](auto rpn_c) __attribute__((always_inline)) {
+                constexpr int RPN = decltype(rpn_c)::value;      // registers per node and lane: k / 2
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dst[2 * q] = make_float4(res[4 * q], res[4 * q + 1], res[4 * q + 2], res[4 * q + 3]);
-                if (BN && !ADD) {
-                    float4 *dst2 = reinterpret_cast<float4 *>(out2 + node * H2 + 32 * mb2 + 4 * hh);
+                for (int n = 0; n < 16 / RPN; ++n) {
+                    float a = m[n * RPN], b = (BN && !ADD) ? mn[n * RPN] : ninf;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        dst2[2 * q] = make_float4(-res2[4 * q], -res2[4 * q + 1], -res2[4 * q + 2], -res2[4 * q + 3]);
+                    for (int e = 1; e < RPN; ++e) {
+                        a = ADD ? a + m[n * RPN + e] : __builtin_fmaxf(a, m[n * RPN + e]);
+                        if (BN && !ADD) b = __builtin_fmaxf(b, mn[n * RPN + e]);
+                    }
+                    tot[n] = a; tot2[n] = b;
+                }
+            };
+            tot[0] = tot[1] = tot[2] = tot[3] = 0.0f; tot2[0] = tot2[1] = tot2[2] = tot2[3] = 0.0f;
+            if (k == 16) fold(std::integral_constant<int, 8>{});
+            else if (k == 8) fold(std::integral_constant<int, 4>{});
+            else fold(std::integral_constant<int, 16>{});
+            // exchange between the halves: after swap(V0, V1) lanes 0..31 hold (own V0, upper V0), lanes 32..63 (lower V1,
+            // own V1): with V0 = node 2p, V1 = node 2p + 1 the lower half ends up with node 2p, the upper with node 2p + 1
+            auto combine = [&](float v0, float v1, bool add) -> float {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v0), __float_as_uint(v1), false, false);
+                const float x0 = __uint_as_float(sw[0]), x1 = __uint_as_float(sw[1]);
+                return add ? x0 + x1 : __builtin_fmaxf(x0, x1);
+            };
+            const int pairs = npt >= 2 ? npt / 2 : 1;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (p >= pairs) break;
+                const float v0 = tot[npt >= 2 ? 2 * p : 0], v1 = tot[npt >= 2 ? 2 * p + 1 : 0];
+                float res = combine(v0, v1, ADD);
+                float res2 = 0.0f;
+                if (BN && !ADD) res2 = combine(tot2[npt >= 2 ? 2 * p : 0], tot2[npt >= 2 ? 2 * p + 1 : 0], false);
+                const int64_t onode = tile * npt + (npt >= 2 ? 2 * p + hh : 0);
+                const bool writer = onode < N && (npt >= 2 || hh == 0);
+                if (!BN) res = (!ADD && res == ninf) ? 0.0f : res;     // a node without any neighbour aggregates to 0 (R3)
+                if (writer) {
+                    out[onode * H2 + 32 * mb2 + r] = res;
+                    if (BN && !ADD) out2[onode * H2 + 32 * mb2 + r] = -res2;
                 }
             }
         }
         if (BN) {
-            const float c = group_reduce<true>(valid ? 1.0f : 0.0f, k);     // valid edges of the node
-            if (ADD && live && slot == 0 && hh == 0) out2[node] = c;
+            // valid edges per node from the tile's mask (wave-uniform)
+            if (ADD && r < npt && hh == 0) {
+                const int64_t onode = tile * npt + r;
+                const unsigned bits = k == 32 ? vmask : ((vmask >> (r * k)) & ((1u << k) - 1u));
+                if (onode < N) out2[onode] = (float)__popc(bits);
+            }
             if (hh == 0) stc += valid ? 1.0f : 0.0f;
         }
     }
     if (BN && partial) {
-        // per-WORKGROUP partials [2][H2] + count: sums over the 32 lanes of a half (same channels) by a fixed butterfly,
-        // then the four wavefronts in order through LDS (one partial per wavefront made the one-workgroup finalize
+        // per-WORKGROUP partials [2][H2] + count: the two lane halves (same channel, the other half of the edges) are added
+        // first, then the four wavefronts in order through LDS (one partial per wavefront made the one-workgroup finalize
         // kernel walk 8192 of them: 1 ms)
         __shared__ float pst[4][2 * H2 + 4];
         const int wv = threadIdx.x >> 6;
 #pragma unroll
-        for (int mb2 = 0; mb2 < MB2; ++mb2)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float a = group_reduce<true>(st1[mb2][e], 32), b = group_reduce<true>(st2[mb2][e], 32);
-                if (r == 0) {
-                    const int c = 32 * mb2 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    pst[wv][c] = a;
-                    pst[wv][H2 + c] = b;
-                }
+        for (int mb2 = 0; mb2 < MB2; ++mb2) {
+            const auto sa = __builtin_amdgcn_permlane32_swap(__float_as_uint(st1[mb2]), __float_as_uint(st1[mb2]), false, false);
+            const auto sb = __builtin_amdgcn_permlane32_swap(__float_as_uint(st2[mb2]), __float_as_uint(st2[mb2]), false, false);
+            if (hh == 0) {
+                pst[wv][32 * mb2 + r] = __uint_as_float(sa[0]) + __uint_as_float(sa[1]);
+                pst[wv][H2 + 32 * mb2 + r] = __uint_as_float(sb[0]) + __uint_as_float(sb[1]);
             }
+        }
         const float cc = group_reduce<true>(stc, 32);
         if (lane == 0) pst[wv][2 * H2] = cc;
         __syncthreads();

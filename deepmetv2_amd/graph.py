@@ -225,6 +225,7 @@ class NeighborTable:
         # sized E = N k without asking the device; the expectation is verified by a deferred check (knn_table).  Unlike
         # `dense` it is not relied upon for masking: a short row (non-finite query) still yields 0 and no gradient.
         self.full_rows = full_rows
+        self._pending = None        # a GraphFuture whose side-stream build has not been joined on the consumer's stream
         self.pq = None              # (P, Q, sliced) of the consuming EdgeConv's dense layer when the kNN build carried it
         self.rows16 = rows16        # counted tables: the rows again as event-local uint16 ids (_native.radius(local=True))
         self.nonempty = nonempty    # True: every row holds at least one entry (tables built with self loops)
@@ -241,14 +242,22 @@ class NeighborTable:
         self._edges = None
         self._edge_index = {}
 
+    def join(self) -> "NeighborTable":
+        """Make the table's device tensors usable on the current stream (a table built by graph.build_async; no-op else)."""
+        if self._pending is not None:
+            self._pending.result()
+        return self
+
     def order_by_count(self) -> Optional[torch.Tensor]:
         """Counted tables: per event, the local node indices grouped by slot count (one small kernel, cached)."""
+        self.join()
         if self._order is None and self.cnt is not None and self.ptr is not None:
             self._order = _native.table_order_by_count(self.cnt, self.ptr)
         return self._order
 
     def reverse(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """rev_ptr[N+1], rev_slot[...]: the table positions i*k+s that hold node j, ascending, for every j."""
+        self.join()
         if self._rev is None:
             if self.cnt is None:
                 self._rev = _native.reverse_index(self.nbr.view(-1), self.num_nodes)
@@ -264,6 +273,7 @@ class NeighborTable:
 
     def _rowptr(self):
         """(rowptr[N+1] int32, E): one host sync to learn the edge count (upstream returns exact-size tensors too)."""
+        self.join()
         if self._rp is None:
             if self.dense or self.full_rows:
                 N, k = self.num_nodes, self.k
@@ -296,6 +306,57 @@ class NeighborTable:
 
 
 _graph_registry: Dict[int, Tuple[weakref.ref, int, object]] = {}
+
+
+class GraphFuture:
+    """A graph that is being built on a side HIP stream while the caller goes on enqueueing work that does not need it.
+
+    The reference builds its static graph first and only then calls the model (train.py:48-49), but the model's encoder
+    (embeddings, three dense layers, bn_all; model/graph_met_network.py:48-58) does not depend on the graph.  The radius
+    build is latency-bound (every wavefront resident at once, vector ALU ~50 % busy), so the encoder's kernels fit beside
+    it: `build_async(lambda: radius_table(...))` forks a side stream for the build, and the first operator that is handed
+    the future (`EdgeConv.forward`) joins it.  Inside a captured step the fork / join become graph dependencies."""
+    _side = {}
+
+    def __init__(self, build):
+        dev = torch.cuda.current_device()
+        side = GraphFuture._side.get(dev)
+        if side is None:
+            side = GraphFuture._side[dev] = torch.cuda.Stream(dev)
+        cur = torch.cuda.current_stream(dev)
+        side.wait_stream(cur)                       # the build's inputs are produced on the caller's stream
+        with torch.cuda.stream(side):
+            self._table = build()
+        self._side_stream = side
+        self._joined = False
+        if isinstance(self._table, NeighborTable):
+            self._table._pending = self          # consumers of the table's tensors join through NeighborTable.join()
+
+    def peek(self):
+        """The graph object WITHOUT joining: its host-side fields (sizes, largest event) are final, its device tensors
+        are not ready on the caller's stream until `result()` / `NeighborTable.join()` ran."""
+        return self._table
+
+    def result(self):
+        """The finished graph, on the caller's current stream (a device-side wait; the host does not block)."""
+        if not self._joined:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._side_stream)
+            t = self._table
+            for name in ("nbr", "cnt", "rows16", "nbr_local", "dist"):
+                v = getattr(t, name, None)
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(cur)            # allocated on the side stream, consumed on this one
+            self._joined = True
+            if isinstance(t, NeighborTable):
+                t._pending = None
+        return self._table
+
+
+def build_async(build) -> GraphFuture:
+    """Run `build()` (e.g. `lambda: radius_table(etaphi, r, batch, ...)`) on a side stream; hand the returned future to the
+    model where it expects `edge_index`."""
+    return GraphFuture(build)
 
 
 def lookup_graph(edge_index: torch.Tensor):

@@ -4,6 +4,7 @@ Bars: kNN indices bit-exact; EdgeConv features |d| <= 
 reassociates W.[x_i||x_j-x_i] into (W1-W2).x_i + W2.x_j); MET sums relative 1e-5 of sum|w*p|.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -11,6 +12,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 FEAT_RTOL, FEAT_ATOL = 1e-5, 1e-5
+
+
+def _default_path_only(switch, value, why):
+    """tools/toggle_sweep.sh runs this suite under every diagnostic switch.  A test that asserts a property OF THE DEFAULT
+    PATH ITSELF (its counters, its table layouts) has nothing to say under a switch that leaves that path; it says so here,
+    with the reason, instead of failing."""
+    import os
+    if os.environ.get(switch) == value:
+        pytest.skip(f"{switch}={value}: {why}")
 
 
 def _ragged(sizes, D, seed, dup=False):
@@ -150,8 +160,9 @@ def test_knn_matrix_core_path_certification(dev, case):
         assert st["flagged_queries"] == 0, st
     if case == "outliers":    # only the outlier queries themselves (1 in 97) may be beyond bf16-split certification
         assert st["flagged_queries"] <= N // 97 + 1, st
-    if case == "identical":
-        assert st["flagged_tiles"] > 0, st            # the fallback really ran
+    if case == "identical" and os.environ.get("DMET_KNN_PATH") != "exact":
+        assert st["flagged_tiles"] > 0, st            # the fallback really ran (under DMET_KNN_PATH=exact nothing is flagged:
+                                                      # the exact kernel computes every tile by itself)
 
 
 def test_knn_matrix_core_vs_exact_kernel_full_size(dev, monkeypatch):
@@ -184,7 +195,8 @@ def test_knn_oversized_event_goes_to_exact_kernel(dev, monkeypatch):
     x = torch.randn(sum(sizes), 32, generator=g)
     ptr = torch.tensor([0, 66000, 66700])
     nbr, dist, st = _knn_with_stats(x.to(dev), ptr.to(dev), 16)
-    assert st["flagged_queries"] >= 66000 and st["flagged_queries"] < 66000 + 16, st
+    if os.environ.get("DMET_KNN_PATH") != "exact":      # (the property of the matrix-core path: the oversized event is handed over)
+        assert st["flagged_queries"] >= 66000 and st["flagged_queries"] < 66000 + 16, st
     monkeypatch.setenv("DMET_KNN_PATH", "exact")
     nbr_x, dist_x, st_x = _knn_with_stats(x.to(dev), ptr.to(dev), 16)
     assert st_x["flagged_queries"] == 0
@@ -599,6 +611,8 @@ def test_gather_max_local_ids_kernel_matches(dev, k):
     """K3: the LDS gather kernel fed with the uint16 event-local table must return the bits of the int32 form (and
     of the L2 form), including an event too large for the LDS image (reads the int32 table) and empty events."""
     from deepmetv2_amd import _native
+    _default_path_only("DMET_GATHER_MAX_FORM", "l2-only", "the slice-major / LDS-resident forms compared here are switched off "
+                       "(gather_max raises ValueError for slice-major tables by design)")
     sizes = [300, 1, 0, 77, 5200, 4500]
     x, batch, ptr = _ragged(sizes, 32, seed=11 + k)
     xd, ptrd = x.to(dev), ptr.to(dev)
@@ -634,6 +648,7 @@ def test_gather_max_work_mappings_agree(dev, monkeypatch):
     walking equal ranges of the [event][slice][node] axis, whose boundaries cut events and slices) must give the
     same bits on a ragged batch with empty, tiny and oversized events, for both table forms and P / Q layouts."""
     from deepmetv2_amd import _native
+    _default_path_only("DMET_GATHER_MAX_FORM", "l2-only", "both mappings under test belong to the LDS-resident kernel")
     sizes = [1900, 0, 3, 4800, 64, 5150, 1, 2500, 700]
     x, batch, ptr = _ragged(sizes, 32, seed=21)
     xd, ptrd = x.to(dev), ptr.to(dev)
@@ -1130,6 +1145,7 @@ def test_counted_gather_winner_ids_and_ordered_rows(dev):
     be the slot form's winners, and the backward scatter fed by the ids must equal the one that looks the ids up."""
     import deepmetv2_amd as dm
     from deepmetv2_amd import _native
+    _default_path_only("DMET_GATHER_MAX_FORM", "l2-only", "the winner-id form is an LDS-resident kernel reading slice-major tables")
     g = torch.Generator().manual_seed(31)
     sizes = [1200, 0, 37, 900, 2100]
     N = sum(sizes)
@@ -1325,6 +1341,12 @@ def test_batch_norm_transform_rides_in_the_knn_prep(dev, sizes, with_res):
     assert torch.equal(y, y_ref)
     nbr0, dist0, loc0, pq0 = _native.knn_local_dense(y_ref, pd, 16, Wd, bbd, True)
     assert torch.equal(nbr, nbr0) and torch.equal(dist, dist0) and torch.equal(loc, loc0)
+    if os.environ.get("DMET_KNN_FILTER") == "1":
+        # the first filter form alone (knn_filter_kernel, every event) carries the BatchNorm transform in the shared prep
+        # launch (everything above held) but has no rider workgroups for the dense layer: both entries report
+        # dense_done = 0 and the layer launches node_linear_split itself (conv._EdgeConvLinearMax)
+        assert pq is None and pq0 is None
+        return
     assert pq is not None and torch.equal(pq[0], pq0[0]) and torch.equal(pq[1], pq0[1])
 
 
@@ -1365,3 +1387,49 @@ def test_model_with_fused_transform_matches_unfused(dev, monkeypatch):
             monkeypatch.setattr(dense, "HEAD_FUSE", fuse)
             ev.append(model(*split_features(xd), None, bd).clone())
     assert torch.equal(ev[0], ev[1])
+
+
+def test_async_graph_build_matches_inline(dev):
+    """graph.build_async: the radius table built on a side stream beside the encoder and joined by the first EdgeConv gives
+    the bits of the inline build -- eager and inside a captured step (parallel.GraphedTrainStep)."""
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import synth
+    from deepmetv2_amd.model import Net
+    from deepmetv2_amd.optim import FlatAdamW
+    from deepmetv2_amd.parallel import FlatModule, GradSync, GraphedTrainStep, train_step
+    sizes = [700, 90, 1300]
+    x, y, batch, ptr = synth.make_events(sizes, seed=15, device=dev)
+    dm.register_batch(batch, ptr, len(sizes), max_nodes=max(sizes), min_nodes=min(sizes))
+
+    def radius(xx):
+        etaphi = torch.stack([xx[:, 3], torch.atan2(xx[:, 1], xx[:, 0])], 1)
+        return dm.radius_table(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255)
+
+    finals = []
+    for mode in ("inline", "async", "async-graphed"):
+        torch.manual_seed(4)
+        model = Net(8, 3, graph="static", k=16).to(dev).train()
+        flat = FlatModule(model); sync = GradSync(flat)
+        opt = FlatAdamW([flat.flat_param], lr=1e-3)
+        graph_fn = radius if mode == "inline" else (lambda xx: dm.build_async(lambda: radius(xx)))
+        if mode == "async-graphed":
+            p0 = flat.flat_param.detach().clone()
+            bufs0 = [b.detach().clone() for b in model.buffers()]
+            step = GraphedTrainStep(model, flat, sync, opt, x, y, batch, ptr, warmup=1, graph_fn=graph_fn)
+            with torch.no_grad():
+                flat.flat_param.copy_(p0)
+                for b, b0 in zip(model.buffers(), bufs0):
+                    b.copy_(b0)
+                for st in opt.state.values():
+                    for name, v in st.items():
+                        if name == "bias_pow":
+                            v.fill_(1.0)
+                        elif torch.is_tensor(v) and name != "lr_dev":
+                            v.zero_()
+        for _ in range(3):
+            loss = step() if mode == "async-graphed" else train_step(model, flat, sync, opt, x, y, batch, ptr,
+                                                                     edge_index=graph_fn(x))
+        torch.cuda.synchronize()
+        finals.append((flat.flat_param.detach().clone(), float(loss)))
+    for other in finals[1:]:
+        assert other[1] == finals[0][1] and torch.equal(other[0], finals[0][0])
