@@ -274,11 +274,13 @@ def gather_roofline(args, ksum, ev_overhead_ms, model, x, batch, ptr, sizes, sta
                            "ids and outputs cold; FETCH_SIZE counts Infinity-Cache hits, so `frac` is not a pure DRAM figure"}
     # HBM-side traffic from PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, profiles/README.md)
     # cannot be collected from inside this process: quoted from the committed summary of this round, if present
-    tpath = os.path.join(ROOT, "profiles", "r02_pmc_gather_max.json")
-    if args.dtype == "f32" and args.graph == "dynamic" and args.ragged is None and os.path.exists(tpath):
+    import glob
+    tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_gather_max.json")))
+    if args.dtype == "f32" and args.graph == "dynamic" and args.ragged is None and tpaths:
         try:
-            roof["traffic"] = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            roof["traffic_source"] = "profiles/r02_pmc_gather_max.json (rocprofv3 PMC run of this bench command)"
+            roof["traffic"] = json.load(open(tpaths[-1])).get("hbm_bytes_per_launch")
+            roof["traffic_source"] = (f"profiles/{os.path.basename(tpaths[-1])} (rocprofv3 PMC passes of this bench command, "
+                                      "collected by tools/collect_profiles.sh: a committed figure, not measured by this process)")
         except Exception:
             pass
     # untimed legs: the same kernel form standalone, warm and cold

@@ -41,6 +41,7 @@ SIGNATURES = {
     "dmet_edgeconv_fused_lds_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dmet_node_linear_split_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "dmet_node_linear_split_sliced_f32": (_i, [_vp, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dmet_bn_node_linear_split_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "dmet_gather_max_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "dmet_gather_max_counted_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp]),
     "dmet_gather_max_lds_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),

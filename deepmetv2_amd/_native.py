@@ -276,6 +276,43 @@ def node_linear_split(x: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor
     return PQ[0], PQ[1]
 
 
+def bn_node_linear_split(raw: torch.Tensor, residual: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                         mean: torch.Tensor, invstd: torch.Tensor, W: torch.Tensor, b: Optional[torch.Tensor],
+                         sliced: bool = False):
+    """(y, P, Q): y = residual + BatchNorm(raw) (statistics given; the bits of bn_fwd's transform) and the dense layer
+    node_linear_split(y, W, b, sliced) in ONE launch (dmet_bn_node_linear_split_f32), or None when the operands do not
+    qualify (32 -> 32 features, 16-byte aligned vectors)."""
+    dev = _require_device(raw, gamma, beta, mean, invstd, W)
+    L = _lib.load()
+    if raw.dim() != 2 or raw.shape[1] != 32 or tuple(W.shape) != (32, 64) or raw.dtype != torch.float32:
+        return None
+    raw = _f32c(raw, "raw"); W = _f32c(W, "W")
+    vecs = [_f32c(t, "bn vector") for t in (gamma, beta, mean, invstd)]
+    if residual is not None:
+        residual = _f32c(residual, "residual")
+        if residual.shape != raw.shape:
+            raise ValueError("bn_node_linear_split: residual must have the shape of raw")
+    bp = _f32c(b, "b") if b is not None else None
+    if any(t.data_ptr() % 16 for t in vecs) or raw.data_ptr() % 16 or (residual is not None and residual.data_ptr() % 16):
+        return None
+    N = raw.shape[0]
+    y = torch.empty_like(raw)
+    PQ = torch.empty((2, 4, N, 8) if sliced else (2, N, 32), dtype=torch.float32, device=dev)
+    if N == 0:
+        return y, PQ[0], PQ[1]
+    _t = timer.record('node_linear_split', dev)
+    with _on(dev):
+        _lib.check(L.dmet_bn_node_linear_split_f32(raw.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                                   vecs[0].data_ptr(), vecs[1].data_ptr(), vecs[2].data_ptr(),
+                                                   vecs[3].data_ptr(), y.data_ptr(), N, 32, W.data_ptr(),
+                                                   bp.data_ptr() if bp is not None else None, 1 if sliced else 0,
+                                                   PQ[0].data_ptr(), PQ[1].data_ptr(), _stream(dev)),
+                   "dmet_bn_node_linear_split_f32")
+    if _t is not None:
+        _t.record(torch.cuda.current_stream(dev))
+    return y, PQ[0], PQ[1]
+
+
 def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optional[torch.Tensor],
                want_arg: bool, cnt: Optional[torch.Tensor] = None, lds: bool = False,
                nbr_local: Optional[torch.Tensor] = None, sliced: bool = False, mixed: bool = False

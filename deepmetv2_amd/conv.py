@@ -94,7 +94,12 @@ class _EdgeConvLinearMax(torch.autograd.Function):
             lds = (x.shape[1] == 32 and weight.shape[0] == 32 and table.ptr is not None
                    and table.max_nodes is not None and table.max_nodes <= _LDS_MAX_EVENT_NODES)
             sliced = lds and _native.GATHER_MAX_FORM != "l2-only" and os.environ.get("DMET_PQ_SLICED", "1") != "0"
-            P, Q = _native.node_linear_split(x, weight, bias, sliced=sliced)
+            pq = table.pq
+            table.pq = None
+            if pq is not None and pq[2] is bool(sliced) and pq[0].shape[-2 if sliced else 0] == x.shape[0]:
+                P, Q = pq[0], pq[1]     # formed together with x by the BatchNorm before (EdgeConv.prebuild_hook)
+            else:
+                P, Q = _native.node_linear_split(x, weight, bias, sliced=sliced)
             table.join()    # a table still being built on a side stream (graph.build_async): the dense layer ran beside it
             # radius tables with self loops (train.py:48): remember the winner's id, not its slot, so that the backward
             # needs no look-up in the 255-wide table, and walk the rows in order of their depth
@@ -316,6 +321,8 @@ class EdgeConv(torch.nn.Module):
     def _forward_table(self, x: torch.Tensor, table: NeighborTable, passthrough: bool = False):
         lin = _as_fusable_linear(self.nn) if self.aggr == "max" else None
         if lin is not None and x.shape[1] * 2 == lin.in_features and table.k <= 255:  # arg slot is uint8
+            if table.cnt is not None:
+                self._take_prebuilt_pq(x, table)
             return _EdgeConvLinearMax.apply(x, lin.weight, lin.bias, table, self._use_bf16(lin, table), passthrough)
         table.join()
         mlp = _as_mlp2(self.nn) if self.aggr in ("max", "add", "sum") else None
@@ -385,6 +392,44 @@ class EdgeConv(torch.nn.Module):
             return self._forward_table(x, hit[0])
         return self._forward_edges(x, edge_list_from_edge_index(edge_index, x.shape[0], self.flow))
 
+    # -- BatchNorm transform of the PREVIOUS block fused into this layer's node-level dense layer (static graphs) --------
+    def prebuild_hook(self, batch=None, graph=None):
+        """A callable for dense.batch_norm(..., next_build=...) when this EdgeConv will convolve over the static `graph`
+        (a NeighborTable / GraphFuture / the [2,E] tensor of radius_graph; model/graph_met_network.py:65): given the
+        BatchNorm's input, residual, affine parameters and statistics it forms y = residual + BN(raw) inside the launch of
+        this layer's dense layer (dmet_bn_node_linear_split_f32), keeps (P, Q) for the forward call on that y and returns
+        y.  None when this layer cannot use it (DMET_BN_NLS_FUSE=0, not the fused Linear(64 -> 32) max form)."""
+        if os.environ.get("DMET_BN_NLS_FUSE", "1") == "0" or self.aggr != "max" or EDGECONV_FORM != "split":
+            return None
+        lin = _as_fusable_linear(self.nn)
+        if lin is None or lin.in_features != 64 or lin.out_features != 32 or self._wants_bf16():
+            return None
+        table = graph.peek() if isinstance(graph, GraphFuture) else graph
+        if torch.is_tensor(table):
+            hit = lookup_graph(table)
+            table = hit[0] if hit is not None and hit[1] == self.flow else None
+        if not isinstance(table, NeighborTable) or table.cnt is None:
+            return None
+        lds = table.ptr is not None and table.max_nodes is not None and table.max_nodes <= _LDS_MAX_EVENT_NODES
+        sliced = bool(lds and _native.GATHER_MAX_FORM != "l2-only" and os.environ.get("DMET_PQ_SLICED", "1") != "0")
+
+        def build(raw, residual, gamma, beta, mean, invstd):
+            if not raw.is_cuda or raw.dim() != 2 or raw.shape[0] != table.num_nodes:
+                return None
+            out = _native.bn_node_linear_split(raw, residual, gamma, beta, mean, invstd, lin.weight.detach(),
+                                               lin.bias.detach() if lin.bias is not None else None, sliced)
+            if out is None:
+                return None
+            y, P, Q = out
+            self._prebuilt_pq = (y, P, Q, sliced)
+            return y
+        return build
+
+    def _take_prebuilt_pq(self, x: torch.Tensor, table: NeighborTable) -> None:
+        pre, self._prebuilt_pq = getattr(self, "_prebuilt_pq", None), None
+        if pre is not None and pre[0].data_ptr() == x.data_ptr() and pre[0].shape == x.shape:
+            table.pq = (pre[1], pre[2], pre[3])
+
     def forward_with_residual_input(self, x: torch.Tensor, edge_index: torch.Tensor):
         """(conv(x), x'): x' is x routed through this operator's autograd node, for blocks of the form
         `x + f(conv(x))` (graph_met_network.py:66).  Using x' for the residual branch makes both gradients of x meet
@@ -441,7 +486,7 @@ class DynamicEdgeConv(EdgeConv):
         return self._forward_table(x, table, passthrough=True)
 
     # -- BatchNorm transform of the PREVIOUS block fused into this layer's graph build --------------------------------
-    def prebuild_hook(self, batch: Optional[torch.Tensor]):
+    def prebuild_hook(self, batch: Optional[torch.Tensor] = None, graph=None):
         """A callable for dense.batch_norm(..., next_build=...): given the BatchNorm's input, residual, affine parameters
         and batch statistics it runs this layer's graph build with the transform fused into the prep launch
         (dmet_bn_knn_local_dense_f32) and returns y = residual + BN(raw); the table is kept for the forward call on that

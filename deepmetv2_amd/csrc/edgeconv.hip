@@ -13,6 +13,8 @@
 
 #include <hip/hip_bf16.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "nls_body.h"
 
@@ -36,6 +38,20 @@ __global__ __launch_bounds__(256) void node_linear_split_kernel(const float *__r
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     node_linear_split_wave<HIN, HOUT, SLICED>(x, N, W, bias, P, Q, tpose[SLICED ? wv : 0], wave, nwaves, threadIdx.x & 63);
+}
+
+// the same with the rows FORMED as residual + BatchNorm(raw) and written to aff.y (NlsAffine, csrc/nls_body.h)
+template <int HIN, int HOUT, bool SLICED>
+__global__ __launch_bounds__(256) void node_linear_split_bn_kernel(NlsAffine aff, int64_t N, const float *__restrict__ W,
+                                                                    const float *__restrict__ bias,
+                                                                    float *__restrict__ P, float *__restrict__ Q)
+{
+    __shared__ __attribute__((aligned(16))) float tpose[SLICED ? 4 : 1][SLICED ? kNlsLdsFloats : 1];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    node_linear_split_wave<HIN, HOUT, SLICED, true>(nullptr, N, W, bias, P, Q, tpose[SLICED ? wv : 0], wave, nwaves,
+                                                    threadIdx.x & 63, aff);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -647,6 +663,11 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_counted_kern
         if (threadIdx.x < 2) qs[n * 2 + threadIdx.x] = make_float4(ninf, ninf, ninf, ninf);   // the -inf row
         __syncthreads();
     }
+    // Round 3: the LDS / global choice is block-uniform, but as a run-time value inside the slot loop hipcc compiled it
+    // as a branch pair PER SLOT -- every one of a chunk's eight LDS reads was followed by its own s_waitcnt (eight
+    // serialised LDS round trips per chunk).  As a compile-time constant of the row loop the eight reads issue back to back.
+    auto rows = [&](auto in_lds_c) __attribute__((always_inline)) {
+    constexpr bool in_lds = decltype(in_lds_c)::value;
     for (int r = r0; r < n; r += RPI) {
         const int64_t node = lo + (order ? order[lo + r] : r);
         const int32_t *row = nbr + node * kmax;
@@ -727,6 +748,9 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_counted_kern
             }
         }
     }
+    };
+    if (in_lds) rows(std::true_type{});
+    else rows(std::false_type{});
 }
 
 // order[ptr[b] .. ptr[b+1]) = the event's local node indices grouped by slot count, deepest rows first (counting sort
@@ -1109,6 +1133,32 @@ extern "C" int dmet_node_linear_split_sliced_f32(const float *x, int64_t N, int 
     if (Hin == 32 && Hout == 64) return launch_node_linear<32, 64, true>(x, N, W, b, P, Q, st);
     set_error("dmet_node_linear_split_sliced_f32: unsupported (Hin,Hout)=(%d,%d); supported: 32/64", Hin, Hout);
     return -22;
+}
+
+extern "C" int dmet_bn_node_linear_split_f32(const float *raw, const float *residual, const float *gamma, const float *beta,
+                                             const float *mean, const float *invstd, float *y, int64_t N, int H,
+                                             const float *W, const float *b, int sliced, float *P, float *Q,
+                                             dmet_stream_t stream)
+{
+    DMET_REQUIRE(N >= 0, "dmet_bn_node_linear_split_f32: N<0");
+    if (N == 0) return 0;
+    DMET_REQUIRE(H == 32, "dmet_bn_node_linear_split_f32: H=%d (built for 32 -> 32)", H);
+    DMET_REQUIRE(raw && gamma && beta && mean && invstd && y && W && P && Q, "dmet_bn_node_linear_split_f32: null pointer");
+    DMET_REQUIRE(aligned16(raw) && aligned16(y) && aligned16(P) && aligned16(Q) && aligned16(gamma) && aligned16(beta) &&
+                     aligned16(mean) && aligned16(invstd) && (!residual || aligned16(residual)),
+                 "dmet_bn_node_linear_split_f32: pointers must be 16-B aligned");
+    NlsAffine aff{raw, residual, gamma, beta, mean, invstd, y};
+    const int64_t ntiles = (N + 31) / 32;
+    int64_t blocks = (ntiles + 3) / 4;
+    if (blocks > num_cus()) blocks = num_cus();
+    if (blocks < 1) blocks = 1;
+    hipStream_t st = as_stream(stream);
+    if (sliced)
+        hipLaunchKernelGGL((node_linear_split_bn_kernel<32, 32, true>), dim3((unsigned)blocks), dim3(256), 0, st, aff, N, W, b, P, Q);
+    else
+        hipLaunchKernelGGL((node_linear_split_bn_kernel<32, 32, false>), dim3((unsigned)blocks), dim3(256), 0, st, aff, N, W, b, P, Q);
+    DMET_LAUNCH_CHECK("node_linear_split_bn_kernel");
+    return 0;
 }
 
 extern "C" int dmet_gather_max_counted_f32(const float *P, const float *Q, const int32_t *nbr, const int32_t *cnt,

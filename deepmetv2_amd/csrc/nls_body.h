@@ -23,12 +23,21 @@ constexpr int kNlsLdsFloats = 2 * 32 * kNlsTP;     // per wavefront (SLICED only
 // SLICED: P and Q are written slice-major, [HOUT/8][N][8] (the 8-channel slice of every node contiguous), which is how
 // gather_max_lds_kernel's (event, slice) workgroups read them: their LDS staging and P reads become contiguous
 // streams instead of 32-byte pieces of 128-byte rows.  `tp`: kNlsLdsFloats floats of LDS owned by this wavefront.
-template <int HIN, int HOUT, bool SLICED>
+// AFFINE (round 3, the static flow: model/graph_met_network.py:65-66 -- no kNN prep launch for the transform to ride in):
+// the rows are not read but FORMED, y = residual + BatchNorm(raw) with the expression of bn_apply_kernel (csrc/norm.hip:
+// same bits), stored to aff.y (the block's output, needed by the residual branch and the backward) and fed to the matrix
+// cores from the registers: one pass over the rows and one launch less than transform + dense layer.
+struct NlsAffine {
+    const float *raw, *res, *gamma, *beta, *mean, *invstd;
+    float *y;
+};
+
+template <int HIN, int HOUT, bool SLICED, bool AFFINE = false>
 __device__ __forceinline__ void node_linear_split_wave(const float *__restrict__ x, int64_t N,
                                                        const float *__restrict__ W, const float *__restrict__ bias,
                                                        float *__restrict__ P, float *__restrict__ Q,
                                                        float *__restrict__ tp, const int64_t wave, const int64_t nwaves,
-                                                       const int lane)
+                                                       const int lane, const NlsAffine aff = NlsAffine{})
 {
     constexpr int KS = HIN / 2;     // k-steps
     constexpr int JT = HOUT / 32;   // output column tiles
@@ -53,20 +62,50 @@ __device__ __forceinline__ void node_linear_split_wave(const float *__restrict__
 
     // the rows of the NEXT tile are loaded while the matrix products of the current one run (second session of round 2:
     // load / wait / 32 MFMAs / store left the matrix pipe 24 % busy with 43 % of the wave cycles in s_waitcnt)
-    float4 nxt[KS / 4];
+    float4 nxt[KS / 4], nxr[AFFINE ? KS / 4 : 1];
+    // AFFINE: this lane's KS features' constants (mean, gamma * invstd, beta), formed exactly as bn_apply_kernel forms them
+    float4 cmu[AFFINE ? KS / 4 : 1], csc[AFFINE ? KS / 4 : 1], cbe[AFFINE ? KS / 4 : 1];
+    if constexpr (AFFINE) {
+#pragma unroll
+        for (int s = 0; s < KS / 4; ++s) {
+            const int f4 = (KS * h) / 4 + s;
+            const float4 ga = reinterpret_cast<const float4 *>(aff.gamma)[f4], is = reinterpret_cast<const float4 *>(aff.invstd)[f4];
+            cmu[s] = reinterpret_cast<const float4 *>(aff.mean)[f4];
+            cbe[s] = reinterpret_cast<const float4 *>(aff.beta)[f4];
+            csc[s] = make_float4(ga.x * is.x, ga.y * is.y, ga.z * is.z, ga.w * is.w);
+        }
+    }
     auto fetch = [&](const int64_t tile) __attribute__((always_inline)) {
         const int64_t node = tile * 32 + r;
         const int64_t nload = node < N ? node : N - 1;
-        const float4 *src = reinterpret_cast<const float4 *>(x + nload * HIN + KS * h);
+        const float4 *src = reinterpret_cast<const float4 *>((AFFINE ? aff.raw : x) + nload * HIN + KS * h);
 #pragma unroll
         for (int s = 0; s < KS / 4; ++s) nxt[s] = src[s];
+        if constexpr (AFFINE) {
+            if (aff.res) {
+                const float4 *rs = reinterpret_cast<const float4 *>(aff.res + nload * HIN + KS * h);
+#pragma unroll
+                for (int s = 0; s < KS / 4; ++s) nxr[s] = rs[s];
+            }
+        }
     };
     if (wave < ntiles) fetch(wave);
     for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
         float a[KS];
 #pragma unroll
         for (int s = 0; s < KS; s += 4) {
-            const float4 v = nxt[s / 4];
+            float4 v = nxt[s / 4];
+            if constexpr (AFFINE) {
+                const float4 mu = cmu[s / 4], sc = csc[s / 4], be = cbe[s / 4];
+                v.x = (v.x - mu.x) * sc.x + be.x; v.y = (v.y - mu.y) * sc.y + be.y;
+                v.z = (v.z - mu.z) * sc.z + be.z; v.w = (v.w - mu.w) * sc.w + be.w;
+                if (aff.res) {
+                    const float4 rr = nxr[s / 4];
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                const int64_t node = tile * 32 + r;
+                if (node < N) reinterpret_cast<float4 *>(aff.y + node * HIN + KS * h)[s / 4] = v;
+            }
             a[s] = v.x; a[s + 1] = v.y; a[s + 2] = v.z; a[s + 3] = v.w;
         }
         if (tile + nwaves < ntiles) fetch(tile + nwaves);

@@ -60,21 +60,24 @@ class GraphMETNetwork(nn.Module):
                 and x_cat.shape[1] == 3 and self.encode_all[0].weight.shape == (32, 32)
                 and list(self.pdgs) == list(PDG_CLASSES) and not x_cont.requires_grad)
 
-    def _next_build(self, layer: int, batch):
-        """The prebuild hook of convolution `layer` when it is a DynamicEdgeConv (its kNN build can carry the BatchNorm
-        transform that produces its input: dense.batch_norm(..., next_build=...)); None otherwise."""
-        if self.graph != "dynamic" or layer >= len(self.conv_continuous):
+    def _next_build(self, layer: int, batch, graph=None):
+        """The prebuild hook of convolution `layer`: a DynamicEdgeConv's kNN build, or a static EdgeConv's node-level dense
+        layer, can carry the BatchNorm transform that produces its input (dense.batch_norm(..., next_build=...)); None
+        when there is no such layer or it cannot."""
+        if layer >= len(self.conv_continuous):
             return None
         hook = getattr(self.conv_continuous[layer][0], "prebuild_hook", None)
-        return hook(batch) if hook is not None else None
+        if hook is None:
+            return None
+        return hook(batch) if self.graph == "dynamic" else hook(batch, graph=graph)
 
-    def embed(self, x_cont: torch.Tensor, x_cat: torch.Tensor, batch=None, fuse_next: bool = False) -> torch.Tensor:
+    def embed(self, x_cont: torch.Tensor, x_cat: torch.Tensor, batch=None, fuse_next: bool = False, graph=None) -> torch.Tensor:
         """Per-node encoder (graph_met_network.py:48-58): columns of x_cat are (pdgId, charge, fromPV).
         The standard shape (8 continuous columns, hidden_dim 32) runs as one HIP kernel each way (csrc/encoder.hip);
         anything else takes the layer-by-layer route below."""
         if self._fused_encoder_ok(x_cont, x_cat):
             lc, lk, la = self.embed_continuous[0], self.embed_categorical[0], self.encode_all[0]
-            return dense.encode_bn(x_cont, x_cat, self.bn_all, self._next_build(0, batch) if fuse_next else None,
+            return dense.encode_bn(x_cont, x_cat, self.bn_all, self._next_build(0, batch, graph) if fuse_next else None,
                                    lc.weight, lc.bias, lk.weight, lk.bias, la.weight, la.bias,
                                    self.embed_charge.weight, self.embed_pdgid.weight, self.embed_pv.weight)
         if x_cat.is_floating_point():      # split_features(x, lazy_cat=True) on the layer-by-layer route
@@ -97,12 +100,12 @@ class GraphMETNetwork(nn.Module):
     def forward(self, x_cont, x_cat, edge_index, batch, apply_sigmoid: bool = False):
         """Per-node logit (graph_met_network.py:60-69); apply_sigmoid=True returns sigmoid(logit) instead (what
         Net does), which lets the standard head shape run as one HIP kernel each way (csrc/head.hip)."""
-        emb = self.embed(x_cont, x_cat, batch, fuse_next=True)
+        emb = self.embed(x_cont, x_cat, batch, fuse_next=True, graph=edge_index)
         for layer, (conv, norm) in enumerate(self.conv_continuous):
             # res is emb routed through the conv's autograd node: both gradients of emb meet in its backward
             msg, res = conv.forward_with_residual_input(emb, batch if self.graph == "dynamic" else edge_index)
             # emb + norm(msg) in one streaming pass -- inside the next layer's graph build when that is a kNN build
-            nb = self._next_build(layer + 1, batch)
+            nb = self._next_build(layer + 1, batch, edge_index)
             if nb is None and layer + 1 == len(self.conv_continuous) and apply_sigmoid and self._fused_head_ok(res):
                 l1, l2 = self.output[0], self.output[2]     # last block: the transform rides in the head's forward launch
                 nb = dense.head_prebuild_hook(l1.weight, l1.bias, l2.weight, l2.bias)

@@ -155,6 +155,15 @@ int dmet_gather_max_f32(const float *P, const float *Q, const int32_t *nbr, cons
  * H % 8 == 0.  Same results as dmet_node_linear_split_f32 + dmet_gather_max_lds_f32. */
 int dmet_node_linear_split_sliced_f32(const float *x, int64_t N, int Hin, int Hout, const float *W,
                                       const float *b, float *P, float *Q, dmet_stream_t stream);
+/* The same dense layer with its input rows FORMED on the fly as y = residual + BatchNorm(raw) -- the block shape
+ * `emb = emb + bn(conv(emb, edge_index))` of model/graph_met_network.py:65-66 followed by the next EdgeConv over the SAME
+ * static graph (the reference's active flow, train.py:48: no kNN build whose prep launch could carry the transform):
+ * y[N,H] is written (the block's output), P / Q are computed from the registers; y has the bits of dmet_bn_fwd_f32's
+ * transform, P / Q those of dmet_node_linear_split[_sliced]_f32 on that y.  mean / invstd: dmet_bn_stats_f32 (training)
+ * or dmet_bn_eval_stats_f32.  residual may be NULL.  H = 32 -> 32 only; sliced != 0: slice-major P / Q. */
+int dmet_bn_node_linear_split_f32(const float *raw, const float *residual, const float *gamma, const float *beta,
+                                  const float *mean, const float *invstd, float *y, int64_t N, int H, const float *W,
+                                  const float *b, int sliced, float *P, float *Q, dmet_stream_t stream);
 int dmet_gather_max_lds_sliced_f32(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr_local,
                                    const int64_t *ptr, int B, int64_t N, int k, int H, float *out, uint8_t *arg,
                                    dmet_stream_t stream);

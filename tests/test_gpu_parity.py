@@ -1433,3 +1433,60 @@ def test_async_graph_build_matches_inline(dev):
         finals.append((flat.flat_param.detach().clone(), float(loss)))
     for other in finals[1:]:
         assert other[1] == finals[0][1] and torch.equal(other[0], finals[0][0])
+
+
+@pytest.mark.parametrize("graph_kind", ["table", "edge_index", "future"])
+def test_static_model_with_transform_in_the_dense_layer_matches_unfused(dev, monkeypatch, graph_kind):
+    """The reference's active flow (one radius graph per batch, model/graph_met_network.py:65): the BatchNorm transform that
+    produces an EdgeConv's input formed inside that layer's node-level dense layer launch (dmet_bn_node_linear_split_f32,
+    EdgeConv.prebuild_hook) against the separate transform pass -- whole model, forward, backward, buffers, bit for bit;
+    with the graph handed over as the table, as radius_graph's [2,E] tensor and as a side-stream future; an event beyond
+    the LDS image (row-major P / Q) included; eval mode too."""
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import _native, synth
+    from deepmetv2_amd.model import Net, loss_fn, split_features
+    sizes = [900, 2500, 64, 5300] if graph_kind == "table" else [900, 2500, 64, 300]
+    x, y, batch, ptr = synth.make_events(sizes, seed=14, device=dev)
+    dm.register_batch(batch, ptr, len(sizes), max_nodes=max(sizes), min_nodes=min(sizes))
+    etaphi = torch.stack([x[:, 3], torch.atan2(x[:, 1], x[:, 0])], 1)
+
+    def graph():
+        if graph_kind == "edge_index":
+            return dm.radius_graph(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255)
+        build = lambda: dm.radius_table(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255)
+        return dm.build_async(build) if graph_kind == "future" else build()
+
+    torch.manual_seed(6)
+    model = Net(8, 3, graph="static", k=16).to(dev).train()
+    calls = []
+    real = _native.bn_node_linear_split
+
+    def spy(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+
+    monkeypatch.setattr(_native, "bn_node_linear_split", spy)
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("DMET_BN_NLS_FUSE", fuse)
+        for bn in [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm1d)]:
+            bn.reset_running_stats()
+        model.zero_grad(set_to_none=True)
+        n0 = len(calls)
+        w = model(*split_features(x), graph(), batch)
+        loss = loss_fn(w, x, y, batch)
+        loss.backward()
+        assert len(calls) - n0 == (2 if fuse == "1" else 0)      # both EdgeConv layers took their input that way
+        outs.append((w.detach().clone(), [p.grad.clone() for p in model.parameters()], [b.clone() for b in model.buffers()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)
+    model.eval()
+    ev = []
+    with torch.no_grad():
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("DMET_BN_NLS_FUSE", fuse)
+            ev.append(model(*split_features(x), graph(), batch).clone())
+    assert torch.equal(ev[0], ev[1])
