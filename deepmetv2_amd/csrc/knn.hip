@@ -1492,15 +1492,29 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter_kernel(c
 #define DMET_F2_DEFER 32
 #endif
 constexpr int kF2Defer = DMET_F2_DEFER;   // tiles that only feed tau in the main sweep
+// DMET_F2_LEAN (experiment builds, tools/knn_lean.sh): THREE wavefronts per SIMD -- 26 entry slots, no row staging area
+// (13 KB of LDS per wavefront, 12 wavefronts per CU), registers capped at 168 by the launch bounds
+#ifdef DMET_F2_LEAN
+constexpr int kF2Slots = 26;
+constexpr int kF2StageRows = 4;
+constexpr int kF2WavesPerSimd = 3;
+#else
 constexpr int kF2Slots = 30;        // entries per lane
+constexpr int kF2StageRows = kWave;
+constexpr int kF2WavesPerSimd = 2;
+#endif
 constexpr int kF2RowF = 16;         // features staged per re-rank half round
 constexpr unsigned kF2TileBits = 11u, kF2TileMask = (1u << kF2TileBits) - 1u;
 
 struct F2Wave {
     uint2 ent[kF2Slots][kWave];              // 15 360 B
-    float rows[kWave][kF2RowF + 4];          //  5 120 B: half rows of the re-rank (16-byte aligned, conflict-free b128)
+    float rows[kF2StageRows][kF2RowF + 4];   //  5 120 B: half rows of the re-rank (16-byte aligned, conflict-free b128)
 };
+#ifndef DMET_F2_LEAN
 static_assert(sizeof(F2Wave) == 20480, "two workgroups of four wavefronts fill the CU's 160 KB exactly");
+#else
+static_assert(sizeof(F2Wave) * 12 <= 163840, "three workgroups of four wavefronts per CU");
+#endif
 
 template <int M>
 struct F2Lane {
@@ -2107,11 +2121,13 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
 // items.  The wavefront number is wave-uniform, but only readfirstlane tells the compiler: without it the tile, the
 // event, the loop counters and every record address are computed per lane on the vector ALU.
 template <int KP, int NH = 1>
-__global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter12_kernel(const KnnFilterArgs a)
+__global__ __launch_bounds__(kWave * kWavesPerGroup, kF2WavesPerSimd) void knn_filter12_kernel(const KnnFilterArgs a)
 {
     union WaveLds {
         F2Wave f2;
+#ifndef DMET_F2_LEAN
         FilterQueue<filter_queue_len(filter_list_len(KP))> f1;
+#endif
     };
     __shared__ WaveLds sh_all[kWavesPerGroup];
     if constexpr (NH == 1) {
@@ -2135,15 +2151,19 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup, 2) void knn_filter12_kernel
     // neither the staging (features 0..15 of a row) nor the first form's queue (at most 19 968 bytes) ever touches;
     // cleared here, before any wavefront of the group can arrive
     static_assert(sizeof(WaveLds) == sizeof(F2Wave), "the union is sized by the second form");
+#ifndef DMET_F2_LEAN
     static_assert(sizeof(FilterQueue<filter_queue_len(filter_list_len(KP))>) <= sizeof(F2Wave) - 8, "ticket bytes are free");
+#endif
     static_assert(kWavesPerGroup / 2 <= 2, "two ticket words");
-    int *tickets = reinterpret_cast<int *>(&sh_all[0].f2.rows[kWave - 1][kF2RowF + 2]);
+    int *tickets = reinterpret_cast<int *>(&sh_all[0].f2.rows[kF2StageRows - 1][kF2RowF + 2]);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (threadIdx.x < kWavesPerGroup / 2) tickets[threadIdx.x] = 0;
     __syncthreads();
     const int group = filter_group(a);
     filter2_wave<KP, NH>(a, sh_all[wv].f2, tickets, group, wv, lane);   // returns at once unless the item's event is a second-form event
+#ifndef DMET_F2_LEAN
     if constexpr (NH == 1) filter1_wave<KP>(a, sh_all[wv].f1, group, wv, lane);   // likewise (32 features only)
+#endif
 }
 
 // Exact R1 chain for the kept candidates of one query, top-k by (d, j), certification.  M lanes per query (one kept
@@ -2390,7 +2410,7 @@ template <int KF, int NH = 1>
 int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, const KnnPlanOut &px, const KnnPlanOut &pf,
                   hipStream_t st)
 {
-    const int slots = simds * 2;   // two filter wavefronts per SIMD
+    const int slots = simds * kF2WavesPerSimd;   // filter wavefronts per SIMD
     bool affine = false;
     if constexpr (NH == 1) affine = g_affine.raw != nullptr && !g_affine.done;
     if (affine) {
@@ -2445,7 +2465,7 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     if constexpr ((DP == 32 || DP == 64) && KP <= 32)
         use_filter = D == DP && k <= 20 && aligned16(x) && filter_mode() != 0 && (DP == 32 || filter_form2());
     constexpr int NH = DP == 64 ? 2 : 1;   // 64 features (the DRN's hidden width): second filter form only
-    const int slots = simds * 2;   // two filter wavefronts per SIMD
+    const int slots = simds * kF2WavesPerSimd;   // filter wavefronts per SIMD
     const KnnPlanOut px{QT, simds, kMaxSplit, w.order, w.pos_of, w.tile_ptr, w.plan};
     const KnnPlanOut pf{kFQ, slots, kFilterMaxSplit, w.forder, w.fpos_of, w.ftile_ptr, w.fplan};
     if (!use_filter) {   // the filter path computes both plans inside its prep launch
