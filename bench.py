@@ -83,6 +83,23 @@ def parse_args():
     return ap.parse_args()
 
 
+class _StdoutToStderr:
+    """RCCL prints a five-line version banner with printf on the first communicator of a process.  The contract is ONE JSON
+    line on stdout: while the communicator is created, file descriptor 1 points at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def usable_cores() -> int:
     """Host cores this process may really use: min(affinity mask, cgroup cpu.max quota, cpu_count)."""
     n = os.cpu_count() or 1
@@ -348,10 +365,12 @@ def main():
     use_group = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
     if use_group:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(args.backend)
+        with _StdoutToStderr():
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(args.backend)
+            dist.barrier()          # the communicator exists (and has said what it has to say) before anything is timed
 
     import deepmetv2_amd as dm
     from deepmetv2_amd import _native, synth
