@@ -153,3 +153,31 @@ def test_accelerate_one_line_matches_oracle(dev, fuse):
     # running statistics moved exactly once, in the shared buffers
     torch.testing.assert_close(stock.graphnet.bn_all.running_mean.cpu(), ref.graphnet.bn_all.running_mean, rtol=1e-4, atol=1e-5)
     assert int(stock.graphnet.bn_all.num_batches_tracked) == 1
+
+
+def test_knn_graph_short_row_surfaces_as_deferred_error(dev):
+    """The sync-free [2,E] view rests on an expectation (every event >= k nodes => every row full).  A query with a NaN
+    coordinate finds nobody: its row is short, the edge list carries -1 for it (defined, never uninitialised memory), the
+    graph operators still treat the row as empty -- and the violated expectation is reported by the deferred device-side
+    check, at the latest when the loop synchronises (`raise_deferred_errors`, cf. train.py:54 `loss.item()`)."""
+    import deepmetv2_amd as dm
+    sizes = [200, 64]
+    g = torch.Generator().manual_seed(2)
+    emb = torch.randn(sum(sizes), 32, generator=g)
+    emb[17, 3] = float("nan")
+    emb = emb.to(dev)
+    counts = torch.tensor(sizes)
+    batch = torch.repeat_interleave(torch.arange(2), counts).to(dev)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)]).to(dev)
+    dm.register_batch(batch, ptr, 2, max_nodes=200, min_nodes=64)
+    dm.raise_deferred_errors()                      # nothing pending from earlier tests
+    ei = dm.knn_graph(emb, k=16, batch=batch, loop=True)
+    assert ei.shape == (2, sum(sizes) * 16)
+    row = ei[:, 17 * 16:18 * 16].cpu()
+    assert bool((row[0] == -1).all()) and bool((row[1] == 17).all())
+    conv = dm.EdgeConv(nn=torch.nn.Sequential(torch.nn.Linear(64, 32))).to(dev)
+    out = conv(torch.nan_to_num(emb), ei)           # the table behind ei: node 17 has no neighbour -> 0 (R3)
+    assert bool((out[17] == 0).all())
+    with pytest.raises(RuntimeError, match="came out short"):
+        dm.raise_deferred_errors()
+    dm.raise_deferred_errors()                      # reported once

@@ -1,6 +1,6 @@
 """Where does the launch thread spend its time?  cProfile over N eager training steps of the benchmark (the GPU is not
 waited for inside the profiled region), top functions by own time and by cumulative time.
-Usage: python tools/host_profile.py [steps] [fused|stock-knn-graph|stock-dynamic]"""
+Usage: python tools/host_profile.py [steps] [fused|stock-knn-graph|stock-dynamic][+layers|+fuse]"""
 import cProfile
 import io
 import os
@@ -31,7 +31,14 @@ if which == "fused":
     def step():
         return train_step(model, flat, sync, opt, x, y, batch, ptr)
 else:
+    acc = None
+    if "+" in which:
+        which, acc = which.split("+")
     model = stock_model.StockNet(dm, 8, 3, variant=which[len("stock-"):].replace("-", "_"), k=16).to(dev).train()
+    if acc == "layers":
+        model = dm.accelerate(model, fuse=False)
+    elif acc == "fuse":
+        model = dm.accelerate(model, graph="dynamic", k=16)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
 
     def step():
