@@ -1566,21 +1566,10 @@ struct F2Ops {
 template <int NH = 1>
 __device__ __forceinline__ f32x16 f2_block(const f16x8 (&av)[2 * NH], const f16x8 (&bv)[2 * NH], const f32x16 &cinit)
 {
-#ifdef DMET_F2_ASM_MFMA
-    // experiment: the first MFMA of the block written with D distinct from C, so that the shared accumulator seed (the
-    // candidates' norms) is read in place by both blocks of a tile -- hipcc otherwise copies the sixteen seed registers for
-    // one of the two blocks (8 v_mov_b64 among ~135 vector instructions per tile visit)
-    f32x16 acc;
-    asm("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(av[0]), "v"(bv[0]), "v"(cinit));
-#pragma unroll
-    for (int m = 1; m < 2 * NH; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[m], bv[m], acc, 0, 0, 0);
-    return acc;
-#else
     f32x16 acc = cinit;
 #pragma unroll
     for (int m = 0; m < 2 * NH; ++m) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[m], bv[m], acc, 0, 0, 0);
     return acc;
-#endif
 }
 
 // one fp16 candidate tile record: the lane's 2 NH A operands and the squared norms of the 16 candidate rows it receives
