@@ -97,6 +97,7 @@ SIGNATURES = {
     "dmet_bn_bwd_stats_f32": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_encode_bn_bwd_f32": (_i, [_vp, _i64, _vp, _i64] + [_vp] * 9 + [_vp, _vp] + [_vp] * 5 + [_vp] * 9 + [_vp, _vp, _sz, _vp]),
     "dmet_bn_eval_stats_f32": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp]),
+    "dmet_bn_apply_f32": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dmet_bn_stats_f32": (_i, [_vp, _i64, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_bn_bwd_f32": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_encode_fwd_f32": (_i, [_vp, _i64, _vp, _i64] + [_vp] * 9 + [_vp, _vp]),

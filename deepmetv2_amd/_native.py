@@ -971,6 +971,35 @@ def bn_stats(x: torch.Tensor, eps: float, momentum: float, running_mean: Optiona
     return stats[0], stats[1]
 
 
+def _aligned16(t: torch.Tensor) -> torch.Tensor:
+    """`t` itself when its storage starts on a 16-byte boundary, else a fresh (aligned) copy."""
+    return t if t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.contiguous_format)
+
+
+def bn_apply(x: torch.Tensor, residual: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+             mean: torch.Tensor, invstd: torch.Tensor) -> torch.Tensor:
+    """y = (x - mean) * (gamma * invstd) + beta (+ residual): the transform of bn_fwd with the statistics given
+    (bn_stats / bn_eval_stats) -- same kernel, same bits (dmet_bn_apply_f32).  Small vectors that do not start on a
+    16-byte boundary (views into somebody else's flat buffer) are copied first."""
+    dev = _require_device(x, gamma, beta, mean, invstd)
+    L = _lib.load()
+    x = _aligned16(_f32c(x, "x"))
+    N, H = x.shape
+    if residual is not None:
+        residual = _aligned16(_f32c(residual, "residual"))
+        if residual.shape != x.shape:
+            raise ValueError("bn_apply: residual must have the shape of x")
+    vec = [_aligned16(_f32c(t, n)) for t, n in ((gamma, "gamma"), (beta, "beta"), (mean, "mean"), (invstd, "invstd"))]
+    if any(v.numel() != H for v in vec):
+        raise ValueError("bn_apply: gamma / beta / mean / invstd must have H elements")
+    y = torch.empty_like(x)
+    with _on(dev):
+        _lib.check(L.dmet_bn_apply_f32(x.data_ptr(), residual.data_ptr() if residual is not None else None, N, H,
+                                       vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(),
+                                       y.data_ptr(), _stream(dev)), "dmet_bn_apply_f32")
+    return y
+
+
 def bn_eval_stats(running_mean: torch.Tensor, running_var: torch.Tensor, eps: float):
     """(mean, invstd) of an eval-mode BatchNorm1d: running_mean and 1 / sqrt(running_var + eps), as bn_fwd(training=False)
     forms them."""

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/dmet.h"
@@ -31,6 +32,14 @@ int hip_fail(hipError_t e, const char *what);
     } while (0)
 
 static inline hipStream_t as_stream(dmet_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Experiment / A-B switches are read on EVERY call (never cached in a static): entry points that share a switch then
+// always agree, also when a test changes the variable inside one process.
+static inline bool env_is(const char *name, const char *value)
+{
+    const char *e = getenv(name);
+    return e && strcmp(e, value) == 0;
+}
 
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -715,16 +715,12 @@ extern "C" int dmet_encode_fwd_f32(const float *x, int64_t x_stride, const int64
     DMET_REQUIRE(aligned16(h), "dmet_encode_fwd_f32: h must be 16-B aligned");
     const int64_t blocks = (N + 255) / 256;
     DMET_REQUIRE(blocks < (1ll << 31), "dmet_encode_fwd_f32: too many nodes");
-    static int form = -1;    // DMET_ENCODER_FWD=valu: the scalar-weight kernel (experiments, A/B)
-    if (form < 0) {
-        const char *e = getenv("DMET_ENCODER_FWD");
-        form = (e && strcmp(e, "valu") == 0) ? 0 : 1;
-    }
+    const int form = env_is("DMET_ENCODER_FWD", "valu") ? 0 : 1;    // valu: the scalar-weight kernel (experiments, A/B)
     if (form == 1 && aligned16(Echg) && aligned16(Epdg) && aligned16(Epv)) {
         const int64_t tiles = (N + 31) / 32;
         int64_t grid = (tiles + 3) / 4;
-        static int gmax = 0;
-        if (gmax == 0) { const char *e = getenv("DMET_ENC_GRID"); gmax = e ? atoi(e) : 512; if (gmax < 1) gmax = 512; }
+        int gmax = 512;
+        if (const char *e = getenv("DMET_ENC_GRID")) { gmax = atoi(e); if (gmax < 1) gmax = 512; }
         if (grid > gmax) grid = gmax;       // 2048 wavefronts (three per SIMD fit), 4-5 tiles each at 288 000 nodes: the weights are loaded once per wavefront
         hipLaunchKernelGGL(encode_fwd_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, x_stride, xcat, N,
                            ENC_ARGS, h);
@@ -761,11 +757,7 @@ extern "C" int dmet_encode_bwd_f32(const float *x, int64_t x_stride, const int64
     const int64_t npw = enc_nodes_per_wave(N, &nw);
     float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u);
     hipStream_t st = as_stream(stream);
-    static int form = -1;    // DMET_ENCODER_BWD=valu: the scalar-weight kernel (experiments, A/B)
-    if (form < 0) {
-        const char *e = getenv("DMET_ENCODER_BWD");
-        form = (e && strcmp(e, "valu") == 0) ? 0 : 1;
-    }
+    const int form = env_is("DMET_ENCODER_BWD", "valu") ? 0 : 1;    // valu: the scalar-weight kernel (experiments, A/B)
     int64_t nparts = nw / kEncBwdWaves;    // workgroup partials the finalize kernel sums
     if (form == 1 && aligned16(Echg) && aligned16(Epdg) && aligned16(Epv) && aligned16(g_h) && aligned16(h)) {
         // 2048 wavefronts = two per SIMD everywhere, 32-node tiles dealt round-robin; never more workgroups than the
@@ -805,8 +797,7 @@ extern "C" int dmet_encode_bn_bwd_f32(const float *x, int64_t x_stride, const in
     DMET_REQUIRE(fused, "dmet_encode_bn_bwd_f32: fused is null");
     *fused = 0;
     DMET_REQUIRE(bn_gamma && bn_mean && bn_invstd && bn_mean_g && bn_mean_gx, "dmet_encode_bn_bwd_f32: null pointer");
-    const char *e = getenv("DMET_ENCODER_BWD");
-    const bool ok = !(e && strcmp(e, "valu") == 0) && N > 0 && aligned16(Echg) && aligned16(Epdg) && aligned16(Epv) && aligned16(g_y) &&
+    const bool ok = !env_is("DMET_ENCODER_BWD", "valu") && N > 0 && aligned16(Echg) && aligned16(Epdg) && aligned16(Epv) && aligned16(g_y) &&
                     aligned16(h) && aligned16(bn_gamma) && aligned16(bn_mean) && aligned16(bn_invstd) && aligned16(bn_mean_g) &&
                     aligned16(bn_mean_gx);
     if (!ok) return 0;     // nothing launched: the caller applies the BatchNorm's backward transform and calls dmet_encode_bwd_f32

@@ -463,11 +463,7 @@ extern "C" int dmet_head_fwd_f32(const float *emb, int64_t N, const float *W1, c
     if (N == 0) return 0;
     DMET_REQUIRE(emb && W1 && b1 && W2 && b2 && out, "dmet_head_fwd_f32: null pointer");
     DMET_REQUIRE(aligned16(emb), "dmet_head_fwd_f32: emb must be 16-byte aligned");
-    static int form = -1;    // DMET_HEAD_FWD=valu: the scalar-weight kernel (experiments, A/B)
-    if (form < 0) {
-        const char *e = getenv("DMET_HEAD_FWD");
-        form = (e && strcmp(e, "valu") == 0) ? 0 : 1;
-    }
+    const int form = env_is("DMET_HEAD_FWD", "valu") ? 0 : 1;    // valu: the scalar-weight kernel (experiments, A/B)
     if (form == 1 && aligned16(W1) && aligned16(b1) && aligned16(W2))
         hipLaunchKernelGGL(head_fwd_mfma_kernel<false>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), emb, N,
                            W1, b1, W2, b2, out, HeadAffine{});
@@ -488,8 +484,7 @@ extern "C" int dmet_bn_head_fwd_f32(const float *raw, const float *residual, con
     DMET_REQUIRE(N >= 0, "dmet_bn_head_fwd_f32: N=%lld", (long long)N);
     if (N == 0) { *fused = 1; return 0; }
     DMET_REQUIRE(raw && gamma && beta && mean && invstd && emb && W1 && b1 && W2 && b2 && out, "dmet_bn_head_fwd_f32: null pointer");
-    const char *e = getenv("DMET_HEAD_FWD");
-    const bool ok = !(e && strcmp(e, "valu") == 0) && aligned16(raw) && aligned16(emb) && aligned16(gamma) && aligned16(beta) &&
+    const bool ok = !env_is("DMET_HEAD_FWD", "valu") && aligned16(raw) && aligned16(emb) && aligned16(gamma) && aligned16(beta) &&
                     aligned16(mean) && aligned16(invstd) && (!residual || aligned16(residual)) && aligned16(W1) &&
                     aligned16(b1) && aligned16(W2);
     if (!ok) return 0;    // nothing launched: the caller runs the transform and dmet_head_fwd_f32
@@ -521,11 +516,7 @@ extern "C" int dmet_head_bwd_f32(const float *emb, int64_t N, const float *W1, c
     const int64_t npw = head_nodes_per_wave(N, &nw);
     float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u);
     hipStream_t st = as_stream(stream);
-    static int form = -1;    // DMET_HEAD_BWD=valu: the scalar-weight kernel (experiments, A/B)
-    if (form < 0) {
-        const char *e = getenv("DMET_HEAD_BWD");
-        form = (e && strcmp(e, "valu") == 0) ? 0 : 1;
-    }
+    const int form = env_is("DMET_HEAD_BWD", "valu") ? 0 : 1;    // valu: the scalar-weight kernel (experiments, A/B)
     if (form == 1)
         hipLaunchKernelGGL(head_bwd_mfma_kernel, dim3((unsigned)(nw / kHeadWaves)), dim3(64 * kHeadWaves), 0, st, emb, N, W1, b1,
                            W2, out, g_out, npw, g_emb, partial);

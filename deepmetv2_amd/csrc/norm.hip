@@ -343,6 +343,26 @@ extern "C" int dmet_bn_bwd_stats_f32(const float *x, const float *g_y, int64_t N
     return 0;
 }
 
+extern "C" int dmet_bn_apply_f32(const float *x, const float *residual, int64_t N, int H, const float *gamma,
+                                 const float *beta, const float *mean, const float *invstd, float *y,
+                                 dmet_stream_t stream)
+{
+    DMET_REQUIRE(bn_shape_ok(H), "dmet_bn_apply_f32: H=%d must be a multiple of 4 in [4,64]", H);
+    DMET_REQUIRE(N >= 0, "dmet_bn_apply_f32: N=%lld", (long long)N);
+    if (N == 0) return 0;
+    DMET_REQUIRE(x && gamma && beta && mean && invstd && y, "dmet_bn_apply_f32: null pointer");
+    DMET_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta) && aligned16(mean) &&
+                     aligned16(invstd) && (!residual || aligned16(residual)),
+                 "dmet_bn_apply_f32: pointers must be 16-byte aligned");
+    const int64_t total = N * (H / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, residual, N, H, gamma,
+                       beta, mean, invstd, y);
+    DMET_LAUNCH_CHECK("bn_apply_kernel");
+    return 0;
+}
+
 extern "C" int dmet_bn_eval_stats_f32(const float *running_mean, const float *running_var, int H, float eps,
                                       float *save_mean, float *save_invstd, dmet_stream_t stream)
 {

@@ -99,10 +99,8 @@ class _BatchNorm(torch.autograd.Function):
             else:
                 mean, invstd = _native.bn_eval_stats(running_mean, running_var, eps)
             y = next_build(x, residual, weight.detach(), bias.detach(), mean, invstd)
-            if y is None:   # that build takes another path after all: plain transform (the statistics are done)
-                y = (x - mean) * (weight.detach() * invstd) + bias.detach()
-                if residual is not None:
-                    y = y + residual
+            if y is None:   # that build takes another path after all: the transform alone (the statistics are done),
+                y = _native.bn_apply(x, residual, weight.detach(), bias.detach(), mean, invstd)   # bn_fwd's kernel and bits
         if y is None:
             y, mean, invstd = _native.bn_fwd(x, residual, weight.detach(), bias.detach(), eps, momentum,
                                              running_mean, running_var, training, num_batches_tracked=tracked)
@@ -142,7 +140,7 @@ class _EncodeBN(torch.autograd.Function):
             mean, invstd = _native.bn_stats(h, eps, momentum, running_mean, running_var, tracked)
             y = next_build(h, None, weight.detach(), bias.detach(), mean, invstd)
             if y is None:
-                y = (h - mean) * (weight.detach() * invstd) + bias.detach()
+                y = _native.bn_apply(h, None, weight.detach(), bias.detach(), mean, invstd)
         if y is None:
             y, mean, invstd = _native.bn_fwd(h, None, weight.detach(), bias.detach(), eps, momentum, running_mean,
                                              running_var, True, num_batches_tracked=tracked)

@@ -47,20 +47,27 @@ class FlatModule:
         if not params:
             raise ValueError("module has no trainable parameters")
         dev, dt = params[0].device, params[0].dtype
-        total = sum(p.numel() for p in params)
-        self.flat_param = torch.nn.Parameter(torch.empty(total, device=dev, dtype=dt))
+        # every parameter starts on a 16-byte boundary (4 floats): the fused kernels take 16-byte loads of weights and
+        # BatchNorm vectors and fall back to slower forms otherwise.  The padding elements are zero, get zero gradients
+        # and stay zero under AdamW; the reference model's sizes are all multiples of 4 except the last bias, so its
+        # flat buffer has no padding at all (6 641 elements)
+        offsets, total = [], 0
+        for p in params:
+            total = (total + 3) // 4 * 4
+            offsets.append(total)
+            total += p.numel()
+        self.flat_param = torch.nn.Parameter(torch.zeros(total, device=dev, dtype=dt))
         self.flat_param.grad = torch.zeros(total, device=dev, dtype=dt)
-        off = 0
         self.grad_views = []
         with torch.no_grad():
-            for p in params:
+            for p, off in zip(params, offsets):
                 n = p.numel()
                 self.flat_param.data[off:off + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_param.data[off:off + n].view_as(p)
                 self.grad_views.append(self.flat_param.grad[off:off + n].view_as(p))
                 p.grad = None
-                off += n
         self.params = params
+        self.offsets = offsets
         self.numel = total
 
     @property

@@ -442,6 +442,12 @@ int dmet_bn_bwd_stats_f32(const float *x, const float *g_y, int64_t N, int H, co
  * training == 0), for callers that apply the transform elsewhere (dmet_bn_knn_local_dense_f32, dmet_bn_head_fwd_f32). */
 int dmet_bn_eval_stats_f32(const float *running_mean, const float *running_var, int H, float eps, float *save_mean,
                            float *save_invstd, dmet_stream_t stream);
+/* The transform half of dmet_bn_fwd_f32 with the statistics given (dmet_bn_stats_f32 / dmet_bn_eval_stats_f32):
+ * y = (x - mean) * (gamma * invstd) + beta (+ residual when not NULL), the same kernel and therefore the same bits as
+ * dmet_bn_fwd_f32 -- for a caller whose fused consumer (dmet_bn_knn_local_dense_f32, dmet_bn_head_fwd_f32) declined
+ * after the statistics were computed (model/graph_met_network.py:58,66).  All pointers 16-byte aligned. */
+int dmet_bn_apply_f32(const float *x, const float *residual, int64_t N, int H, const float *gamma, const float *beta,
+                      const float *mean, const float *invstd, float *y, dmet_stream_t stream);
 /* The statistics half of dmet_bn_fwd_tracked_f32 in training mode (column sums + finalize: save_mean, save_invstd,
  * running statistics, num_batches_tracked), for a caller that applies the transform elsewhere
  * (dmet_bn_knn_local_dense_f32 fuses it into the next layer's graph build). */

@@ -847,6 +847,30 @@ def test_batch_norm_residual_fwd_bwd(dev, N, H, residual, training):
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
 
 
+@pytest.mark.parametrize("N,H,residual", [(5000, 32, True), (70001, 32, False), (3, 8, True), (1000, 64, False)])
+def test_batch_norm_apply_alone_has_the_bits_of_bn_fwd(dev, N, H, residual):
+    """dmet_bn_apply_f32 (the transform with the statistics given: what a caller runs when its fused consumer declined
+    after the statistics were computed) = dmet_bn_fwd_f32 bit for bit, training and eval statistics, also with the
+    small vectors sitting at odd offsets of a flat buffer."""
+    from deepmetv2_amd import _native
+    g = torch.Generator().manual_seed(7 * N + H)
+    x = (torch.randn(N, H, generator=g) * 0.7 + 3.0).to(dev)
+    r = torch.randn(N, H, generator=g).to(dev) if residual else None
+    flat = torch.randn(4 * H + 3, generator=g).to(dev)          # gamma / beta at 4-byte offsets 1 and H + 2
+    gamma, beta = flat[1:1 + H], flat[H + 2:2 * H + 2]
+    assert gamma.data_ptr() % 16 != 0
+    rm, rv = torch.randn(H, generator=g).to(dev), (torch.rand(H, generator=g) + 0.5).to(dev)
+    for training in (True, False):
+        y_ref, mean, invstd = _native.bn_fwd(x, r, gamma.clone(), beta.clone(), 1e-5, 0.1, rm.clone(), rv.clone(), training)
+        if training:
+            m2, i2 = _native.bn_stats(x, 1e-5, 0.1, rm.clone(), rv.clone())
+        else:
+            m2, i2 = _native.bn_eval_stats(rm, rv, 1e-5)
+        assert torch.equal(m2, mean) and torch.equal(i2, invstd)
+        y = _native.bn_apply(x, r, gamma, beta, m2, i2)
+        assert torch.equal(y, y_ref)
+
+
 @pytest.mark.parametrize("N", [1, 64, 65, 5000, 70001])
 def test_fused_head_fwd_bwd(dev, N):
     """N3: csrc/head.hip vs sigmoid(Linear(ELU(Linear(emb)))) in float64 on the CPU."""

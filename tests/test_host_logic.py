@@ -174,3 +174,37 @@ def test_nn_shim_and_accelerate_structure(monkeypatch):
     assert dm.accelerate(other) is other and type(other[0]) is dnn.Linear
     with pytest.raises(ValueError):
         dm.accelerate(stock_model.StockNet(dm, 8, 3), graph="sometimes")
+
+
+def test_flat_module_aligns_every_parameter_to_16_bytes():
+    """Odd-sized parameters in the middle of a model must not push the ones behind them off a 16-byte boundary (the
+    fused kernels take 16-byte loads of weights; an unaligned view silently selects a slower, differently rounded form)."""
+    import torch
+    from deepmetv2_amd.parallel import FlatModule
+
+    class Odd(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Parameter(torch.arange(3, dtype=torch.float32))          # 3 floats: 12 bytes
+            self.b = torch.nn.Parameter(torch.arange(10, dtype=torch.float32).view(2, 5))
+            self.c = torch.nn.Parameter(torch.ones(1))
+            self.d = torch.nn.Parameter(torch.full((4,), 7.0))
+
+    m = Odd()
+    flat = FlatModule(m)
+    assert flat.offsets == [0, 4, 16, 20] and flat.numel == 24
+    for p in m.parameters():
+        assert p.data_ptr() % 16 == 0
+    assert torch.equal(m.b.detach(), torch.arange(10, dtype=torch.float32).view(2, 5))
+    pad = torch.ones(24, dtype=torch.bool)
+    for off, p in zip(flat.offsets, m.parameters()):
+        pad[off:off + p.numel()] = False
+    assert torch.count_nonzero(flat.flat_param.detach()[pad]) == 0
+    # gradients land in the matching slices; the padding stays zero
+    (m.a.sum() * 2 + (m.b * 3).sum() + m.c.sum() + m.d.sum()).backward()
+    flat.gather_grads()
+    assert torch.equal(flat.flat_grad[0:3], torch.full((3,), 2.0)) and torch.equal(flat.flat_grad[4:14], torch.full((10,), 3.0))
+    assert torch.count_nonzero(flat.flat_grad[pad]) == 0
+    # the reference model: no padding at all
+    from deepmetv2_amd.model import Net
+    assert FlatModule(Net(8, 3, graph="dynamic", k=16)).numel == 6641
