@@ -197,11 +197,20 @@ class GraphedTrainStep:
                 sync.average_gradients()
                 optimizer.step()
         torch.cuda.current_stream().wait_stream(side)
+        # With a process group alive, its watchdog THREAD polls the events of outstanding collectives (here: the warm-up's
+        # all-reduces).  Under the default capture mode ("global") an event query from any thread while this one captures
+        # is an error (hipErrorStreamCaptureUnsupported) that the watchdog turns into process termination -- seen once
+        # in ~25 runs of tests/test_gpu_rccl.py.  So: nothing of ours outstanding when the capture starts, and a capture
+        # mode that only polices the capturing thread.
+        mode = "global"
+        if sync.active:
+            torch.cuda.synchronize()
+            mode = "thread_local"
         self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a):
+        with torch.cuda.graph(self.graph_a, capture_error_mode=mode):
             self.loss = fwd_bwd()
         self.graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_b):
+        with torch.cuda.graph(self.graph_b, capture_error_mode=mode):
             optimizer.step()
 
     def load(self, x, y) -> None:
