@@ -272,6 +272,83 @@ __global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const f
     const int tid = threadIdx.x;
     const bool loc16 = nbr16 != nullptr && n <= 65535;   // event-local uint16 table (half the row bytes) when given
 
+    // window: CH channels x JW nodes of accumulators
+    const int CH = (n <= kBwdCells / 4) ? 4 : (n <= kBwdCells / 2) ? 2 : 1;
+    // Events of 4 609 .. 9 216 nodes (the upper half of a ragged batch, BASELINE configs[4]): the window holds two of
+    // the slice's four channels, so the event takes two accumulation passes -- but only ONE look-up pass: the first
+    // pass resolves the winners of all four channels (slot -> id, the dependent loads this kernel waits on), scatters
+    // channels 0..1 and keeps the ids of channels 2..3 (and the gradients) in registers for the second, which then is
+    // LDS atomics only.  (Before: both passes walked arg / ids / g_out again and a large event cost twice its nodes.)
+    constexpr int kBwdBig = 9;                        // rows per thread: 9 x 1024 = 9 216 = kBwdCells / 2
+    if (CH == 2) {
+        float4 g9[kBwdBig];
+        unsigned jk[kBwdBig];
+        float mb = 0.0f;
+#pragma unroll
+        for (int u = 0; u < kBwdBig; ++u) {
+            const int i = tid + u * kBwdThreads;
+            g9[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n) g9[u] = reinterpret_cast<const float4 *>(g_out + (lo + i) * kH + c0)[0];
+            mb = fmaxf(mb, fmaxf(fmaxf(fabsf(g9[u].x), fabsf(g9[u].y)), fmaxf(fabsf(g9[u].z), fabsf(g9[u].w))));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mb = fmaxf(mb, __shfl_xor(mb, off, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = mb;
+        __syncthreads();
+        mb = red[0];
+#pragma unroll
+        for (int w = 1; w < kBwdThreads / kWave; ++w) mb = fmaxf(mb, red[w]);
+        int exb = 0;
+        (void)frexpf(mb, &exb);
+        exb = max(exb, -96);
+        const float scale_b = ldexpf(1.0f, 30 - exb), inv_b = ldexpf(1.0f, exb - 30);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();
+            for (int t = tid; t < n * 2; t += kBwdThreads) cells[t] = 0ull;
+            __syncthreads();
+            if (mb > 0.0f) {
+#pragma unroll
+                for (int u = 0; u < kBwdBig; ++u) {
+                    const int i = tid + u * kBwdThreads;
+                    if (i < n) {
+                        const int64_t gi = lo + i;
+                        unsigned ja = 0xFFFFu, jb = 0xFFFFu;       // winners of this pass's two channels (0xFFFF: none)
+                        if (pass == 0) {
+                            unsigned jj[4];
+                            if (J16) {
+                                const ushort4 a4 = reinterpret_cast<const ushort4 *>(arg)[(gi * kH + c0) >> 2];
+                                jj[0] = a4.x; jj[1] = a4.y; jj[2] = a4.z; jj[3] = a4.w;
+                            } else {
+                                const uchar4 a4 = reinterpret_cast<const uchar4 *>(arg + gi * kH + c0)[0];
+                                const unsigned as[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const unsigned sl = as[q] != 255u ? as[q] : 0u;       // clamped: the load is always issued
+                                    const unsigned j = loc16 ? (unsigned)nbr16[gi * k + sl] : (unsigned)(nbr[gi * k + sl] - (int)lo);
+                                    jj[q] = as[q] != 255u ? j : 0xFFFFu;
+                                }
+                            }
+                            ja = jj[0]; jb = jj[1];
+                            jk[u] = (jj[2] & 0xFFFFu) | (jj[3] << 16);
+                        } else {
+                            ja = jk[u] & 0xFFFFu; jb = jk[u] >> 16;
+                        }
+                        const float ga = pass == 0 ? g9[u].x : g9[u].z, gb2 = pass == 0 ? g9[u].y : g9[u].w;
+                        if (ja < (unsigned)n) atomicAdd(&cells[ja * 2], (unsigned long long)(long long)__float2int_rn(ga * scale_b));
+                        if (jb < (unsigned)n) atomicAdd(&cells[jb * 2 + 1], (unsigned long long)(long long)__float2int_rn(gb2 * scale_b));
+                    }
+                }
+            }
+            __syncthreads();
+            for (int j = tid; j < n; j += kBwdThreads) {
+                const float2 o = make_float2((float)(long long)cells[2 * j] * inv_b, (float)(long long)cells[2 * j + 1] * inv_b);
+                *reinterpret_cast<float2 *>(gQ + (lo + j) * kH + c0 + 2 * pass) = o;
+            }
+        }
+        return;
+    }
+
     // scale: 2^(30 - e) with 2^e > max |g| over the slice (exactly representable, so the final rescale is exact)
     // the slice of g_out is needed twice (its maximum, then the terms): events of up to kBwdKeep * 1024 nodes keep it
     // in registers in between instead of reading the 16-byte pieces of the rows a second time
@@ -305,8 +382,6 @@ __global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const f
     ex = max(ex, -96);                          // gradients below 2^-96 everywhere: keep the scale finite
     const float scale = ldexpf(1.0f, 30 - ex), inv_scale = ldexpf(1.0f, ex - 30);
 
-    // window: CH channels x JW nodes of accumulators
-    const int CH = (n <= kBwdCells / 4) ? 4 : (n <= kBwdCells / 2) ? 2 : 1;
     const int JW = kBwdCells / CH;
     for (int cb = 0; cb < 4; cb += CH) {
         for (int j0 = 0; j0 < n; j0 += JW) {

@@ -606,6 +606,40 @@ def test_gather_max_bwd_lds_matches_reverse_index_route(dev, sizes):
     assert bool(((got - ref).abs() <= scale + 1e-5 * ref.abs()).all())
 
 
+@pytest.mark.parametrize("sizes", [[4609, 20], [6000, 9216, 300], [9217, 4608]])
+def test_gather_max_bwd_winner_id_form_at_large_events(dev, sizes):
+    """K5, winner-id form (dmet_gather_max_bwd_j16_f32) around the window boundaries of the LDS scatter: events of
+    4 609 .. 9 216 nodes take the two-pass / one-look-up path, larger ones the one-channel windows.  Against the slot
+    form on the same winners (integer sums: bit for bit) and against a float64 index_add (1e-6 of max|g| x in-degree)."""
+    from deepmetv2_amd import _native
+    g = torch.Generator().manual_seed(sum(sizes))
+    N, k, H = sum(sizes), 16, 32
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.tensor(sizes).cumsum(0)])
+    lo = torch.repeat_interleave(ptr[:-1], torch.tensor(sizes)).view(-1, 1)
+    cnt = torch.repeat_interleave(torch.tensor(sizes), torch.tensor(sizes)).view(-1, 1)
+    nbr = (lo + (torch.rand(N, k, generator=g) * cnt).long().clamp_(max=int(max(sizes)) - 1)).to(torch.int32)
+    nbr = torch.minimum(nbr, (lo + cnt - 1).to(torch.int32))
+    arg = torch.randint(0, k, (N, H), generator=g).to(torch.uint8)
+    arg[::5, 1] = 255
+    arg[3::11, 30] = 255
+    g_out = torch.randn(N, H, generator=g) * torch.logspace(-2, 2, H)
+    win = torch.gather(nbr.long(), 1, arg.long().clamp(max=k - 1)) - lo           # event-local winner ids
+    argj = torch.where(arg == 255, torch.full_like(win, 0xFFFF), win)
+    argj16 = torch.where(argj >= 0x8000, argj - 0x10000, argj).to(torch.int16)
+    pd, gd = ptr.to(dev), g_out.to(dev)
+    got = _native.gather_max_bwd_j16(gd, argj16.to(dev), pd)
+    assert torch.equal(got, _native.gather_max_bwd_j16(gd, argj16.to(dev), pd))
+    slot_form = _native.gather_max_bwd_lds(gd, arg.to(dev), nbr.to(dev), pd)
+    assert torch.equal(got, slot_form)
+    ref = torch.zeros(N, H, dtype=torch.float64)
+    tgt = (win + lo).clamp(0, N - 1)
+    gm = torch.where(arg == 255, torch.zeros(()), g_out).double()
+    ref.scatter_add_(0, tgt, gm)
+    indeg = torch.zeros(N, H).scatter_add_(0, tgt, (arg != 255).float()).amax()
+    tol = g_out.abs().amax(0).double() * float(indeg) * 1e-6 + 1e-12
+    assert bool(((got.cpu().double() - ref).abs() <= tol + 1e-6 * ref.abs()).all())
+
+
 @pytest.mark.parametrize("k", [8, 16, 32])
 def test_gather_max_local_ids_kernel_matches(dev, k):
     """K3: the LDS gather kernel fed with the uint16 event-local table must return the bits of the int32 form (and
