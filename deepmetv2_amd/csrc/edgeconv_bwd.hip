@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const f
                                 for (int q = 0; q < 4; ++q) {
                                     const unsigned sl = as[q] != 255u ? as[q] : 0u;       // clamped: the load is always issued
                                     const unsigned j = loc16 ? (unsigned)nbr16[gi * k + sl] : (unsigned)(nbr[gi * k + sl] - (int)lo);
-                                    jj[q] = as[q] != 255u ? j : 0xFFFFu;
+                                    jj[q] = (as[q] != 255u && j < (unsigned)n) ? j : 0xFFFFu;      // (a -1 slot would wrap to >= n)
                                 }
                             }
                             ja = jj[0]; jb = jj[1];
