@@ -156,7 +156,19 @@ __device__ unsigned long long g_knn_stamps[1 << 16][4];
 #endif
 
 // events the second matrix-core filter form sweeps (filter2_wave); the plan counts the others
-constexpr int kF2MinNodes = 2048;   // smaller events: first form (tau of the second form needs M tiles to exist at all)
+// Smaller events take the first form: the threshold of the second form is the M-th smallest of the event's tile minima (M = 22
+// tiles = 704 nodes at least), and below ~800 nodes the first form is the faster one (tools/knn_small_events.py: 64 events
+// of 704 nodes 155 us against 241, of 800 nodes 168 against 133, of 1000 nodes 188 against 109, of 2000 nodes 265 against 140).
+// Until round 3 the boundary stood at 2048 -- twice the build time for events of 1000..2047 nodes.
+#ifndef DMET_F2_MIN_NODES
+#define DMET_F2_MIN_NODES 800
+#endif
+constexpr int kF2MinNodes = DMET_F2_MIN_NODES;
+constexpr int kFilterMaxSplit = 2;  // tail balancing of the filter: at most 2 candidate sub-sweeps (the re-rank assumes 2).
+#ifndef DMET_F2_SPLIT_MIN_NODES
+#define DMET_F2_SPLIT_MIN_NODES 2560
+#endif
+constexpr int kF2SplitMinNodes = DMET_F2_SPLIT_MIN_NODES;   // smaller second-form events are never cut into candidate sub-sweeps (see filter2_wave)
 constexpr int kF2MaxNodes = 65536;  // tile number must fit 11 bits
 
 // Device-side launch plan (no host synchronisation): tiles never straddle events, so tile -> event needs a prefix.
@@ -307,6 +319,31 @@ __device__ __forceinline__ void knn_plan_body(const int64_t *__restrict__ ptr, i
         const int b = order[p];
         tile_ptr[p] = run;
         run += (int)((ptr[b + 1] - ptr[b] + tile_queries - 1) / tile_queries);
+    }
+    // When does cutting the tail's sweeps in two pay for SECOND-form events?  Each half has its own threshold from half
+    // the tile minima (looser: more candidates to re-rank, a fixed cost per piece), so it pays only while the pieces
+    // find idle SIMDs -- few tail tiles -- and the halves still have a threshold to speak of -- large events
+    // (tools/knn_small_events.py, 2048 wavefront slots: 376 tiles of 3000-node events 106 us split / 154 whole, 568
+    // tiles of 4500-node events 132 / 188, but 512 tiles of 2048-node events 115 / 106, 752 tiles of 3000-node events
+    // 127 / 119, 1024 tiles of 2048-node events 140 / 118).  The tail holds the SMALLEST events (longest-first order),
+    // so its first tile's event bounds them all.  First-form tails (events below kF2MinNodes) and the exact kernel's
+    // plan keep the rule above.
+    if (o.max_split == kFilterMaxSplit) {
+        __syncthreads();
+        if (tid == 0 && plan->split > 1) {
+            const int first_tail = plan->n_full, rem = plan->total_tiles - plan->n_full;
+            int plo = 0, phi = B;
+            while (phi - plo > 1) {
+                const int mid = (plo + phi) >> 1;
+                if (tile_ptr[mid] <= first_tail) plo = mid; else phi = mid;
+            }
+            const int b = order[plo];
+            const int64_t nb = ptr[b + 1] - ptr[b];
+            if (nb >= kF2MinNodes && (nb < kF2SplitMinNodes || rem * 16 > simds * 5)) {
+                plan->n_full = plan->total_tiles;
+                plan->split = 1;
+            }
+        }
     }
 }
 
@@ -766,7 +803,6 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const KnnArgs a, int til
 //      tile kernel above otherwise.
 // Result: bit-identical output at a fraction of the VALU work.
 constexpr int kFQ = 64;             // queries per filter work item: two 32-column MFMA blocks
-constexpr int kFilterMaxSplit = 2;  // tail balancing of the filter: at most 2 candidate sub-sweeps (the re-rank assumes 2).
 // (4 sub-sweeps per tail tile were built and measured for the second form: every sub-sweep re-ranks its own ~27
 // candidates and the 4-way merge took 60 us instead of 17: filter 452 -> 509 us, build 0.55 -> 0.65 ms.  Not kept.)
 
@@ -1786,14 +1822,21 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
         return;
     }
     int clo = ev_lo, chi = ev_hi;
+    bool idle_piece = false;
     if (nsub > 1) {
-        const int chunk = (((chi - clo) + nsub - 1) / nsub + 31) & ~31;
-        clo = min(chi, clo + sub * chunk);
-        chi = min(chi, clo + chunk);
+        if (ev_hi - ev_lo < kF2SplitMinNodes) {
+            // a sub-sweep of fewer than ~2 M tiles has no threshold to speak of (it would hand most of its range to the
+            // exact re-rank): the first piece sweeps the whole event, the others bring an empty list to the merge
+            idle_piece = sub != 0;
+        } else {
+            const int chunk = (((chi - clo) + nsub - 1) / nsub + 31) & ~31;
+            clo = min(chi, clo + sub * chunk);
+            chi = min(chi, clo + chunk);
+        }
     }
     const int64_t rbase = (ptr[ev] >> 5) + ev;
     const int64_t rlast = rbase + (ev_hi - ev_lo - 1) / 32;
-    const int t_lo = (clo - ev_lo) / 32, t_hi = (chi - ev_lo + 31) / 32;
+    const int t_lo = (clo - ev_lo) / 32, t_hi = idle_piece ? t_lo : (chi - ev_lo + 31) / 32;
 
     const int myq = q_first + hh * 32 + col;
     const bool valid = myq < ev_hi;

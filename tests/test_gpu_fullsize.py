@@ -5,7 +5,7 @@
   weights, per-event MET, loss, gradients.  Reference call sites: model/graph_met_network.py:63, train.py:48-51.
 * configs[4]: DynamicEdgeConv forward / backward on a ragged batch with events of 5120..8000 nodes (too large for the
   LDS-resident gather: L2-form gather, multi-pass backward scatter) against `ref_ops.dynamic_edge_conv`.
-* kNN matrix-core filter (both forms: events below / above 2048 nodes) on inputs built to break it: non-finite rows,
+* kNN matrix-core filter (both forms: events below / above 800 nodes, csrc/knn.hip kF2MinNodes) on inputs built to break it: non-finite rows,
   coordinates whose distances exceed the 1e10 sentinel, per-feature heavy tails, a large common offset, mirrored pairs
   that tie to the last ulp.  The result must still be the C oracle's bits; where the certificate cannot hold, the
   exact fallback must have run (flagged_queries > 0).
@@ -15,6 +15,7 @@ import os
 import pytest
 import torch
 
+F2_MIN_NODES = 800     # csrc/knn.hip kF2MinNodes: smallest event the second filter form (fp16 tile records) takes
 pytestmark = pytest.mark.gpu
 
 
@@ -214,12 +215,13 @@ def _knn_vs_oracle(dev, x, sizes, k):
 
 
 @pytest.mark.parametrize("D", [32, 64, "32-first-form"])
-@pytest.mark.parametrize("sizes", [[2500, 900], [4500]])
+@pytest.mark.parametrize("sizes", [[2500, 700], [1300, 900, 600], [4500]])
 @pytest.mark.parametrize("case", ["nonfinite_rows", "beyond_sentinel", "feature_tails", "common_offset",
                                   "mirrored_ulp_ties", "tight_far_cluster"])
 def test_knn_filter_adversarial(dev, monkeypatch, case, sizes, D):
-    """Matrix-core filter + certificate on hostile inputs, events on both sides of the 2048-node switch between the
-    two filter forms, at the model's width (32) and the DRN's (64: second form only, exact kernel for the rest).  Bits
+    """Matrix-core filter + certificate on hostile inputs, events on both sides of the 800-node switch between the
+    two filter forms (kF2MinNodes; 2048 until round 3), at the model's width (32) and the DRN's (64: second form only,
+    exact kernel for the rest).  Bits
     must equal the C oracle's (dmet_oracle.c:62: a candidate at d >= 1e10 or NaN is never a neighbour, short results
     are -1 / 1e10)."""
     if D == "32-first-form":
@@ -269,8 +271,8 @@ def test_knn_filter_adversarial(dev, monkeypatch, case, sizes, D):
     if expect_fallback and filter_runs:
         assert st["flagged_queries"] > 0, st     # the certificate cannot hold here: the exact fallback must have run
     if case == "feature_tails" and filter_runs:
-        # (at 64 features the events below the second form's 2048 nodes are handed to the exact kernel wholesale)
-        by_design = sum(n for n in sizes if n < 2048) if D == 64 else 0
+        # (at 64 features the events below the second form's 800 nodes are handed to the exact kernel wholesale)
+        by_design = sum(n for n in sizes if n < F2_MIN_NODES) if D == 64 else 0
         # The second filter form's operands are fp16: a row with a feature at or beyond 16384 is a forced candidate of
         # every query (and as a query goes to the exact path).  exp(4 randn) per feature puts most rows there, so the
         # second-form events of this case are recomputed exactly BY DESIGN (a stated limit of the fp16 records, DESIGN
@@ -278,7 +280,7 @@ def test_knn_filter_adversarial(dev, monkeypatch, case, sizes, D):
         second_form = os.environ.get("DMET_KNN_FILTER", "") != "1"
         wide = bool((x.abs() >= 16384).any())
         for n in sizes:
-            if second_form and wide and n >= 2048:
+            if second_form and wide and n >= F2_MIN_NODES:
                 by_design += n
         assert st["flagged_queries"] - min(by_design, N) <= N // 20, st
 
@@ -332,15 +334,17 @@ def test_knn_many_sparse_uncertified_queries(dev):
 
 
 def test_knn_second_filter_form_paths_agree_fuzz(dev, monkeypatch):
-    """Events of 2048..7000 nodes (second filter form, including the split tail tiles of a small batch) against the
-    exact kernel on gaussian / clustered-with-duplicates / heavy-tailed / rank-2 data, k in {16, 8, 20, 13, 1}."""
+    """Events of 800..7000 nodes (second filter form: whole sweeps, split tail tiles of a small batch, and the small
+    events whose tail is never split) against the exact kernel on gaussian / clustered-with-duplicates / heavy-tailed /
+    rank-2 data, k in {16, 8, 20, 13, 1}."""
     from deepmetv2_amd import _native
     g = torch.Generator().manual_seed(4242)
-    for it in range(8):
+    for it in range(12):
         B = int(torch.randint(1, 5, (1,), generator=g))
-        sizes = [int(v) for v in torch.randint(2048, 7000, (B,), generator=g)]
+        lo_n = 2048 if it < 8 else F2_MIN_NODES                                 # the last rounds: small second-form events
+        sizes = [int(v) for v in torch.randint(lo_n, 7000 if it < 8 else 2600, (B,), generator=g)]
         if it % 3 == 0:
-            sizes.append(int(torch.randint(1, 2048, (1,), generator=g)))       # a first-form event in the same batch
+            sizes.append(int(torch.randint(1, F2_MIN_NODES, (1,), generator=g)))       # a first-form event in the same batch
         N = sum(sizes)
         k = [16, 8, 20, 13, 1][it % 5]
         x = torch.randn(N, 32, generator=g)
@@ -369,12 +373,14 @@ def test_knn_second_filter_form_paths_agree_fuzz(dev, monkeypatch):
 
 @pytest.mark.parametrize("D", [32, 64])
 def test_knn_filter_form_boundaries(dev, monkeypatch, D):
-    """Event sizes on both sides of every switch of the matrix-core path -- 2047 / 2048 / 2049 nodes (first vs second
-    filter form; exact kernel vs second form at 64 features) and 65535 / 65536 / 65537 nodes (16-bit candidate ids, the
-    second form's upper limit) -- against the exact kernel."""
+    """Event sizes on both sides of every switch of the matrix-core path -- 799 / 800 / 801 nodes (first vs second
+    filter form; exact kernel vs second form at 64 features), 2559 / 2560 / 2561 (smallest event whose tail sweeps are
+    cut in two) and 65535 / 65536 / 65537 nodes (16-bit candidate ids, the second form's upper limit) -- against the
+    exact kernel."""
     from deepmetv2_amd import _native
     g = torch.Generator().manual_seed(700 + D)
-    for sizes in ([2047, 2048, 2049, 31], [65535], [65536, 5], [65537]):
+    for sizes in ([799, 800, 801, 31], [2047, 2048, 2049, 31], [2559, 2560, 2561], [2560, 2600], [703, 704, 705],
+                  [65535], [65536, 5], [65537]):
         N = sum(sizes)
         x = torch.randn(N, D, generator=g).to(dev)
         ptr = _ptr(sizes).to(dev)
