@@ -339,7 +339,16 @@ __device__ __forceinline__ void knn_plan_body(const int64_t *__restrict__ ptr, i
             }
             const int b = order[plo];
             const int64_t nb = ptr[b + 1] - ptr[b];
-            if (nb >= kF2MinNodes && (nb < kF2SplitMinNodes || rem * 16 > simds * 5)) {
+            // (the tile-count bound only for a batch that is ALL tail: behind full rounds -- 64 events of 3000 nodes, 960
+            // tail tiles -- the halves still win, 248 us against 275)
+#ifndef DMET_F2_SPLIT_REM16
+#define DMET_F2_SPLIT_REM16 5
+#endif
+#ifndef DMET_F2_SPLIT_REM_ALLTAIL
+#define DMET_F2_SPLIT_REM_ALLTAIL 1
+#endif
+            if (nb >= kF2MinNodes && (nb < kF2SplitMinNodes ||
+                                      ((first_tail == 0 || !DMET_F2_SPLIT_REM_ALLTAIL) && rem * 16 > simds * DMET_F2_SPLIT_REM16))) {
                 plan->n_full = plan->total_tiles;
                 plan->split = 1;
             }

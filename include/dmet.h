@@ -85,7 +85,7 @@ int dmet_bn_knn_local_dense_f32(const float *raw, const float *residual, const f
                                 size_t ws_bytes, dmet_stream_t stream);
 
 /* Diagnostics of the matrix-core kNN path (D = 32 or 64, k <= 20): dmet_knn_f32 first ranks candidates with an MFMA
- * filter (fp16 operands for events of 2048..65536 nodes, a bf16 split for smaller ones), re-ranks the kept ones with
+ * filter (fp16 operands for events of 800..65536 nodes, a bf16 split for smaller ones), re-ranks the kept ones with
  * the exact R1 chain and certifies every query; uncertified queries are recomputed exactly (one workgroup per query
  * when their 128-query tile has at most 8 of them, by the exact tile kernel otherwise).  Rows with a feature of
  * magnitude >= 16384 (or not finite) in an event of 2048..65536 nodes are outside the fp16 operand range: they stay
