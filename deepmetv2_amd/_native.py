@@ -470,7 +470,9 @@ def gather_max_local_j16(P: torch.Tensor, Q: torch.Tensor, rows16: torch.Tensor,
     return out, argj
 
 
-def gather_max_bwd_j16(g_out: torch.Tensor, argj: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:
+def gather_max_bwd_j16(g_out: torch.Tensor, argj: torch.Tensor, ptr: torch.Tensor,
+                       max_nodes: Optional[int] = None) -> torch.Tensor:
+    """max_nodes: the batch's largest event when the caller knows it (a hint: workgroups sized for small events)."""
     dev = _require_device(g_out, argj, ptr)
     L = _lib.load()
     g_out = _f32c(g_out, "g_out")
@@ -480,8 +482,9 @@ def gather_max_bwd_j16(g_out: torch.Tensor, argj: torch.Tensor, ptr: torch.Tenso
     gQ = torch.empty((N, H), dtype=torch.float32, device=dev)
     _t = timer.record('gather_max_bwd', dev)
     with _on(dev):
-        _lib.check(L.dmet_gather_max_bwd_j16_f32(g_out.data_ptr(), argj.data_ptr(), ptr.data_ptr(), ptr.numel() - 1, N, H,
-                                                 gQ.data_ptr(), _stream(dev)), "dmet_gather_max_bwd_j16_f32")
+        _lib.check(L.dmet_gather_max_bwd_j16_cap_f32(g_out.data_ptr(), argj.data_ptr(), ptr.data_ptr(), ptr.numel() - 1, N, H,
+                                                     gQ.data_ptr(), int(max_nodes or 0), _stream(dev)),
+                   "dmet_gather_max_bwd_j16_cap_f32")
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))
     return gQ
@@ -1121,8 +1124,9 @@ def edgeconv_linear_bwd(x: torch.Tensor, weight: torch.Tensor, g_out: torch.Tens
 
 
 def gather_max_bwd_lds(g_out: torch.Tensor, arg: torch.Tensor, nbr: torch.Tensor, ptr: torch.Tensor,
-                       nbr_local: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """gQ[N,32] by per-event LDS scatter with exact integer sums (no reverse index); see include/dmet.h."""
+                       nbr_local: Optional[torch.Tensor] = None, max_nodes: Optional[int] = None) -> torch.Tensor:
+    """gQ[N,32] by per-event LDS scatter with exact integer sums (no reverse index); see include/dmet.h.
+    max_nodes: the batch's largest event when the caller knows it (a hint: workgroups sized for small events)."""
     dev = _require_device(g_out, arg, nbr, ptr)
     L = _lib.load()
     g_out = _f32c(g_out, "g_out")
@@ -1136,10 +1140,11 @@ def gather_max_bwd_lds(g_out: torch.Tensor, arg: torch.Tensor, nbr: torch.Tensor
         if nbr_local is not None and (nbr_local.shape != nbr.shape or nbr_local.dtype != torch.int16
                                       or not nbr_local.is_contiguous()):
             raise ValueError("nbr_local must be the contiguous int16 [N, k] table of knn_local()")
-        _lib.check(L.dmet_gather_max_bwd_lds16_f32(g_out.data_ptr(), arg.data_ptr(), nbr.data_ptr(),
-                                                   nbr_local.data_ptr() if nbr_local is not None else None,
-                                                   ptr.data_ptr(), B, N, nbr.shape[1], H, gQ.data_ptr(), _stream(dev)),
-                   "dmet_gather_max_bwd_lds16_f32")
+        _lib.check(L.dmet_gather_max_bwd_lds16_cap_f32(g_out.data_ptr(), arg.data_ptr(), nbr.data_ptr(),
+                                                       nbr_local.data_ptr() if nbr_local is not None else None,
+                                                       ptr.data_ptr(), B, N, nbr.shape[1], H, gQ.data_ptr(),
+                                                       int(max_nodes or 0), _stream(dev)),
+                   "dmet_gather_max_bwd_lds16_cap_f32")
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))
     return gQ

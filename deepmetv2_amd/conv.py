@@ -156,10 +156,11 @@ class _EdgeConvLinearMax(torch.autograd.Function):
             # arg holds the winners' event-local ids.  A row can still be empty although the table has self loops: a
             # query with a NaN / inf coordinate finds nobody, not even itself (0xFFFF, output 0 by R3) -- the node-level
             # kernel masks g_out there from the same ids (dmet_edgeconv_linear_bwd_add_j16_f32)
-            gQ = _native.gather_max_bwd_j16(g_out, arg, table.ptr)
+            gQ = _native.gather_max_bwd_j16(g_out, arg, table.ptr, max_nodes=table.max_nodes)
         elif H == 32 and g_out.dtype == torch.float32 and table.ptr is not None and GATHER_BWD_FORM != "reverse":
             # per-event LDS scatter with exact integer sums: no reverse index (radix sort) needed
-            gQ = _native.gather_max_bwd_lds(g_out, arg, table.nbr, table.ptr, nbr_local=table.nbr_local)
+            gQ = _native.gather_max_bwd_lds(g_out, arg, table.nbr, table.ptr, nbr_local=table.nbr_local,
+                                            max_nodes=table.max_nodes)
         else:
             rev_ptr, rev_pos = table.reverse()
             gQ = _native.gather_max_bwd(g_out, arg, rev_ptr, rev_pos, table.k)

@@ -252,14 +252,16 @@ constexpr int kBwdCells = 18432;             // 64-bit cells in LDS (144 KB)
 
 // J16: `arg` holds the winner's event-local node id per (node, channel) (uint16, 0xFFFF = none; written by
 // dmet_gather_max_counted_lds_j16_f32) instead of the winning slot: no table look-up at all.
-template <bool J16 = false>
-__global__ __launch_bounds__(kBwdThreads) void gather_max_bwd_lds_kernel(const float *__restrict__ g_out,
+template <bool J16 = false, int THREADS = kBwdThreads, int CELLS = kBwdCells>
+__global__ __launch_bounds__(THREADS) void gather_max_bwd_lds_kernel(const float *__restrict__ g_out,
                                                                           const uint8_t *__restrict__ arg,
                                                                           const int32_t *__restrict__ nbr,
                                                                           const uint16_t *__restrict__ nbr16,
                                                                           const int64_t *__restrict__ ptr, int B, int k,
                                                                           float *__restrict__ gQ)
 {
+    // (the names of the full-size constants, shadowed: a workgroup of THREADS threads with CELLS accumulators)
+    constexpr int kBwdThreads = THREADS, kBwdCells = CELLS;
     extern __shared__ unsigned long long cells[];
     __shared__ float red[kBwdThreads / kWave];
     const int bid = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -521,28 +523,60 @@ extern "C" int dmet_edgeconv_linear_bwd_f32(const float *x, const float *W, cons
     return dmet_edgeconv_linear_bwd_add_f32(x, W, g_out, arg, gQ, nullptr, N, H, gx, gW, gb, ws, ws_bytes, stream);
 }
 
-extern "C" int dmet_gather_max_bwd_lds16_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr,
-                                             const uint16_t *nbr_local, const int64_t *ptr, int B, int64_t N, int k,
-                                             int H, float *gQ, dmet_stream_t stream)
+// One launch of the scatter with a workgroup sized for the batch's largest event: the accumulators of a workgroup are
+// (event nodes) x 4 channels x 8 bytes of LDS, and a workgroup that reserves the whole CU's 144 KB for an event of 2 000
+// nodes runs alone on its CU through its serial phases (maximum, clearing, write-out).  `max_nodes` is a HINT (0 =
+// unknown): events larger than the chosen window take more passes, never a wrong result.
+//   max_nodes <= 1 152: 256 threads,  36 KB -> four workgroups per CU;   <= 2 304: 512 threads, 72 KB -> two;
+//   otherwise (and unknown): 1 024 threads, 144 KB.
+// 128 events of 1000 / 2000 nodes: 29.2 -> 20.3 us / 43.8 -> 35.8 us (same bits: integer sums).
+template <bool J16, int THREADS, int CELLS>
+int bwd_scatter_launch_as(const float *g_out, const uint8_t *arg, const int32_t *nbr, const uint16_t *nbr16,
+                          const int64_t *ptr, int B, int k, float *gQ, hipStream_t st)
 {
-    DMET_REQUIRE(H == kH, "dmet_gather_max_bwd_lds_f32: H=%d (only 32 is built)", H);
-    DMET_REQUIRE(N >= 0 && B >= 0 && k >= 1 && k <= 255, "dmet_gather_max_bwd_lds_f32: bad sizes");
-    if (N == 0 || B == 0) return 0;
-    DMET_REQUIRE(g_out && arg && nbr && ptr && gQ, "dmet_gather_max_bwd_lds_f32: null pointer");
-    DMET_REQUIRE(aligned16(g_out) && aligned16(gQ) && (reinterpret_cast<uintptr_t>(arg) & 3u) == 0,
-                 "dmet_gather_max_bwd_lds_f32: rows must be 16-byte aligned");
-    static bool attr_set = false;
-    const size_t lds = sizeof(unsigned long long) * (size_t)kBwdCells;
+    static bool attr_set = false;      // one flag per instantiation
+    const size_t lds = sizeof(unsigned long long) * (size_t)CELLS;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gather_max_bwd_lds_kernel<false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gather_max_bwd_lds_kernel<J16, THREADS, CELLS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gather_max_bwd_lds_kernel)");
         attr_set = true;
     }
-    hipLaunchKernelGGL(gather_max_bwd_lds_kernel<false>, dim3((unsigned)B * 8u), dim3(kBwdThreads), lds, as_stream(stream),
-                       g_out, arg, nbr, nbr_local, ptr, B, k, gQ);
+    hipLaunchKernelGGL((gather_max_bwd_lds_kernel<J16, THREADS, CELLS>), dim3((unsigned)B * 8u), dim3(THREADS), lds, st, g_out,
+                       arg, nbr, nbr16, ptr, B, k, gQ);
     DMET_LAUNCH_CHECK("gather_max_bwd_lds_kernel");
     return 0;
+}
+
+template <bool J16>
+int bwd_scatter_launch(const float *g_out, const uint8_t *arg, const int32_t *nbr, const uint16_t *nbr16,
+                       const int64_t *ptr, int B, int k, float *gQ, int64_t max_nodes, hipStream_t st)
+{
+    if (max_nodes > 0 && max_nodes <= kBwdCells / 16)
+        return bwd_scatter_launch_as<J16, 256, kBwdCells / 4>(g_out, arg, nbr, nbr16, ptr, B, k, gQ, st);
+    if (max_nodes > 0 && max_nodes <= kBwdCells / 8)
+        return bwd_scatter_launch_as<J16, 512, kBwdCells / 2>(g_out, arg, nbr, nbr16, ptr, B, k, gQ, st);
+    return bwd_scatter_launch_as<J16, kBwdThreads, kBwdCells>(g_out, arg, nbr, nbr16, ptr, B, k, gQ, st);
+}
+
+extern "C" int dmet_gather_max_bwd_lds16_cap_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr,
+                                                 const uint16_t *nbr_local, const int64_t *ptr, int B, int64_t N, int k,
+                                                 int H, float *gQ, int64_t max_nodes, dmet_stream_t stream)
+{
+    DMET_REQUIRE(H == kH, "dmet_gather_max_bwd_lds_f32: H=%d (only 32 is built)", H);
+    DMET_REQUIRE(N >= 0 && B >= 0 && k >= 1 && k <= 255 && max_nodes >= 0, "dmet_gather_max_bwd_lds_f32: bad sizes");
+    if (N == 0 || B == 0) return 0;
+    DMET_REQUIRE(g_out && arg && nbr && ptr && gQ, "dmet_gather_max_bwd_lds_f32: null pointer");
+    DMET_REQUIRE(aligned16(g_out) && aligned16(gQ) && (reinterpret_cast<uintptr_t>(arg) & 3u) == 0,
+                 "dmet_gather_max_bwd_lds_f32: rows must be 16-byte aligned");
+    return bwd_scatter_launch<false>(g_out, arg, nbr, nbr_local, ptr, B, k, gQ, max_nodes, as_stream(stream));
+}
+
+extern "C" int dmet_gather_max_bwd_lds16_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr,
+                                             const uint16_t *nbr_local, const int64_t *ptr, int B, int64_t N, int k,
+                                             int H, float *gQ, dmet_stream_t stream)
+{
+    return dmet_gather_max_bwd_lds16_cap_f32(g_out, arg, nbr, nbr_local, ptr, B, N, k, H, gQ, 0, stream);
 }
 
 extern "C" int dmet_gather_max_bwd_lds_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr,
@@ -552,26 +586,21 @@ extern "C" int dmet_gather_max_bwd_lds_f32(const float *g_out, const uint8_t *ar
     return dmet_gather_max_bwd_lds16_f32(g_out, arg, nbr, nullptr, ptr, B, N, k, H, gQ, stream);
 }
 
-extern "C" int dmet_gather_max_bwd_j16_f32(const float *g_out, const uint16_t *argj, const int64_t *ptr, int B, int64_t N,
-                                           int H, float *gQ, dmet_stream_t stream)
+extern "C" int dmet_gather_max_bwd_j16_cap_f32(const float *g_out, const uint16_t *argj, const int64_t *ptr, int B,
+                                               int64_t N, int H, float *gQ, int64_t max_nodes, dmet_stream_t stream)
 {
     DMET_REQUIRE(H == kH, "dmet_gather_max_bwd_j16_f32: H=%d (only 32 is built)", H);
-    DMET_REQUIRE(N >= 0 && B >= 0, "dmet_gather_max_bwd_j16_f32: bad sizes");
+    DMET_REQUIRE(N >= 0 && B >= 0 && max_nodes >= 0, "dmet_gather_max_bwd_j16_f32: bad sizes");
     if (N == 0 || B == 0) return 0;
     DMET_REQUIRE(g_out && argj && ptr && gQ, "dmet_gather_max_bwd_j16_f32: null pointer");
     DMET_REQUIRE(aligned16(g_out) && aligned16(gQ) && (reinterpret_cast<uintptr_t>(argj) & 7u) == 0,
                  "dmet_gather_max_bwd_j16_f32: rows must be 16-byte (argj: 8-byte) aligned");
-    static bool attr_set = false;
-    const size_t lds = sizeof(unsigned long long) * (size_t)kBwdCells;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gather_max_bwd_lds_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(gather_max_bwd_lds_kernel)");
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(gather_max_bwd_lds_kernel<true>, dim3((unsigned)B * 8u), dim3(kBwdThreads), lds, as_stream(stream),
-                       g_out, reinterpret_cast<const uint8_t *>(argj), (const int32_t *)nullptr, (const uint16_t *)nullptr, ptr,
-                       B, 1, gQ);
-    DMET_LAUNCH_CHECK("gather_max_bwd_lds_kernel (winner ids)");
-    return 0;
+    return bwd_scatter_launch<true>(g_out, reinterpret_cast<const uint8_t *>(argj), nullptr, nullptr, ptr, B, 1, gQ, max_nodes,
+                                    as_stream(stream));
+}
+
+extern "C" int dmet_gather_max_bwd_j16_f32(const float *g_out, const uint16_t *argj, const int64_t *ptr, int B, int64_t N,
+                                           int H, float *gQ, dmet_stream_t stream)
+{
+    return dmet_gather_max_bwd_j16_cap_f32(g_out, argj, ptr, B, N, H, gQ, 0, stream);
 }

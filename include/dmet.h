@@ -272,6 +272,16 @@ int dmet_gather_max_bwd_lds_f32(const float *g_out, const uint8_t *arg, const in
 int dmet_gather_max_bwd_lds16_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr,
                                   const uint16_t *nbr_local, const int64_t *ptr, int B, int64_t N, int k, int H,
                                   float *gQ, dmet_stream_t stream);
+/* The same two scatters with a HINT on the batch's largest event (max_nodes; 0 = unknown = the entries above): a
+ * workgroup's accumulators are (event nodes) x 4 channels x 8 bytes of LDS, so for batches of small events -- what
+ * model/data_loader.py:67-90 yields on real data, 1 000-2 500 candidates per event -- the workgroups are sized down
+ * (<= 1 152 nodes: 256 threads, 36 KB; <= 2 304: 512 threads, 72 KB) and several share a CU.  Events larger than the
+ * hint take more passes: slower, never wrong.  Same bits as the unhinted entries (integer sums). */
+int dmet_gather_max_bwd_lds16_cap_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr,
+                                      const uint16_t *nbr_local, const int64_t *ptr, int B, int64_t N, int k, int H,
+                                      float *gQ, int64_t max_nodes, dmet_stream_t stream);
+int dmet_gather_max_bwd_j16_cap_f32(const float *g_out, const uint16_t *argj, const int64_t *ptr, int B, int64_t N, int H,
+                                    float *gQ, int64_t max_nodes, dmet_stream_t stream);
 /* Reverse index: a stable sort of the positions 0..M-1 of an int32 key array by key value.
  *   rev_ptr[num_keys+1]: rev_pos[rev_ptr[j] .. rev_ptr[j+1]-1] = the positions holding key j, ascending.
  * Keys outside [0, num_keys) (the -1 "no neighbour" entries) sort last and are not indexed.

@@ -264,7 +264,7 @@ def edgeconv_linear_bwd(x, weight, g_out, arg, gQ, want_bias=True, g_add=None):
     return gx, gW, (gP.sum(0) if want_bias else None)
 
 
-def gather_max_bwd_lds(g_out, arg, nbr, ptr, nbr_local=None):
+def gather_max_bwd_lds(g_out, arg, nbr, ptr, nbr_local=None, max_nodes=None):
     N, H = g_out.shape
     gQ = torch.zeros_like(g_out)
     a = arg.long()
@@ -358,7 +358,7 @@ def gather_max_local_j16(P, Q, rows16, cnt, order, ptr, kmax, sliced):
     return gather_max_counted_j16(P, Q, nbr, cnt, order, ptr, sliced)
 
 
-def gather_max_bwd_j16(g_out, argj, ptr):
+def gather_max_bwd_j16(g_out, argj, ptr, max_nodes=None):
     N, H = g_out.shape
     counts = (ptr[1:] - ptr[:-1]).long()
     lo = torch.repeat_interleave(ptr[:-1], counts).view(-1, 1)

@@ -571,7 +571,7 @@ def test_counted_radius_table_consumers_go_by_cnt(dev, monkeypatch, reverse_rout
             assert torch.equal(o0, o1) and torch.equal(a0, a1)
 
 
-@pytest.mark.parametrize("sizes", [[300, 1, 0, 77], [4700, 50], [9500], [19000, 3]])
+@pytest.mark.parametrize("sizes", [[300, 1, 0, 77], [1152, 1100, 5], [2304, 1153], [4700, 50], [9500], [19000, 3]])
 def test_gather_max_bwd_lds_matches_reverse_index_route(dev, sizes):
     """K5: the LDS fixed-point scatter (no reverse index) against the sorted reverse-index kernel (itself pinned to
     the oracle by the EdgeConv backward tests): 1e-6 of max|g| per cell (each term is rounded to 2^-30 of the
@@ -602,6 +602,11 @@ def test_gather_max_bwd_lds_matches_reverse_index_route(dev, sizes):
     loc = nbr - lo
     loc = torch.where(loc >= 0x8000, loc - 0x10000, loc).to(torch.int16).to(dev)
     assert torch.equal(got, _native.gather_max_bwd_lds(gd, ad, nd, pd, nbr_local=loc))
+    # the hint on the largest event only sizes the workgroups (256 / 512 / 1024 threads): same bits for a true hint, for
+    # one that is too small (more passes over the window) and for one that is too large
+    for hint in (max(sizes), 1000, 2304, 2305, 100000):
+        assert torch.equal(got, _native.gather_max_bwd_lds(gd, ad, nd, pd, nbr_local=loc, max_nodes=hint)), hint
+        assert torch.equal(got, _native.gather_max_bwd_lds(gd, ad, nd, pd, max_nodes=hint)), hint
     scale = g_out.abs().amax(0).to(dev) * float(max(sizes)) * 1e-6 + 1e-12
     assert bool(((got - ref).abs() <= scale + 1e-5 * ref.abs()).all())
 
@@ -629,6 +634,8 @@ def test_gather_max_bwd_winner_id_form_at_large_events(dev, sizes):
     pd, gd = ptr.to(dev), g_out.to(dev)
     got = _native.gather_max_bwd_j16(gd, argj16.to(dev), pd)
     assert torch.equal(got, _native.gather_max_bwd_j16(gd, argj16.to(dev), pd))
+    for hint in (max(sizes), 900, 2000):          # workgroup size hint: true, and far too small
+        assert torch.equal(got, _native.gather_max_bwd_j16(gd, argj16.to(dev), pd, max_nodes=hint)), hint
     slot_form = _native.gather_max_bwd_lds(gd, arg.to(dev), nbr.to(dev), pd)
     assert torch.equal(got, slot_form)
     ref = torch.zeros(N, H, dtype=torch.float64)
