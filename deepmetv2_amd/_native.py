@@ -114,6 +114,11 @@ GATHER_MAX_FORM = os.environ.get("DMET_GATHER_MAX_FORM", "auto")
 RADIUS_FORM = os.environ.get("DMET_RADIUS", "windowed")   # "sweep": all pairs of an event (dmet_radius_f32)
 
 
+# table widths the LDS-resident fp32 gather kernels are built for (k = 4 K4; 20 = the reference's own default,
+# model/graph_met_network.py:63); other widths take the L2 form
+LDS_GATHER_K = (8, 16, 20, 32)
+
+
 def _note_gather(name: str) -> None:
     global last_gather_kernel
     last_gather_kernel = name
@@ -318,7 +323,7 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
                nbr_local: Optional[torch.Tensor] = None, sliced: bool = False, mixed: bool = False
                ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """out = P + max over the rows of Q listed in nbr (+ uint8 arg).  lds=True: the caller knows every event fits
-    the LDS image (<= 5119 nodes, k in {8,16,32}, H % 8 == 0) -> LDS-resident kernel; mixed=True: some events do not,
+    the LDS image (<= 5119 nodes, k in LDS_GATHER_K, H % 8 == 0) -> LDS-resident kernel; mixed=True: some events do not,
     the form is chosen per event inside the call (row-major P / Q); else gathers come from L2."""
     dev = _require_device(P, Q, nbr)
     L = _lib.load()
@@ -350,7 +355,7 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
     out = torch.empty((N, H), dtype=torch.float32, device=dev)
     arg = torch.empty((N, H), dtype=torch.uint8, device=dev) if want_arg else None
     if sliced and cnt is None:
-        if ptr is None or k not in (8, 16, 32) or GATHER_MAX_FORM == "l2-only":
+        if ptr is None or k not in LDS_GATHER_K or GATHER_MAX_FORM == "l2-only":
             raise ValueError("gather_max: slice-major tables are only read by the LDS-resident kernels")
         _t = timer.record('gather_max', dev)
         _note_gather("gather_max_lds_kernel (per-event Q slice resident in LDS; slice-major P/Q, "
@@ -388,7 +393,7 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
     _t = timer.record('gather_max', dev)
     use_lds = (lds or GATHER_MAX_FORM == "lds") and GATHER_MAX_FORM != "l2-only" and ptr is not None and H % 8 == 0
     with _on(dev):
-        if use_lds and nbr_local is not None and k in (8, 16, 32):
+        if use_lds and nbr_local is not None and k in LDS_GATHER_K:
             if nbr_local.shape != nbr.shape or nbr_local.dtype != torch.int16 or not nbr_local.is_contiguous():
                 raise ValueError("nbr_local must be the contiguous int16 [N, k] table of knn_local()")
             _note_gather("gather_max_lds_kernel (per-event Q slice resident in LDS; row-major P/Q, uint16 ids)")

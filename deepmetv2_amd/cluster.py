@@ -43,10 +43,10 @@ def knn_table(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loo
     # fused form (table.pq = (P, Q, sliced), or None when the build could not)
     loc = None
     pq = None
-    if loop and kk in (8, 16, 32) and dense is not None and x.shape[1] == 32:
+    if loop and kk in _native.LDS_GATHER_K and dense is not None and x.shape[1] == 32:
         W, b, sliced_of = dense
         nbr, dist, loc, pq = _native.knn_local_dense(x, info.ptr, kk, W, b, sliced_of(info.max_nodes))
-    elif loop and kk in (8, 16, 32):
+    elif loop and kk in _native.LDS_GATHER_K:
         nbr, dist, loc = _native.knn_local(x, info.ptr, kk)
     else:
         nbr, dist = _native.knn(x, info.ptr, kk)

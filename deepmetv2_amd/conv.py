@@ -65,7 +65,7 @@ BN_KNN_FUSE = os.environ.get("DMET_BN_KNN_FUSE", "1")
 
 
 def _lds_eligible(x, weight, table: NeighborTable, any_size: bool = False) -> bool:
-    return (x.shape[1] == 32 and weight.shape[0] == 32 and table.k in (8, 16, 32)
+    return (x.shape[1] == 32 and weight.shape[0] == 32 and table.k in _native.LDS_GATHER_K
             and table.ptr is not None and table.max_nodes is not None
             and (any_size or table.max_nodes <= _LDS_MAX_EVENT_NODES) and table.nbr.data_ptr() % 16 == 0)
 
@@ -523,7 +523,7 @@ class DynamicEdgeConv(EdgeConv):
         if KNN_RIDER == "0" or self.aggr != "max" or EDGECONV_FORM != "split" or x.shape[1] != 32 or not x.is_cuda:
             return None
         lin = _as_fusable_linear(self.nn)
-        if lin is None or lin.in_features != 64 or lin.out_features != 32 or self.k not in (8, 16, 32):
+        if lin is None or lin.in_features != 64 or lin.out_features != 32 or self.k not in _native.LDS_GATHER_K:
             return None
         bf16 = self._wants_bf16()
 

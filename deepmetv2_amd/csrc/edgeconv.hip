@@ -331,9 +331,14 @@ __device__ __forceinline__ void load_ids16_pair(unsigned (&w)[K4], const uint16_
             const uint4 v = reinterpret_cast<const uint4 *>(src)[q];
             w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
         }
-    } else {
+    } else if (K4 == 2) {
         const uint2 v = *reinterpret_cast<const uint2 *>(src);
         w[0] = v.x; w[1] = v.y;
+    } else {
+        // k = 20 (the reference's own default, model/graph_met_network.py:63): rows of 40 bytes, a lane's half starts on a
+        // 4-byte boundary only -- plain dword loads
+#pragma unroll
+        for (int q = 0; q < K4; ++q) w[q] = src[q];
     }
 }
 
@@ -350,7 +355,7 @@ __device__ __forceinline__ void gather_max_lds_segment(
     float *__restrict__ out, uint8_t *__restrict__ arg, int64_t N, int skip_big, const int b, const int sl, const int i0,
     const int i1)
 {
-    static_assert(!IDS16 || K4 % 2 == 0, "uint16 tables: k must be a multiple of 8");
+    static_assert(K4 >= 1 && K4 <= 8, "k = 4 K4 <= 32");
     constexpr int RPI = kLdsGatherThreads / 2;                                // rows per iteration (2 lanes per node)
     const int lo = (int)ptr[b], hi = (int)ptr[b + 1];
     const int n = hi - lo;
@@ -511,10 +516,12 @@ __device__ __forceinline__ void gather_max_lds_segment(
 #pragma unroll
         for (int q0 = 0; q0 < (GML_MODE == 2 ? 0 : K4); q0 += 2) {
             float4 v[8];
+            constexpr int kLastSlot = 4 * K4 - 1;     // odd K4 (k = 20): the last round holds four slots, not eight
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = qs[off[4 * q0 + u]];
+            for (int u = 0; u < 8; ++u) v[u] = qs[off[min(4 * q0 + u, kLastSlot)]];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
+                if (4 * q0 + u > kLastSlot) continue;
                 if (WITH_ARG) {
                     switch (4 * q0 + u) {   // the slot must be an immediate
 #define DMET_CASE(S_) case S_: DMET_MAX_ARG(bx, a0, v[u].x, S_); DMET_MAX_ARG(by, a1, v[u].y, S_); \
@@ -527,7 +534,7 @@ __device__ __forceinline__ void gather_max_lds_segment(
                         DMET_CASE(31)
 #undef DMET_CASE
                     }
-                } else if ((u & 1) == 0) {   // two rows per v_max3_f32
+                } else if ((u & 1) == 0) {   // two rows per v_max3_f32 (4 K4 is even: a pair never straddles the end)
                     asm("v_max3_f32 %0, %0, %1, %2" : "+v"(bx) : "v"(v[u].x), "v"(v[u + 1].x));
                     asm("v_max3_f32 %0, %0, %1, %2" : "+v"(by) : "v"(v[u].y), "v"(v[u + 1].y));
                     asm("v_max3_f32 %0, %0, %1, %2" : "+v"(bz) : "v"(v[u].z), "v"(v[u + 1].z));
@@ -1365,9 +1372,10 @@ static int gather_max_lds_impl(const float *P, const float *Q, const int32_t *nb
 #endif
     if (k == 8) DMET_GML(2);
     else if (k == 16) DMET_GML(4);
+    else if (k == 20) DMET_GML(5);
     else if (k == 32) DMET_GML(8);
     else {
-        DMET_REQUIRE(!sliced, "dmet_gather_max_lds_sliced_f32: k=%d (slice-major tables need k in {8,16,32})", k);
+        DMET_REQUIRE(!sliced, "dmet_gather_max_lds_sliced_f32: k=%d (slice-major tables need k in {8,16,20,32})", k);
         return dmet_gather_max_f32(P, Q, nbr, ptr, B, N, k, H, out, arg, stream);  // other widths: L2 form
     }
 #undef DMET_GML

@@ -151,7 +151,7 @@ int dmet_gather_max_f32(const float *P, const float *Q, const int32_t *nbr, cons
                         int64_t N, int k, int H, float *out, uint8_t *arg, dmet_stream_t stream);
 /* Slice-major pair: step 1 writes P and Q as [Hout/8][N][8] (the 8-channel slice of every node contiguous) and the
  * LDS-resident gather reads them that way -- its (event, slice) workgroups then stage Q and stream P as contiguous
- * bytes instead of 32-byte pieces of 128-byte rows.  out / arg stay row-major; nbr_local may be NULL; k in {8,16,32},
+ * bytes instead of 32-byte pieces of 128-byte rows.  out / arg stay row-major; nbr_local may be NULL; k in {8,16,20,32},
  * H % 8 == 0.  Same results as dmet_node_linear_split_f32 + dmet_gather_max_lds_f32. */
 int dmet_node_linear_split_sliced_f32(const float *x, int64_t N, int Hin, int Hout, const float *W,
                                       const float *b, float *P, float *Q, dmet_stream_t stream);
@@ -205,7 +205,7 @@ int dmet_gather_max_local_j16_f32(const float *P, const float *Q, const uint16_t
  * with exact integer sums of dmet_gather_max_bwd_lds_f32 (bitwise reproducible), H = 32. */
 int dmet_gather_max_bwd_j16_f32(const float *g_out, const uint16_t *argj, const int64_t *ptr, int B, int64_t N, int H,
                                 float *gQ, dmet_stream_t stream);
-/* Same again with the table ALSO given as event-local uint16 ids (nbr_local from dmet_knn_local_f32; k in {8,16,32},
+/* Same again with the table ALSO given as event-local uint16 ids (nbr_local from dmet_knn_local_f32; k in {8,16,20,32},
  * 16-byte aligned): events that fit the LDS image read their ids from it -- half the id bytes, and every one of the
  * H/8 slice workgroups of an event re-reads the ids, so this is a third of the kernel's L2 requests.  Larger events
  * read nbr as before.  Results are identical to dmet_gather_max_lds_f32. */
@@ -215,7 +215,7 @@ int dmet_gather_max_lds16_f32(const float *P, const float *Q, const int32_t *nbr
 /* Ragged batches (BASELINE configs[4]: events of 500..8000 nodes): the gather form is chosen PER EVENT inside one call.
  * Events whose Q slice fits the LDS image (<= 5119 nodes) take the LDS-resident kernel, larger ones the L2-form kernel
  * (8 lanes per node, 16 row gathers in flight); both read the row-major P / Q tables and each skips the other's
- * events.  nbr_local may be NULL.  H = 32 and k in {8,16,32}; anything else is dmet_gather_max_f32.  Results are
+ * events.  nbr_local may be NULL.  H = 32 and k in {8,16,20,32}; anything else is dmet_gather_max_f32.  Results are
  * identical to dmet_gather_max_f32.  Replaces the same reference lines as dmet_gather_max_f32
  * (model/graph_met_network.py:63,65 through torch_geometric.nn.EdgeConv / torch_scatter.scatter(max)). */
 int dmet_gather_max_mixed_f32(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr_local,

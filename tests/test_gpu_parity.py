@@ -57,7 +57,8 @@ def test_knn_bit_exact(dev, sizes, D, k):
     t = dm.knn_table(x.to(dev), k, batch.to(dev), loop=True, num_events=len(sizes))
     assert torch.equal(t.nbr.cpu(), nbr_ref)
     assert torch.equal(t.dist.cpu(), dist_ref)  # distances are the same fmaf chain: bit-exact too
-    assert (t.nbr_local is not None) == (k in (8, 16, 32))
+    from deepmetv2_amd import _native
+    assert (t.nbr_local is not None) == (k in _native.LDS_GATHER_K)
     n2, d2, _ = _knn_with_stats(x.to(dev), ptr.to(dev), k)     # also checks the uint16 local table (any k)
     assert torch.equal(n2, nbr_ref) and torch.equal(d2, dist_ref)
 
@@ -647,7 +648,7 @@ def test_gather_max_bwd_winner_id_form_at_large_events(dev, sizes):
     assert bool(((got.cpu().double() - ref).abs() <= tol + 1e-6 * ref.abs()).all())
 
 
-@pytest.mark.parametrize("k", [8, 16, 32])
+@pytest.mark.parametrize("k", [8, 16, 20, 32])
 def test_gather_max_local_ids_kernel_matches(dev, k):
     """K3: the LDS gather kernel fed with the uint16 event-local table must return the bits of the int32 form (and
     of the L2 form), including an event too large for the LDS image (reads the int32 table) and empty events."""
