@@ -78,6 +78,9 @@ def parse_args():
                     help="untimed run-in before the W warm-up steps: the same step repeated for this long, so that the "
                          "module loads, the allocator's growth and the GPU's clock ramp are over when warm-up starts "
                          "(a cold start makes the first ~30 steps 5 %% slower); 0 disables it")
+    ap.add_argument("--bracket-every", type=int, default=4,
+                    help="the graded kernel's HIP-event bracket is recorded in every n-th step of the timed region "
+                         "(a bracket is two extra stream commands)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-events", type=int, default=0, help="0 = one event per host core (max 16)")
     return ap.parse_args()
@@ -546,7 +549,8 @@ def main():
     barrier()
     t0 = time.perf_counter()
     dbg = [] if os.environ.get("DMET_BENCH_STEP_TIMES") == "1" else None
-    for _ in range(args.steps):
+    for it in range(args.steps):
+        _native.timer.enabled = it % args.bracket_every == 0
         step()
         if dbg is not None:
             dbg.append(time.perf_counter() - t0)
@@ -641,7 +645,9 @@ def main():
                        "global_batch": B * world, "mode": args.mode, "graph": args.graph, "parallelism": f"dp{world}",
                        "hip_graph": bool(args.hip_graph), "input": args.input,
                        "model": args.model + ("" if args.accelerate == "none" else f" + accelerate({args.accelerate})"),
-                       "optimizer": optimizer_name, "prewarm_ms": args.prewarm_ms, "gc_disabled": True},
+                       "optimizer": optimizer_name, "prewarm_ms": args.prewarm_ms, "gc_disabled": True,
+                       "graded_kernel_bracketed_every_nth_step": args.bracket_every,
+                       "weight_grad_sums": "one launch per step (dmet_finalize_flush)" if _native.DEFER_FINALIZE else "per call"},
             "roofline": roof, "kernels": kernels,
         }
         if hip_graph_note:

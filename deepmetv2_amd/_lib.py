@@ -31,6 +31,10 @@ SIGNATURES = {
                                          _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_knn_local_dense_f32": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_knn_fallback_stats": (_i, [_vp, _i64, _i, _i, _i, _vp, _vp]),
+    "dmet_knn_size_hint": (_i, [_i, _i]),
+    "dmet_finalize_defer_begin": (_i, []),
+    "dmet_finalize_pending": (_i, []),
+    "dmet_finalize_flush": (_i, [_vp]),
     "dmet_radius_f32": (_i, [_vp, _vp, _i, _i64, _i, _f, _i, _i, _vp, _vp, _vp]),
     "dmet_radius_counted_f32": (_i, [_vp, _vp, _i, _i64, _i, _f, _i, _i, _vp, _vp, _vp]),
     "dmet_radius_workspace_bytes": (_sz, [_i64]),

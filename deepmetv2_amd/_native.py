@@ -125,6 +125,53 @@ def _note_gather(name: str) -> None:
 
 
 # ---- K1 ------------------------------------------------------------------------------------------------------
+# ---- the weight-gradient sums of a backward pass in one launch (dmet_finalize_defer_begin / dmet_finalize_flush) --------
+DEFER_FINALIZE = os.environ.get("DMET_DEFER_FINALIZE", "1") != "0"
+_DEFER = {"active": False, "keep": [], "dev": None}
+
+
+def finalize_defer_begin() -> bool:
+    """From here to finalize_flush() (process-wide: autograd runs backward on a thread of its own) edgeconv_linear_bwd, encode_bwd / encode_bn_bwd and head_bwd leave
+    the small second launch that sums their weight-gradient partials to ONE launch at the flush: their parameter
+    gradients hold garbage until then (the harness flushes right after loss.backward()), and their workspaces are kept
+    alive here.  DMET_DEFER_FINALIZE=0: a no-op (every call sums its own partials at once, as without this call)."""
+    if not DEFER_FINALIZE:
+        return False
+    _lib.check(_lib.load().dmet_finalize_defer_begin(), "dmet_finalize_defer_begin")
+    _DEFER["active"], _DEFER["keep"], _DEFER["dev"] = True, [], None
+    return True
+
+
+def finalize_flush() -> None:
+    """Form every queued weight-gradient sum (one launch on the stream of the device the queued calls ran on) and end
+    the deferral; a no-op outside one."""
+    if not _DEFER["active"]:
+        return
+    dev = _DEFER["dev"]
+    L = _lib.load()
+    try:
+        if dev is not None and L.dmet_finalize_pending() > 0:
+            with _on(dev):
+                _lib.check(L.dmet_finalize_flush(_stream(dev)), "dmet_finalize_flush")
+        else:
+            _lib.check(L.dmet_finalize_flush(None), "dmet_finalize_flush")
+    finally:
+        _DEFER["active"], _DEFER["keep"], _DEFER["dev"] = False, [], None
+
+
+def _defer_keep(dev: torch.device, *workspaces: torch.Tensor) -> None:
+    # a queued sum reads its partials from the call's workspace at the flush: the workspace must not go back to the allocator
+    if _DEFER["active"]:
+        _DEFER["dev"] = dev
+        _DEFER["keep"].extend(workspaces)
+
+
+def knn_size_hint(min_nodes: Optional[int], max_nodes: Optional[int]) -> None:
+    """Tell the NEXT kNN build on this thread what the caller knows about its event sizes (dmet_knn_size_hint)."""
+    if min_nodes and max_nodes:
+        _lib.check(_lib.load().dmet_knn_size_hint(int(min_nodes), int(max_nodes)), "dmet_knn_size_hint")
+
+
 def _knn(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict], want_local: bool, dense=None):
     """dense = (W[32,64], b or None, sliced): also ask the build for the node-level dense layer of the EdgeConv that
     consumes the graph (dmet_knn_local_dense_f32); a fourth result (P, Q) or None is then returned."""
@@ -886,6 +933,7 @@ def encode_bwd(x_cont: torch.Tensor, x_cat: torch.Tensor, params, h: torch.Tenso
         _lib.check(L.dmet_encode_bwd_f32(x.data_ptr(), x.stride(0), xc.data_ptr() if xc is not None else None, N, *[t.data_ptr() for t in ps],
                                          h.data_ptr(), g_h.data_ptr(), *[g.data_ptr() for g in grads], ws.data_ptr(),
                                          ws.numel(), _stream(dev)), "dmet_encode_bwd_f32")
+        _defer_keep(dev, ws)
     return grads
 
 
@@ -918,6 +966,7 @@ def encode_bn_bwd(x_cont: torch.Tensor, x_cat: torch.Tensor, params, h: torch.Te
                                             *[g.data_ptr() for g in grads],
                                             ctypes.cast(ctypes.pointer(fused), ctypes.c_void_p), ws2.data_ptr(), ws2.numel(),
                                             _stream(dev)), "dmet_encode_bn_bwd_f32")
+        _defer_keep(dev, ws2)
     if not fused.value:
         return None
     return grads, st[0], st[1]
@@ -1125,6 +1174,7 @@ def edgeconv_linear_bwd(x: torch.Tensor, weight: torch.Tensor, g_out: torch.Tens
                          gb.data_ptr() if gb is not None else None,
                          ws.data_ptr(), ws.numel(), _stream(dev)),
                    "dmet_edgeconv_linear_bwd_add_j16_f32" if j16 else "dmet_edgeconv_linear_bwd_add_f32")
+        _defer_keep(dev, ws)
     return gx, gW, gb
 
 
@@ -1243,6 +1293,7 @@ def head_bwd(emb: torch.Tensor, params, out: torch.Tensor, g_out: torch.Tensor):
                                        out.data_ptr(), g_out.data_ptr(), g_emb.data_ptr(),
                                        *[g.data_ptr() for g in grads], ws.data_ptr(), ws.numel(), _stream(dev)),
                    "dmet_head_bwd_f32")
+        _defer_keep(dev, ws)
     return [g_emb] + grads
 
 

@@ -12,7 +12,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 OBJ_DIR = os.path.join(CSRC, "_obj")
 LIB_PATH = os.path.join(PKG_DIR, "libdmet_hip.so")
 SOURCES = ["knn.hip", "edgeconv.hip", "edgemlp.hip", "misc.hip", "dense.hip", "encoder.hip", "norm.hip", "edgeconv_bwd.hip",
-           "head.hip"]
+           "head.hip", "finalize.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "nls_body.h"), os.path.join(PKG_DIR, "..", "include", "dmet.h")]
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall",

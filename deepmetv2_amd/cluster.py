@@ -43,6 +43,7 @@ def knn_table(x: torch.Tensor, k: int, batch: Optional[torch.Tensor] = None, loo
     # fused form (table.pq = (P, Q, sliced), or None when the build could not)
     loc = None
     pq = None
+    _native.knn_size_hint(info.min_nodes, info.max_nodes)    # what the loader knows about the event sizes (spent by the build below)
     if loop and kk in _native.LDS_GATHER_K and dense is not None and x.shape[1] == 32:
         W, b, sliced_of = dense
         nbr, dist, loc, pq = _native.knn_local_dense(x, info.ptr, kk, W, b, sliced_of(info.max_nodes))

@@ -501,6 +501,7 @@ class DynamicEdgeConv(EdgeConv):
             info = batch_info(batch, raw.shape[0], raw.device)
             req = self._dense_request(raw)
             dense = (req[0], req[1], req[2](info.max_nodes)) if req is not None else None
+            _native.knn_size_hint(info.min_nodes, info.max_nodes)
             out = _native.bn_knn_local_dense(raw, residual, gamma, beta, mean, invstd, info.ptr, self.k, dense)
             if out is None:
                 return None

@@ -65,6 +65,23 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblk)
     return base + idx;
 }
 
+// ---- deferred weight-gradient sums (csrc/finalize.hip) -----------------------------------------------------------------
+// The backward kernels of the EdgeConv's dense layer, the encoder and the output head leave per-workgroup partial sums
+// of their weight gradients and a small second launch adds them up.  Nothing but the optimizer reads those sums, so a
+// caller may ask for all of them to be formed by ONE launch at the end of the backward pass
+// (dmet_finalize_defer_begin / dmet_finalize_flush): the entry points then queue a descriptor instead of launching.
+constexpr int kEcbPartialFloats = 2 * 1024 + 32;    // csrc/edgeconv_bwd.hip: gP^T x | gQ^T x | column sums of gP
+constexpr int kEncPartialFloats = 3 * 1024 + 64;    // csrc/encoder.hip: three 32 x 32 tiles | dba | dbk | dbc
+constexpr int kHeadPartialFloats = 1024 + 64;       // csrc/head.hip: A^T emb tile | gW2 | gb2 | gb1
+enum { kDeferEdgeConv = 0, kDeferEncoder = 1, kDeferHead = 2 };
+struct DeferDesc {
+    int kind;
+    const float *partial;   // [nparts][k*PartialFloats]
+    int64_t nparts;
+    float *out[9];          // edgeconv: gW, gb (may be null) | encoder: Wc bc Wk bk Wa ba Echg Epdg Epv | head: gW1 gb1 gW2 gb2
+};
+bool defer_push(const DeferDesc &d);   // true: queued, the caller launches no finalize step of its own
+
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll

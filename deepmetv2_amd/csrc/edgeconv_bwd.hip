@@ -493,6 +493,8 @@ static int ecb_launch(const float *x, const float *W, const float *g_out, const 
         hipLaunchKernelGGL(edgeconv_linear_bwd_kernel<false>, dim3((unsigned)(nw / kWavesPerBlock)), dim3(kWave * kWavesPerBlock),
                            0, st, x, W, g_out, arg, gQ, N, npw, g_add, gx, partial, fin_counters);
     DMET_LAUNCH_CHECK("edgeconv_linear_bwd_kernel");
+    static_assert(kPartial == kEcbPartialFloats && kFinGroups == 33, "csrc/finalize.hip sums the same partial layout");
+    if (defer_push(DeferDesc{kDeferEdgeConv, partial, nw / kWavesPerBlock, {gW, gb}})) return 0;   // summed by dmet_finalize_flush
     hipLaunchKernelGGL(edgeconv_linear_bwd_finalize_kernel, dim3(kFinGroups), dim3(1024), 0, st, partial, nw / kWavesPerBlock,
                        gW, gb);
     DMET_LAUNCH_CHECK("edgeconv_linear_bwd_finalize_kernel");

@@ -781,6 +781,8 @@ extern "C" int dmet_encode_bwd_f32(const float *x, int64_t x_stride, const int64
     DMET_LAUNCH_CHECK("encode_bwd_kernel");
     EncGrads gr{gWc, gbc, gWk, gbk, gWa, gba, gEchg, gEpdg, gEpv};
     static_assert(kEncPartial % 32 == 0, "finalize blocks own 32 elements");
+    static_assert(kEncPartial == kEncPartialFloats, "csrc/finalize.hip sums the same partial layout");
+    if (defer_push(DeferDesc{kDeferEncoder, partial, nparts, {gWc, gbc, gWk, gbk, gWa, gba, gEchg, gEpdg, gEpv}})) return 0;
     hipLaunchKernelGGL(encode_bwd_finalize_kernel, dim3(kEncPartial / 32), dim3(1024), 0, st, partial, nparts, gr);
     DMET_LAUNCH_CHECK("encode_bwd_finalize_kernel");
     return 0;

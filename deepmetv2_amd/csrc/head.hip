@@ -524,6 +524,8 @@ extern "C" int dmet_head_bwd_f32(const float *emb, int64_t N, const float *W1, c
         hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)(nw / kHeadWaves)), dim3(64 * kHeadWaves), 0, st, emb, N, W1, b1, W2,
                            out, g_out, npw, g_emb, partial);
     DMET_LAUNCH_CHECK("head_bwd_kernel");
+    static_assert(kHeadPartial == kHeadPartialFloats && kHid == 16 && kHin == 32, "csrc/finalize.hip sums the same partial layout");
+    if (defer_push(DeferDesc{kDeferHead, partial, nw / kHeadWaves, {gW1, gb1, gW2, gb2}})) return 0;
     hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3(kHeadPartial / 32), dim3(1024), 0, st, partial, nw / kHeadWaves, gW1, gb1, gW2, gb2);
     DMET_LAUNCH_CHECK("head_bwd_finalize_kernel");
     return 0;

@@ -851,7 +851,15 @@ struct KnnFilterArgs {
     float *rP, *rQ;
     int r_sliced;               // layout: 0 row-major fp32, 1 slice-major fp32, 2 row-major with Q as bf16 bits
     int first_rider;
+    int no_rerank;              // 1: knn_rerank_kernel is not launched (dmet_knn_size_hint: no first-form event); a first-form
+                                // tail item that shows up anyway hands its queries to the exact kernel
 };
+
+// What the caller knows about the event sizes of the NEXT build on this thread (dmet_knn_size_hint; 0 = unknown).
+struct KnnSizeHint {
+    int min_nodes = 0, max_nodes = 0;
+};
+thread_local KnnSizeHint g_size_hint;
 
 // The dense layer a build may carry (set by dmet_knn_local_dense_f32 around its call of the build on this thread).
 struct KnnRider {
@@ -1483,6 +1491,10 @@ __device__ __forceinline__ void filter1_wave(const KnnFilterArgs &a, FilterQueue
         return;
     }
     // ---- split (tail) items: hand the partial list to knn_rerank_kernel, which merges the sub-sweeps ---------------
+    if (a.no_rerank) {   // the caller's size hint ruled this event out and the merge launch was dropped: exact path
+        if (valid && sub == 0) flag_query(a, myq, a.xtile_ptr[pos] + (myq - ev_lo) / a.xtile_queries);
+        return;
+    }
     if (valid) {
         const int64_t slot = (int64_t)(tile - n_full) * kFQ + hh * 32 + col;
         float *ld = a.psd + (slot * nsub + sub) * MS;
@@ -1927,6 +1939,9 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
         return j;
     };
     const float4 *x4 = reinterpret_cast<const float4 *>(a.x);
+#ifdef DMET_RR_PRIO
+    __builtin_amdgcn_s_setprio(DMET_RR_PRIO);   // experiment: the latency-bound phase issues ahead of the other wavefront's sweep
+#endif
     if constexpr (NH != 1) {
         // D = 64: every lane fetches the row of its own candidate (sixteen 16-byte loads in flight) and runs the chain
         // on it -- none of the cooperative staging of the 32-wide form below, whose register budget (three rounds of
@@ -1960,6 +1975,25 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
     // rows are fetched half a row at a time (16 features = 64 bytes): load instruction 4 h + r brings half h of rows
     // 16 r + (lane >> 2), 16 bytes per lane; exhausted lanes re-read the event's first row (no branches, result unused)
     struct HalfRows { float4 v0, v1, v2, v3, v4, v5, v6, v7; };   // named members: stays in registers
+#ifdef DMET_RR_FULLROW
+    // experiment: one load instruction brings 8 WHOLE rows (8 lanes x 16 bytes = one 128-byte line per row) instead of 16
+    // half rows -- half the line look-ups per round
+    auto fetch = [&](int32_t j) __attribute__((always_inline)) -> HalfRows {
+        const int32_t jc = j >= 0 ? j : ev_lo;
+        const int64_t o = lane & 7;
+        const int sub = lane >> 3;
+        HalfRows R;
+        R.v0 = x4[(int64_t)__shfl(jc, 0 + sub, 64) * 8 + o];
+        R.v1 = x4[(int64_t)__shfl(jc, 8 + sub, 64) * 8 + o];
+        R.v2 = x4[(int64_t)__shfl(jc, 16 + sub, 64) * 8 + o];
+        R.v3 = x4[(int64_t)__shfl(jc, 24 + sub, 64) * 8 + o];
+        R.v4 = x4[(int64_t)__shfl(jc, 32 + sub, 64) * 8 + o];
+        R.v5 = x4[(int64_t)__shfl(jc, 40 + sub, 64) * 8 + o];
+        R.v6 = x4[(int64_t)__shfl(jc, 48 + sub, 64) * 8 + o];
+        R.v7 = x4[(int64_t)__shfl(jc, 56 + sub, 64) * 8 + o];
+        return R;
+    };
+#else
     auto fetch = [&](int32_t j) __attribute__((always_inline)) -> HalfRows {
         const int32_t jc = j >= 0 ? j : ev_lo;
         const int64_t o = 4 * 0 + (lane & 3);
@@ -1972,6 +2006,7 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
         R.v4 = x4[r0 + 4]; R.v5 = x4[r1 + 4]; R.v6 = x4[r2 + 4]; R.v7 = x4[r3 + 4];
         return R;
     };
+#endif
     auto chain16 = [&](float dc, int h) __attribute__((always_inline)) -> float {
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
@@ -1986,6 +2021,25 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
         return dc;
     };
     auto round = [&](const HalfRows &R, int32_t j) __attribute__((always_inline)) {
+#ifdef DMET_RR_FULLROW
+        float4 *dst = reinterpret_cast<float4 *>(&S.rows[lane >> 3][4 * (lane & 3)]);   // + 8 r rows per register
+        constexpr int kS8 = 8 * (kF2RowF + 4) / 4;                                        // float4s per 8 rows
+        const bool lowhalf = (lane & 4) == 0;
+        wave_sync();
+        if (lowhalf) {
+            dst[0] = R.v0; dst[kS8] = R.v1; dst[2 * kS8] = R.v2; dst[3 * kS8] = R.v3;
+            dst[4 * kS8] = R.v4; dst[5 * kS8] = R.v5; dst[6 * kS8] = R.v6; dst[7 * kS8] = R.v7;
+        }
+        wave_sync();
+        float dc = chain16(0.0f, 0);
+        wave_sync();
+        if (!lowhalf) {
+            dst[0] = R.v0; dst[kS8] = R.v1; dst[2 * kS8] = R.v2; dst[3 * kS8] = R.v3;
+            dst[4 * kS8] = R.v4; dst[5 * kS8] = R.v5; dst[6 * kS8] = R.v6; dst[7 * kS8] = R.v7;
+        }
+        wave_sync();
+        dc = chain16(dc, 1);
+#else
         float4 *dst = reinterpret_cast<float4 *>(&S.rows[lane >> 2][4 * (lane & 3)]);   // + 16 r rows per register
         constexpr int kStride = 16 * (kF2RowF + 4) / 4;                                    // float4s per 16 rows
         wave_sync();
@@ -1996,6 +2050,7 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
         dst[0] = R.v4; dst[kStride] = R.v5; dst[2 * kStride] = R.v6; dst[3 * kStride] = R.v7;
         wave_sync();
         dc = chain16(dc, 1);
+#endif
         const unsigned long long nk =
             j >= 0 ? (((unsigned long long)__float_as_uint(dc) << 32) | (unsigned)j) : ~0ull;
         bool g[KP];
@@ -2036,6 +2091,9 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
         }
     }
     }
+#ifdef DMET_RR_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     float kd[KP];
     int32_t kj[KP];
 #pragma unroll
@@ -2499,6 +2557,7 @@ int launch_filter(const KnnFilterArgs &f, const KnnWorkspace &w, int simds, cons
     // only the split tail tiles (fewer than `slots`) need the separate re-rank: whole sweeps re-rank in place
     const int64_t tail_max = ftiles_max < slots ? ftiles_max : slots;
     if constexpr (NH == 1) {    // tail tiles of the first form (32 features only)
+        if (f.no_rerank) return 0;     // no first-form event in this batch (size hint): nothing to merge
         hipLaunchKernelGGL((knn_rerank_kernel<KF>), dim3((unsigned)(tail_max * kRerankParts)), dim3(256), 0, st, f);
         DMET_LAUNCH_CHECK("knn_rerank_kernel");
     }
@@ -2536,7 +2595,10 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     if (use_filter) {
         KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.rec, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
                         w.psd, w.psj, nbr, dist, nbr16, w.flags, w.any, w.qflag, w.qlist, w.tile_ptr, QT, filter_form2(),
-                        NH == 1 ? 1.0f : 1.5f, nullptr, nullptr, nullptr, nullptr, 0, 0};
+                        NH == 1 ? 1.0f : 1.5f, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+        // every event is a second-form event (the caller says so): the first form's tail merge has nothing to do
+        f.no_rerank = (f.form2 && g_size_hint.min_nodes >= kF2MinNodes && g_size_hint.max_nodes >= g_size_hint.min_nodes &&
+                       g_size_hint.max_nodes <= kF2MaxNodes) ? 1 : 0;
         int rc = 0;
         if constexpr (DP == 32 || DP == 64) {
             if constexpr (KP == 8) rc = launch_filter<8, NH>(f, w, simds, px, pf, st);
@@ -2920,6 +2982,7 @@ extern "C" size_t dmet_knn_workspace_bytes(int64_t N, int B, int D, int k)
 extern "C" int dmet_knn_local_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,
                                   float *dist, uint16_t *nbr16, void *ws, size_t ws_bytes, dmet_stream_t stream)
 {
+    struct HintScope { ~HintScope() { g_size_hint = KnnSizeHint{}; } } hint_scope;   // the hint describes one batch: it is spent by one build, whatever the outcome
     DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647 - 4096, "dmet_knn_f32/dmet_knn_local_f32: N=%lld out of range", (long long)N);
     DMET_REQUIRE(B >= 0, "dmet_knn_f32/dmet_knn_local_f32: B=%d", B);
     DMET_REQUIRE(k >= 1 && k <= DMET_MAX_K, "dmet_knn_f32/dmet_knn_local_f32: k=%d not in [1,%d]", k, DMET_MAX_K);
@@ -2929,11 +2992,21 @@ extern "C" int dmet_knn_local_f32(const float *x, const int64_t *ptr, int B, int
     DMET_REQUIRE(ws_bytes >= dmet_knn_workspace_bytes(N, B, D, k), "dmet_knn_f32/dmet_knn_local_f32: workspace too small");
     DMET_REQUIRE(!nbr16 || (reinterpret_cast<uintptr_t>(nbr16) & 3u) == 0, "dmet_knn_local_f32: nbr_local must be 4-byte aligned");
     hipStream_t st = as_stream(stream);
-    if (D <= 4) return dispatch_k<4>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
-    if (D <= 8) return dispatch_k<8>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
-    if (D <= 16) return dispatch_k<16>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
-    if (D <= 32) return dispatch_k<32>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
-    return dispatch_k<64>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
+    int rc;
+    if (D <= 4) rc = dispatch_k<4>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
+    else if (D <= 8) rc = dispatch_k<8>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
+    else if (D <= 16) rc = dispatch_k<16>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
+    else if (D <= 32) rc = dispatch_k<32>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
+    else rc = dispatch_k<64>(x, ptr, B, N, D, k, nbr, dist, nbr16, ws, st);
+    return rc;
+}
+
+extern "C" int dmet_knn_size_hint(int min_nodes, int max_nodes)
+{
+    DMET_REQUIRE(min_nodes >= 0 && max_nodes >= 0, "dmet_knn_size_hint: negative size");
+    g_size_hint.min_nodes = min_nodes;
+    g_size_hint.max_nodes = max_nodes;
+    return 0;
 }
 
 extern "C" int dmet_knn_local_dense_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, int k, int32_t *nbr,

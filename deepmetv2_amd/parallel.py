@@ -81,7 +81,10 @@ class FlatModule:
             p.grad = None
 
     def gather_grads(self) -> None:
-        """flat_grad <- the parameters' gradients of the last backward (zeros where a parameter got none)."""
+        """flat_grad <- the parameters' gradients of the last backward (zeros where a parameter got none).  Weight-gradient
+        sums that the backward pass left queued (`_native.finalize_defer_begin`) are formed first, in one launch."""
+        from . import _native
+        _native.finalize_flush()
         pairs = [(v, p.grad) for v, p in zip(self.grad_views, self.params) if p.grad is not None]
         if len(pairs) != len(self.params):
             self.flat_param.grad.zero_()
@@ -157,8 +160,12 @@ def train_step(model: torch.nn.Module, flat: FlatModule, sync: GradSync, optimiz
     x_cont, x_cat = split_features(x, lazy_cat=True)
     weights = model(x_cont, x_cat, edge_index, batch)
     loss = loss_fn(weights, x, y, batch, ptr=ptr)
-    loss.backward(sync.loss_seed(loss))
-    flat.gather_grads()
+    from . import _native
+    _native.finalize_defer_begin()       # the weight-gradient sums of the whole pass: one launch inside gather_grads
+    try:
+        loss.backward(sync.loss_seed(loss))
+    finally:
+        flat.gather_grads()
     sync.average_gradients()
     optimizer.step()
     return loss.detach()
@@ -185,8 +192,12 @@ class GraphedTrainStep:
             x_cont, x_cat = split_features(self.x, lazy_cat=True)
             graph = graph_fn(self.x) if graph_fn is not None else None
             loss = loss_fn(model(x_cont, x_cat, graph, self.batch), self.x, self.y, self.batch, ptr=self.ptr)
-            loss.backward(sync.loss_seed(loss))
-            flat.gather_grads()
+            from . import _native
+            _native.finalize_defer_begin()
+            try:
+                loss.backward(sync.loss_seed(loss))
+            finally:
+                flat.gather_grads()
             return loss.detach()
 
         side = torch.cuda.Stream()

@@ -84,6 +84,13 @@ int dmet_bn_knn_local_dense_f32(const float *raw, const float *residual, const f
                                 const float *bias, int layout, float *P, void *Q, int *dense_done, int *fused, void *ws,
                                 size_t ws_bytes, dmet_stream_t stream);
 
+/* What the caller knows about the event sizes of the NEXT dmet_knn*_f32 call on this thread (a data loader has the sizes
+ * on the host; ptr lives on the device): every event of that batch has min_nodes .. max_nodes nodes; 0 = unknown.  The
+ * hint is spent by that one call.  Today it saves one launch: when every event takes the second filter form (800 ..
+ * 65536 nodes) the merge launch of the first form's tail items is dropped.  A hint that is WRONG costs time, never
+ * results: an event the hint ruled out sends the queries concerned through the exact kernel. */
+int dmet_knn_size_hint(int min_nodes, int max_nodes);
+
 /* Diagnostics of the matrix-core kNN path (D = 32 or 64, k <= 20): dmet_knn_f32 first ranks candidates with an MFMA
  * filter (fp16 operands for events of 800..65536 nodes, a bf16 split for smaller ones), re-ranks the kept ones with
  * the exact R1 chain and certifies every query; uncertified queries are recomputed exactly (one workgroup per query
@@ -486,6 +493,20 @@ size_t dmet_head_bwd_workspace_bytes(int64_t N);
 int dmet_head_bwd_f32(const float *emb, int64_t N, const float *W1, const float *b1, const float *W2, const float *out,
                       const float *g_out, float *g_emb, float *gW1, float *gb1, float *gW2, float *gb2, void *ws,
                       size_t ws_bytes, dmet_stream_t stream);
+
+/* ---- K5 / N3: the weight-gradient sums of a whole backward pass in one launch -----------------------------------
+ * train.py:51-52 (`loss.backward(); optimizer.step()`): dmet_edgeconv_linear_bwd*_f32, dmet_encode_bwd_f32 /
+ * dmet_encode_bn_bwd_f32 and dmet_head_bwd_f32 each end in a small second launch that adds the per-workgroup partials
+ * of their parameter gradients in a fixed order; only the optimizer reads the results.  After
+ * dmet_finalize_defer_begin() those calls -- from ANY thread of the process: an autograd engine runs them on a thread of
+ * its own -- queue that step instead of launching it -- up to 8; a ninth
+ * launches its own as before -- and dmet_finalize_flush(stream) forms every queued sum in ONE launch (the same
+ * additions in the same order: same bits) and ends the deferral.  Contract: the gradient outputs and the workspaces of
+ * the queued calls must stay allocated and untouched until the flush has been enqueued on the same stream; the outputs
+ * hold garbage before it.  dmet_finalize_pending(): queued steps, -1 outside a deferral. */
+int dmet_finalize_defer_begin(void);
+int dmet_finalize_pending(void);
+int dmet_finalize_flush(dmet_stream_t stream);
 
 #ifdef __cplusplus
 }

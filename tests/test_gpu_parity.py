@@ -1561,3 +1561,75 @@ def test_static_model_with_transform_in_the_dense_layer_matches_unfused(dev, mon
             monkeypatch.setenv("DMET_BN_NLS_FUSE", fuse)
             ev.append(model(*split_features(x), graph(), batch).clone())
     assert torch.equal(ev[0], ev[1])
+
+
+def test_deferred_weight_gradient_sums_same_bits(dev, monkeypatch):
+    """K5 / N3 (train.py:51-52): with the weight-gradient sums of the EdgeConv dense layers, the encoder and the head left
+    to ONE launch at the end of the backward pass (dmet_finalize_defer_begin / dmet_finalize_flush, what train_step does)
+    every parameter gradient, the loss and the updated parameters carry the bits of the per-call sums -- and four calls
+    were really queued."""
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import _lib, _native, synth
+    from deepmetv2_amd.model import Net
+    from deepmetv2_amd.optim import FlatAdamW
+    from deepmetv2_amd.parallel import FlatModule, GradSync, train_step
+    sizes = [900, 70, 1300, 33]
+    x, y, batch, ptr = synth.make_events(sizes, seed=11, device=dev)
+    dm.register_batch(batch, ptr, len(sizes), max_nodes=max(sizes), min_nodes=min(sizes))
+    queued = []
+    real_flush = _native.finalize_flush
+
+    def counting_flush():
+        queued.append(_lib.load().dmet_finalize_pending())
+        real_flush()
+
+    monkeypatch.setattr(_native, "finalize_flush", counting_flush)
+    results = []
+    for defer in (False, True):
+        monkeypatch.setattr(_native, "DEFER_FINALIZE", defer)
+        torch.manual_seed(3)
+        model = Net(8, 3, graph="dynamic", k=16).to(dev).train()
+        flat = FlatModule(model); sync = GradSync(flat)
+        opt = FlatAdamW([flat.flat_param], lr=1e-3)
+        losses = [float(train_step(model, flat, sync, opt, x, y, batch, ptr)) for _ in range(3)]
+        results.append((losses, flat.flat_grad.detach().clone(), flat.flat_param.detach().clone()))
+    (l0, g0, p0), (l1, g1, p1) = results
+    assert l0 == l1 and torch.equal(g0, g1) and torch.equal(p0, p1)
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    assert queued == [-1, -1, -1, 4, 4, 4]     # two EdgeConv layers, the encoder, the head; nothing queued without the deferral
+    assert _lib.load().dmet_finalize_pending() == -1
+
+
+def test_knn_size_hint_right_and_wrong(dev):
+    """K1: dmet_knn_size_hint drops the merge launch of the first filter form's tail items when the caller says every event
+    takes the second form.  A RIGHT hint changes no bit; a WRONG one (small events present after all) costs time only:
+    their tail queries go through the exact kernel and the table still equals the oracle's."""
+    from deepmetv2_amd import _native
+    from oracle import ref_ops
+    k = 16
+    # (a) every event >= 800 nodes
+    x, _b, ptr = _ragged([900, 1500, 810], 32, seed=41)
+    ref = ref_ops.knn_table(x, ptr, k)
+    _native.knn_size_hint(810, 1500)
+    nbr, dist, st = _knn_with_stats(x.to(dev), ptr.to(dev), k)
+    assert torch.equal(nbr, ref[0]) and torch.equal(dist, ref[1]) and st["flagged_queries"] == 0
+    # the hint is spent: the next build (first-form events) is an ordinary one
+    x2, _b2, ptr2 = _ragged([300, 120, 500], 32, seed=42)
+    ref2 = ref_ops.knn_table(x2, ptr2, k)
+    nbr2, dist2, st2 = _knn_with_stats(x2.to(dev), ptr2.to(dev), k)
+    assert torch.equal(nbr2, ref2[0]) and torch.equal(dist2, ref2[1]) and st2["flagged_queries"] == 0
+    # (b) a hint that rules out events that are there: 12 first-form events in the split tail of a batch of 30 x 4500
+    # (2 130 whole-sweep tiles + 120 tiles of the small events: more than the 2 048 wavefront slots)
+    sizes = [4500] * 30 + [600] * 12
+    x3, _b3, ptr3 = _ragged(sizes, 32, seed=43)
+    xd, pd = x3.to(dev), ptr3.to(dev)
+    nbr_a, dist_a, st_a = _knn_with_stats(xd, pd, k)
+    assert st_a["flagged_queries"] == 0
+    _native.knn_size_hint(800, 4500)
+    nbr_b, dist_b, st_b = _knn_with_stats(xd, pd, k)
+    assert torch.equal(nbr_a, nbr_b) and torch.equal(dist_a, dist_b)
+    lo = 30 * 4500
+    ref3 = ref_ops.knn_table(x3[lo:], ptr3[30:] - lo, k)         # the small events against the oracle
+    assert torch.equal(nbr_b[lo:] - lo, ref3[0]) and torch.equal(dist_b[lo:], ref3[1])
+    if os.environ.get("DMET_KNN_PATH") != "exact" and os.environ.get("DMET_KNN_FILTER") != "0":
+        assert st_b["flagged_queries"] > 0   # the tail items of the small events took the exact path instead of the merge
