@@ -89,6 +89,9 @@ SIGNATURES = {
     "dmet_gather_max_bwd_lds16_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp]),
     "dmet_gather_max_bwd_lds16_cap_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _i64, _vp]),
     "dmet_gather_max_bwd_j16_cap_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _i64, _vp]),
+    "dmet_gather_max_bwd_sliced_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _i64, _vp]),
+    "dmet_gather_max_bwd_j16_sliced_f32": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _i64, _vp]),
+    "dmet_edgeconv_linear_bwd_sliced_f32": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_edgeconv_linear_bwd_workspace_bytes": (_sz, [_i64, _i]),
     "dmet_edgeconv_linear_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dmet_edgeconv_linear_bwd_add_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

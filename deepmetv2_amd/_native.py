@@ -523,20 +523,24 @@ def gather_max_local_j16(P: torch.Tensor, Q: torch.Tensor, rows16: torch.Tensor,
 
 
 def gather_max_bwd_j16(g_out: torch.Tensor, argj: torch.Tensor, ptr: torch.Tensor,
-                       max_nodes: Optional[int] = None) -> torch.Tensor:
-    """max_nodes: the batch's largest event when the caller knows it (a hint: workgroups sized for small events)."""
+                       max_nodes: Optional[int] = None, sliced: bool = False) -> torch.Tensor:
+    """max_nodes: the batch's largest event when the caller knows it (a hint: workgroups sized for small events).
+    sliced: gQ comes back slice-major, [8, N, 4] (for edgeconv_linear_bwd(..., gq_sliced=True): a scatter workgroup then
+    writes one contiguous run instead of 16-byte pieces of 128-byte rows)."""
     dev = _require_device(g_out, argj, ptr)
     L = _lib.load()
     g_out = _f32c(g_out, "g_out")
     N, H = g_out.shape
     if argj.dtype != torch.int16 or argj.shape != g_out.shape or not argj.is_contiguous():
         raise TypeError("gather_max_bwd_j16: argj must be the contiguous int16 [N,H] tensor of gather_max_counted_j16")
-    gQ = torch.empty((N, H), dtype=torch.float32, device=dev)
+    sliced = bool(sliced and H == 32)
+    gQ = torch.empty((8, N, 4) if sliced else (N, H), dtype=torch.float32, device=dev)
     _t = timer.record('gather_max_bwd', dev)
     with _on(dev):
-        _lib.check(L.dmet_gather_max_bwd_j16_cap_f32(g_out.data_ptr(), argj.data_ptr(), ptr.data_ptr(), ptr.numel() - 1, N, H,
-                                                     gQ.data_ptr(), int(max_nodes or 0), _stream(dev)),
-                   "dmet_gather_max_bwd_j16_cap_f32")
+        entry = L.dmet_gather_max_bwd_j16_sliced_f32 if sliced else L.dmet_gather_max_bwd_j16_cap_f32
+        _lib.check(entry(g_out.data_ptr(), argj.data_ptr(), ptr.data_ptr(), ptr.numel() - 1, N, H,
+                         gQ.data_ptr(), int(max_nodes or 0), _stream(dev)),
+                   "dmet_gather_max_bwd_j16_sliced_f32" if sliced else "dmet_gather_max_bwd_j16_cap_f32")
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))
     return gQ
@@ -1143,7 +1147,8 @@ def bn_bwd(x: torch.Tensor, g_y: torch.Tensor, gamma: torch.Tensor, save_mean: t
 
 
 def edgeconv_linear_bwd(x: torch.Tensor, weight: torch.Tensor, g_out: torch.Tensor, arg: Optional[torch.Tensor],
-                        gQ: torch.Tensor, want_bias: bool = True, g_add: Optional[torch.Tensor] = None):
+                        gQ: torch.Tensor, want_bias: bool = True, g_add: Optional[torch.Tensor] = None,
+                        gq_sliced: bool = False):
     """(gx[N,32], gW[32,64], gb[32] or None) of the fused EdgeConv dense layer (H = 32) from g_out, arg and gQ;
     g_add[N,32] (optional) is added to gx inside the kernel (the residual branch's gradient).  arg: uint8 winning slots
     (255 = none) or uint16 winner ids (0xFFFF = none): g_out is masked to 0 there (R3: such a node produced 0)."""
@@ -1151,8 +1156,9 @@ def edgeconv_linear_bwd(x: torch.Tensor, weight: torch.Tensor, g_out: torch.Tens
     L = _lib.load()
     x = _f32c(x, "x"); weight = _f32c(weight, "weight"); g_out = _f32c(g_out, "g_out"); gQ = _f32c(gQ, "gQ")
     N, H = x.shape
-    if H != 32 or tuple(weight.shape) != (32, 64) or g_out.shape != x.shape or gQ.shape != x.shape:
-        raise ValueError("edgeconv_linear_bwd: built for x[N,32], weight[32,64]")
+    if H != 32 or tuple(weight.shape) != (32, 64) or g_out.shape != x.shape or (
+            tuple(gQ.shape) != ((8, N, 4) if gq_sliced else (N, H))):
+        raise ValueError("edgeconv_linear_bwd: built for x[N,32], weight[32,64], gQ[N,32] (or slice-major [8,N,4])")
     if arg is not None and (arg.dtype not in (torch.uint8, torch.uint16, torch.int16) or arg.shape != x.shape
                             or not arg.is_contiguous()):
         raise ValueError("edgeconv_linear_bwd: arg must be contiguous uint8 (slots) or uint16 (winner ids) [N,32]")
@@ -1166,22 +1172,32 @@ def edgeconv_linear_bwd(x: torch.Tensor, weight: torch.Tensor, g_out: torch.Tens
             g_add = _f32c(g_add, "g_add")
             if g_add.shape != x.shape:
                 raise ValueError("edgeconv_linear_bwd: g_add must have the shape of x")
-        entry = L.dmet_edgeconv_linear_bwd_add_j16_f32 if j16 else L.dmet_edgeconv_linear_bwd_add_f32
-        _lib.check(entry(x.data_ptr(), weight.data_ptr(), g_out.data_ptr(),
-                         arg.data_ptr() if arg is not None else None, gQ.data_ptr(),
-                         g_add.data_ptr() if g_add is not None else None, N, H,
-                         gx.data_ptr(), gW.data_ptr(),
-                         gb.data_ptr() if gb is not None else None,
-                         ws.data_ptr(), ws.numel(), _stream(dev)),
-                   "dmet_edgeconv_linear_bwd_add_j16_f32" if j16 else "dmet_edgeconv_linear_bwd_add_f32")
+        if gq_sliced:
+            _lib.check(L.dmet_edgeconv_linear_bwd_sliced_f32(x.data_ptr(), weight.data_ptr(), g_out.data_ptr(),
+                                                             arg.data_ptr() if arg is not None else None, int(j16), gQ.data_ptr(),
+                                                             g_add.data_ptr() if g_add is not None else None, N, H,
+                                                             gx.data_ptr(), gW.data_ptr(), gb.data_ptr() if gb is not None else None,
+                                                             ws.data_ptr(), ws.numel(), _stream(dev)),
+                       "dmet_edgeconv_linear_bwd_sliced_f32")
+        else:
+            entry = L.dmet_edgeconv_linear_bwd_add_j16_f32 if j16 else L.dmet_edgeconv_linear_bwd_add_f32
+            _lib.check(entry(x.data_ptr(), weight.data_ptr(), g_out.data_ptr(),
+                             arg.data_ptr() if arg is not None else None, gQ.data_ptr(),
+                             g_add.data_ptr() if g_add is not None else None, N, H,
+                             gx.data_ptr(), gW.data_ptr(),
+                             gb.data_ptr() if gb is not None else None,
+                             ws.data_ptr(), ws.numel(), _stream(dev)),
+                       "dmet_edgeconv_linear_bwd_add_j16_f32" if j16 else "dmet_edgeconv_linear_bwd_add_f32")
         _defer_keep(dev, ws)
     return gx, gW, gb
 
 
 def gather_max_bwd_lds(g_out: torch.Tensor, arg: torch.Tensor, nbr: torch.Tensor, ptr: torch.Tensor,
-                       nbr_local: Optional[torch.Tensor] = None, max_nodes: Optional[int] = None) -> torch.Tensor:
+                       nbr_local: Optional[torch.Tensor] = None, max_nodes: Optional[int] = None,
+                       sliced: bool = False) -> torch.Tensor:
     """gQ[N,32] by per-event LDS scatter with exact integer sums (no reverse index); see include/dmet.h.
-    max_nodes: the batch's largest event when the caller knows it (a hint: workgroups sized for small events)."""
+    max_nodes: the batch's largest event when the caller knows it (a hint: workgroups sized for small events).
+    sliced: gQ comes back slice-major, [8, N, 4] (for edgeconv_linear_bwd(..., gq_sliced=True))."""
     dev = _require_device(g_out, arg, nbr, ptr)
     L = _lib.load()
     g_out = _f32c(g_out, "g_out")
@@ -1189,17 +1205,19 @@ def gather_max_bwd_lds(g_out: torch.Tensor, arg: torch.Tensor, nbr: torch.Tensor
     if arg.dtype != torch.uint8 or not arg.is_contiguous() or nbr.dtype != torch.int32 or not nbr.is_contiguous():
         raise TypeError("gather_max_bwd_lds: arg must be contiguous uint8, nbr contiguous int32")
     B = ptr.numel() - 1
-    gQ = torch.empty((N, H), dtype=torch.float32, device=dev)
+    sliced = bool(sliced and H == 32)
+    gQ = torch.empty((8, N, 4) if sliced else (N, H), dtype=torch.float32, device=dev)
     _t = timer.record('gather_max_bwd', dev)
     with _on(dev):
         if nbr_local is not None and (nbr_local.shape != nbr.shape or nbr_local.dtype != torch.int16
                                       or not nbr_local.is_contiguous()):
             raise ValueError("nbr_local must be the contiguous int16 [N, k] table of knn_local()")
-        _lib.check(L.dmet_gather_max_bwd_lds16_cap_f32(g_out.data_ptr(), arg.data_ptr(), nbr.data_ptr(),
-                                                       nbr_local.data_ptr() if nbr_local is not None else None,
-                                                       ptr.data_ptr(), B, N, nbr.shape[1], H, gQ.data_ptr(),
-                                                       int(max_nodes or 0), _stream(dev)),
-                   "dmet_gather_max_bwd_lds16_cap_f32")
+        entry = L.dmet_gather_max_bwd_sliced_f32 if sliced else L.dmet_gather_max_bwd_lds16_cap_f32
+        _lib.check(entry(g_out.data_ptr(), arg.data_ptr(), nbr.data_ptr(),
+                         nbr_local.data_ptr() if nbr_local is not None else None,
+                         ptr.data_ptr(), B, N, nbr.shape[1], H, gQ.data_ptr(),
+                         int(max_nodes or 0), _stream(dev)),
+                   "dmet_gather_max_bwd_sliced_f32" if sliced else "dmet_gather_max_bwd_lds16_cap_f32")
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))
     return gQ

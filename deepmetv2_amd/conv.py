@@ -152,23 +152,27 @@ class _EdgeConvLinearMax(torch.autograd.Function):
         table: NeighborTable = ctx.table
         H = x.shape[1]
         g_out = g_out.contiguous()
+        # the node-level kernel below takes gQ slice-major: the scatter then writes contiguous runs (DMET_GQ_SLICED=0: row-major)
+        fused_node = H == 32 and tuple(weight.shape) == (32, 64) and g_out.dtype == torch.float32
+        gqs = fused_node and os.environ.get("DMET_GQ_SLICED", "1") != "0"
         if ctx.j16:
             # arg holds the winners' event-local ids.  A row can still be empty although the table has self loops: a
             # query with a NaN / inf coordinate finds nobody, not even itself (0xFFFF, output 0 by R3) -- the node-level
             # kernel masks g_out there from the same ids (dmet_edgeconv_linear_bwd_add_j16_f32)
-            gQ = _native.gather_max_bwd_j16(g_out, arg, table.ptr, max_nodes=table.max_nodes)
+            gQ = _native.gather_max_bwd_j16(g_out, arg, table.ptr, max_nodes=table.max_nodes, sliced=gqs)
         elif H == 32 and g_out.dtype == torch.float32 and table.ptr is not None and GATHER_BWD_FORM != "reverse":
             # per-event LDS scatter with exact integer sums: no reverse index (radix sort) needed
             gQ = _native.gather_max_bwd_lds(g_out, arg, table.nbr, table.ptr, nbr_local=table.nbr_local,
-                                            max_nodes=table.max_nodes)
+                                            max_nodes=table.max_nodes, sliced=gqs)
         else:
+            gqs = False
             rev_ptr, rev_pos = table.reverse()
             gQ = _native.gather_max_bwd(g_out, arg, rev_ptr, rev_pos, table.k)
-        if H == 32 and tuple(weight.shape) == (32, 64) and g_out.dtype == torch.float32:
+        if fused_node:
             # one pass over the rows: gx, gW and gb on the fp32 matrix cores (csrc/edgeconv_bwd.hip)
             gx, gW, gb = _native.edgeconv_linear_bwd(x, weight.detach(), g_out,
                                                      None if table.dense else arg, gQ,
-                                                     want_bias=ctx.has_bias, g_add=g_pass)
+                                                     want_bias=ctx.has_bias, g_add=g_pass, gq_sliced=gqs)
             return (gx if ctx.needs_input_grad[0] else None, gW if ctx.needs_input_grad[1] else None,
                     gb if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None, None, None)
         # nodes without any neighbour produced 0 (R3): no gradient reaches P there

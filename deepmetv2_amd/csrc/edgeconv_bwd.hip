@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd
     const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ g_out,
     const uint8_t *__restrict__ arg, const float *__restrict__ gQ, int64_t N, int64_t nodes_per_wave,
     const float *__restrict__ g_add, float *__restrict__ gx, float *__restrict__ partial,
-    int *__restrict__ /*unused: tickets of the former two-level finalize*/)
+    int gq_sliced /* gQ is slice-major [8][N][4] (dmet_gather_max_bwd_sliced_f32) instead of [N][32] */)
 {
     __shared__ float sP[kWavesPerBlock][kChunk * kPad];
     __shared__ float sQ[kWavesPerBlock][kChunk * kPad];
@@ -82,7 +82,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void edgeconv_linear_bwd
             uint2 va = make_uint2(0u, 0u);
             if (i < hi) {
                 vp = reinterpret_cast<const float4 *>(g_out + i * kH)[lp];
-                vq = reinterpret_cast<const float4 *>(gQ + i * kH)[lp];
+                vq = gq_sliced ? reinterpret_cast<const float4 *>(gQ)[(int64_t)lp * N + i]     // 8 lanes: 128 contiguous bytes either way
+                               : reinterpret_cast<const float4 *>(gQ + i * kH)[lp];
                 vx = reinterpret_cast<const float4 *>(x + i * kH)[lp];
                 if (arg) {
                     if (ARG16) va = reinterpret_cast<const uint2 *>(arg + i * kH * 2)[lp];
@@ -258,8 +259,11 @@ __global__ __launch_bounds__(THREADS) void gather_max_bwd_lds_kernel(const float
                                                                           const int32_t *__restrict__ nbr,
                                                                           const uint16_t *__restrict__ nbr16,
                                                                           const int64_t *__restrict__ ptr, int B, int k,
-                                                                          float *__restrict__ gQ)
+                                                                          float *__restrict__ gQ, int64_t gq_sliced_n)
 {
+    // gq_sliced_n = N > 0: gQ is written slice-major, [8][N][4] -- the workgroup's 4 channels of its event are ONE
+    // contiguous run (16-byte pieces of 128-byte rows otherwise: 13 of the kernel's 46 us at 64 x 4500 were the
+    // write-out of such pieces); dmet_edgeconv_linear_bwd_sliced_f32 reads that layout
     // (the names of the full-size constants, shadowed: a workgroup of THREADS threads with CELLS accumulators)
     constexpr int kBwdThreads = THREADS, kBwdCells = CELLS;
     extern __shared__ unsigned long long cells[];
@@ -345,7 +349,8 @@ __global__ __launch_bounds__(THREADS) void gather_max_bwd_lds_kernel(const float
             __syncthreads();
             for (int j = tid; j < n; j += kBwdThreads) {
                 const float2 o = make_float2((float)(long long)cells[2 * j] * inv_b, (float)(long long)cells[2 * j + 1] * inv_b);
-                *reinterpret_cast<float2 *>(gQ + (lo + j) * kH + c0 + 2 * pass) = o;
+                if (gq_sliced_n > 0) *reinterpret_cast<float2 *>(gQ + ((int64_t)slice * gq_sliced_n + lo + j) * 4 + 2 * pass) = o;
+                else *reinterpret_cast<float2 *>(gQ + (lo + j) * kH + c0 + 2 * pass) = o;
             }
         }
         return;
@@ -391,7 +396,11 @@ __global__ __launch_bounds__(THREADS) void gather_max_bwd_lds_kernel(const float
             __syncthreads();
             for (int t = tid; t < jn * CH; t += kBwdThreads) cells[t] = 0ull;
             __syncthreads();
+#if defined(DMET_BWD_ABL) && DMET_BWD_ABL == 3
+            if (m == 123.456f) {    // timing experiment: no look-up / accumulation phase at all
+#else
             if (m > 0.0f) {
+#endif
                 int u_keep = 0;
                 for (int i = tid; i < n; i += kBwdThreads, ++u_keep) {
                     const int64_t gi = lo + i;
@@ -432,24 +441,36 @@ __global__ __launch_bounds__(THREADS) void gather_max_bwd_lds_kernel(const float
                                 // |g| scale < 2^30: one v_cvt_i32_f32 (round to nearest even, like __float2ll_rn) and a
                                 // sign extension instead of the dozen instructions of a float -> int64 conversion
                                 const long long q = (long long)__float2int_rn(gs[u] * scale);
+#if defined(DMET_BWD_ABL) && DMET_BWD_ABL == 1
+                                cells[j * CH + (u - cb)] = (unsigned long long)q;       // timing experiment: plain store
+#elif defined(DMET_BWD_ABL) && DMET_BWD_ABL == 4
+                                if (q == 0x7fffffffll) cells[j * CH + (u - cb)] = (unsigned long long)q;   // timing experiment: no LDS traffic
+#else
                                 atomicAdd(&cells[j * CH + (u - cb)], (unsigned long long)q);
+#endif
                             }
                         }
                     }
                 }
             }
             __syncthreads();
+#if defined(DMET_BWD_ABL) && DMET_BWD_ABL == 2
+            if (m == 123.456f)    // timing experiment: no write-out
+#endif
             if (CH == 4) {   // one node per thread: 16-byte stores
                 for (int j = tid; j < jn; j += kBwdThreads) {
                     const unsigned long long *cj = cells + 4 * j;
                     const float4 o = make_float4((float)(long long)cj[0] * inv_scale, (float)(long long)cj[1] * inv_scale,
                                                  (float)(long long)cj[2] * inv_scale, (float)(long long)cj[3] * inv_scale);
-                    *reinterpret_cast<float4 *>(gQ + (lo + j0 + j) * kH + c0) = o;
+                    if (gq_sliced_n > 0) reinterpret_cast<float4 *>(gQ)[(int64_t)slice * gq_sliced_n + lo + j0 + j] = o;
+                    else *reinterpret_cast<float4 *>(gQ + (lo + j0 + j) * kH + c0) = o;
                 }
             } else {
                 for (int t = tid; t < jn * CH; t += kBwdThreads) {
                     const int j = t / CH, u = t - j * CH;
-                    gQ[(lo + j0 + j) * kH + c0 + cb + u] = (float)(long long)cells[t] * inv_scale;
+                    const float o1 = (float)(long long)cells[t] * inv_scale;
+                    if (gq_sliced_n > 0) gQ[((int64_t)slice * gq_sliced_n + lo + j0 + j) * 4 + cb + u] = o1;
+                    else gQ[(lo + j0 + j) * kH + c0 + cb + u] = o1;
                 }
             }
         }
@@ -471,7 +492,7 @@ extern "C" size_t dmet_edgeconv_linear_bwd_workspace_bytes(int64_t N, int H)
 
 static int ecb_launch(const float *x, const float *W, const float *g_out, const uint8_t *arg, bool arg16, const float *gQ,
                       const float *g_add, int64_t N, int H, float *gx, float *gW, float *gb, void *ws, size_t ws_bytes,
-                      dmet_stream_t stream)
+                      dmet_stream_t stream, int gq_sliced = 0)
 {
     DMET_REQUIRE(H == kH, "dmet_edgeconv_linear_bwd_f32: H=%d (only 32 is built)", H);
     DMET_REQUIRE(N > 0, "dmet_edgeconv_linear_bwd_f32: N=%lld", (long long)N);
@@ -483,15 +504,13 @@ static int ecb_launch(const float *x, const float *W, const float *g_out, const 
     int64_t nw;
     const int64_t npw = ecb_nodes_per_wave(N, &nw);
     float *partial = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u);
-    float *chunk_sums = partial + (size_t)nw * kPartial;
-    int *fin_counters = reinterpret_cast<int *>(chunk_sums + (size_t)kFinChunks * kPartial);
     hipStream_t st = as_stream(stream);
     if (arg16)
         hipLaunchKernelGGL(edgeconv_linear_bwd_kernel<true>, dim3((unsigned)(nw / kWavesPerBlock)), dim3(kWave * kWavesPerBlock),
-                           0, st, x, W, g_out, arg, gQ, N, npw, g_add, gx, partial, fin_counters);
+                           0, st, x, W, g_out, arg, gQ, N, npw, g_add, gx, partial, gq_sliced);
     else
         hipLaunchKernelGGL(edgeconv_linear_bwd_kernel<false>, dim3((unsigned)(nw / kWavesPerBlock)), dim3(kWave * kWavesPerBlock),
-                           0, st, x, W, g_out, arg, gQ, N, npw, g_add, gx, partial, fin_counters);
+                           0, st, x, W, g_out, arg, gQ, N, npw, g_add, gx, partial, gq_sliced);
     DMET_LAUNCH_CHECK("edgeconv_linear_bwd_kernel");
     static_assert(kPartial == kEcbPartialFloats && kFinGroups == 33, "csrc/finalize.hip sums the same partial layout");
     if (defer_push(DeferDesc{kDeferEdgeConv, partial, nw / kWavesPerBlock, {gW, gb}})) return 0;   // summed by dmet_finalize_flush
@@ -534,7 +553,7 @@ extern "C" int dmet_edgeconv_linear_bwd_f32(const float *x, const float *W, cons
 // 128 events of 1000 / 2000 nodes: 29.2 -> 20.3 us / 43.8 -> 35.8 us (same bits: integer sums).
 template <bool J16, int THREADS, int CELLS>
 int bwd_scatter_launch_as(const float *g_out, const uint8_t *arg, const int32_t *nbr, const uint16_t *nbr16,
-                          const int64_t *ptr, int B, int k, float *gQ, hipStream_t st)
+                          const int64_t *ptr, int B, int k, float *gQ, hipStream_t st, int64_t gq_sliced_n)
 {
     static bool attr_set = false;      // one flag per instantiation
     const size_t lds = sizeof(unsigned long long) * (size_t)CELLS;
@@ -545,20 +564,57 @@ int bwd_scatter_launch_as(const float *g_out, const uint8_t *arg, const int32_t 
         attr_set = true;
     }
     hipLaunchKernelGGL((gather_max_bwd_lds_kernel<J16, THREADS, CELLS>), dim3((unsigned)B * 8u), dim3(THREADS), lds, st, g_out,
-                       arg, nbr, nbr16, ptr, B, k, gQ);
+                       arg, nbr, nbr16, ptr, B, k, gQ, gq_sliced_n);
     DMET_LAUNCH_CHECK("gather_max_bwd_lds_kernel");
     return 0;
 }
 
 template <bool J16>
 int bwd_scatter_launch(const float *g_out, const uint8_t *arg, const int32_t *nbr, const uint16_t *nbr16,
-                       const int64_t *ptr, int B, int k, float *gQ, int64_t max_nodes, hipStream_t st)
+                       const int64_t *ptr, int B, int k, float *gQ, int64_t max_nodes, hipStream_t st, int64_t gq_sliced_n = 0)
 {
     if (max_nodes > 0 && max_nodes <= kBwdCells / 16)
-        return bwd_scatter_launch_as<J16, 256, kBwdCells / 4>(g_out, arg, nbr, nbr16, ptr, B, k, gQ, st);
+        return bwd_scatter_launch_as<J16, 256, kBwdCells / 4>(g_out, arg, nbr, nbr16, ptr, B, k, gQ, st, gq_sliced_n);
     if (max_nodes > 0 && max_nodes <= kBwdCells / 8)
-        return bwd_scatter_launch_as<J16, 512, kBwdCells / 2>(g_out, arg, nbr, nbr16, ptr, B, k, gQ, st);
-    return bwd_scatter_launch_as<J16, kBwdThreads, kBwdCells>(g_out, arg, nbr, nbr16, ptr, B, k, gQ, st);
+        return bwd_scatter_launch_as<J16, 512, kBwdCells / 2>(g_out, arg, nbr, nbr16, ptr, B, k, gQ, st, gq_sliced_n);
+    return bwd_scatter_launch_as<J16, kBwdThreads, kBwdCells>(g_out, arg, nbr, nbr16, ptr, B, k, gQ, st, gq_sliced_n);
+}
+
+// gQ slice-major, [8][N][4] floats (see the kernel): for the pair scatter -> dmet_edgeconv_linear_bwd_sliced_f32
+extern "C" int dmet_gather_max_bwd_sliced_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr,
+                                              const uint16_t *nbr_local, const int64_t *ptr, int B, int64_t N, int k, int H,
+                                              float *gQs, int64_t max_nodes, dmet_stream_t stream)
+{
+    DMET_REQUIRE(H == kH, "dmet_gather_max_bwd_sliced_f32: H=%d (only 32 is built)", H);
+    DMET_REQUIRE(N >= 0 && B >= 0 && k >= 1 && k <= 255 && max_nodes >= 0, "dmet_gather_max_bwd_sliced_f32: bad sizes");
+    if (N == 0 || B == 0) return 0;
+    DMET_REQUIRE(g_out && arg && nbr && ptr && gQs, "dmet_gather_max_bwd_sliced_f32: null pointer");
+    DMET_REQUIRE(aligned16(g_out) && aligned16(gQs) && (reinterpret_cast<uintptr_t>(arg) & 3u) == 0,
+                 "dmet_gather_max_bwd_sliced_f32: rows must be 16-byte aligned");
+    return bwd_scatter_launch<false>(g_out, arg, nbr, nbr_local, ptr, B, k, gQs, max_nodes, as_stream(stream), N);
+}
+
+extern "C" int dmet_gather_max_bwd_j16_sliced_f32(const float *g_out, const uint16_t *argj, const int64_t *ptr, int B,
+                                                  int64_t N, int H, float *gQs, int64_t max_nodes, dmet_stream_t stream)
+{
+    DMET_REQUIRE(H == kH, "dmet_gather_max_bwd_j16_sliced_f32: H=%d (only 32 is built)", H);
+    DMET_REQUIRE(N >= 0 && B >= 0 && max_nodes >= 0, "dmet_gather_max_bwd_j16_sliced_f32: bad sizes");
+    if (N == 0 || B == 0) return 0;
+    DMET_REQUIRE(g_out && argj && ptr && gQs, "dmet_gather_max_bwd_j16_sliced_f32: null pointer");
+    DMET_REQUIRE(aligned16(g_out) && aligned16(gQs) && (reinterpret_cast<uintptr_t>(argj) & 7u) == 0,
+                 "dmet_gather_max_bwd_j16_sliced_f32: rows must be 16-byte (argj: 8-byte) aligned");
+    return bwd_scatter_launch<true>(g_out, reinterpret_cast<const uint8_t *>(argj), nullptr, nullptr, ptr, B, 1, gQs, max_nodes,
+                                    as_stream(stream), N);
+}
+
+// dmet_edgeconv_linear_bwd_add_f32 / _add_j16_f32 (arg_is_j16) reading gQ in the slice-major layout those two write
+extern "C" int dmet_edgeconv_linear_bwd_sliced_f32(const float *x, const float *W, const float *g_out, const void *arg,
+                                                   int arg_is_j16, const float *gQs, const float *g_add, int64_t N, int H,
+                                                   float *gx, float *gW, float *gb, void *ws, size_t ws_bytes,
+                                                   dmet_stream_t stream)
+{
+    return ecb_launch(x, W, g_out, reinterpret_cast<const uint8_t *>(arg), arg_is_j16 != 0, gQs, g_add, N, H, gx, gW, gb, ws,
+                      ws_bytes, stream, 1);
 }
 
 extern "C" int dmet_gather_max_bwd_lds16_cap_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr,

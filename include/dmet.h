@@ -289,6 +289,19 @@ int dmet_gather_max_bwd_lds16_cap_f32(const float *g_out, const uint8_t *arg, co
                                       float *gQ, int64_t max_nodes, dmet_stream_t stream);
 int dmet_gather_max_bwd_j16_cap_f32(const float *g_out, const uint16_t *argj, const int64_t *ptr, int B, int64_t N, int H,
                                     float *gQ, int64_t max_nodes, dmet_stream_t stream);
+/* The pair scatter -> node-level kernel with gQ handed over SLICE-MAJOR, gQs[8][N][4] floats: a scatter workgroup owns 4
+ * channels of one event, so in this layout it writes ONE contiguous run instead of a 16-byte piece of every 128-byte
+ * row (13 of the scatter's 46 us at 64 x 4500 nodes were that write-out), and the node-level kernel's loads stay whole
+ * 128-byte lines either way.  Same sums, same bits; only the layout of the intermediate differs.  arg_is_j16: `arg` holds
+ * uint16 winner ids (dmet_gather_max_bwd_j16_sliced_f32) instead of uint8 slots. */
+int dmet_gather_max_bwd_sliced_f32(const float *g_out, const uint8_t *arg, const int32_t *nbr, const uint16_t *nbr_local,
+                                   const int64_t *ptr, int B, int64_t N, int k, int H, float *gQs, int64_t max_nodes,
+                                   dmet_stream_t stream);
+int dmet_gather_max_bwd_j16_sliced_f32(const float *g_out, const uint16_t *argj, const int64_t *ptr, int B, int64_t N,
+                                       int H, float *gQs, int64_t max_nodes, dmet_stream_t stream);
+int dmet_edgeconv_linear_bwd_sliced_f32(const float *x, const float *W, const float *g_out, const void *arg,
+                                        int arg_is_j16, const float *gQs, const float *g_add, int64_t N, int H, float *gx,
+                                        float *gW, float *gb, void *ws, size_t ws_bytes, dmet_stream_t stream);
 /* Reverse index: a stable sort of the positions 0..M-1 of an int32 key array by key value.
  *   rev_ptr[num_keys+1]: rev_pos[rev_ptr[j] .. rev_ptr[j+1]-1] = the positions holding key j, ascending.
  * Keys outside [0, num_keys) (the -1 "no neighbour" entries) sort last and are not indexed.

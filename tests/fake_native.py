@@ -251,8 +251,14 @@ def bn_bwd(x, g_y, gamma, mean, invstd):
     return g_x, g_w, g_b
 
 
-def edgeconv_linear_bwd(x, weight, g_out, arg, gQ, want_bias=True, g_add=None):
+def _to_sliced(gQ):     # [N,32] -> the slice-major [8,N,4] layout of dmet_gather_max_bwd_sliced_f32
+    return gQ.view(gQ.shape[0], 8, 4).permute(1, 0, 2).contiguous()
+
+
+def edgeconv_linear_bwd(x, weight, g_out, arg, gQ, want_bias=True, g_add=None, gq_sliced=False):
     H = x.shape[1]
+    if gq_sliced:
+        gQ = gQ.permute(1, 0, 2).reshape(x.shape[0], 32)
     none = 255 if (arg is not None and arg.dtype == torch.uint8) else 0xFFFF
     gP = g_out if arg is None else g_out * ((arg.long() & 0xFFFF) != none).to(g_out.dtype)
     Wd, W2 = weight[:, :H] - weight[:, H:], weight[:, H:]
@@ -264,7 +270,7 @@ def edgeconv_linear_bwd(x, weight, g_out, arg, gQ, want_bias=True, g_add=None):
     return gx, gW, (gP.sum(0) if want_bias else None)
 
 
-def gather_max_bwd_lds(g_out, arg, nbr, ptr, nbr_local=None, max_nodes=None):
+def gather_max_bwd_lds(g_out, arg, nbr, ptr, nbr_local=None, max_nodes=None, sliced=False):
     N, H = g_out.shape
     gQ = torch.zeros_like(g_out)
     a = arg.long()
@@ -272,7 +278,7 @@ def gather_max_bwd_lds(g_out, arg, nbr, ptr, nbr_local=None, max_nodes=None):
     j = torch.gather(nbr.long(), 1, a.clamp(max=nbr.shape[1] - 1))        # [N,H] winner source per channel
     cols = torch.arange(H).expand(N, H)
     gQ.index_put_((j[valid], cols[valid]), g_out[valid], accumulate=True)
-    return gQ
+    return _to_sliced(gQ) if (sliced and H == 32) else gQ
 
 
 def met_loss(met, truth):
@@ -358,7 +364,7 @@ def gather_max_local_j16(P, Q, rows16, cnt, order, ptr, kmax, sliced):
     return gather_max_counted_j16(P, Q, nbr, cnt, order, ptr, sliced)
 
 
-def gather_max_bwd_j16(g_out, argj, ptr, max_nodes=None):
+def gather_max_bwd_j16(g_out, argj, ptr, max_nodes=None, sliced=False):
     N, H = g_out.shape
     counts = (ptr[1:] - ptr[:-1]).long()
     lo = torch.repeat_interleave(ptr[:-1], counts).view(-1, 1)
@@ -368,7 +374,7 @@ def gather_max_bwd_j16(g_out, argj, ptr, max_nodes=None):
     gQ = torch.zeros_like(g_out)
     cols = torch.arange(H).expand(N, H)
     gQ.index_put_((j[valid], cols[valid]), g_out[valid], accumulate=True)
-    return gQ
+    return _to_sliced(gQ) if (sliced and H == 32) else gQ
 
 
 _NAMES = ["table_order_by_count", "gather_max_local_j16", "gather_max_counted_j16", "gather_max_bwd_j16", "table_rowptr", "table_edges", "head_fwd", "head_bwd", "met_loss", "gather_max_bwd_lds", "edgeconv_linear_bwd", "bn_fwd", "bn_bwd", "encode_fwd", "encode_bwd", "knn", "knn_local", "radius", "node_linear_split", "gather_max", "gather_max_bwd", "reverse_index", "edge_features",

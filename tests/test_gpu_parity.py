@@ -1633,3 +1633,42 @@ def test_knn_size_hint_right_and_wrong(dev):
     assert torch.equal(nbr_b[lo:] - lo, ref3[0]) and torch.equal(dist_b[lo:], ref3[1])
     if os.environ.get("DMET_KNN_PATH") != "exact" and os.environ.get("DMET_KNN_FILTER") != "0":
         assert st_b["flagged_queries"] > 0   # the tail items of the small events took the exact path instead of the merge
+
+
+@pytest.mark.parametrize("sizes", [[700, 90, 1300], [4700, 300], [9300, 40]])
+def test_backward_scatter_slice_major_handover(dev, sizes):
+    """K5: gQ handed from the LDS scatter to the node-level backward kernel slice-major ([8, N, 4]: a scatter workgroup
+    writes one contiguous run) carries the bits of the row-major hand-over -- gQ itself (re-laid out) and gx / gW / gb of
+    dmet_edgeconv_linear_bwd_sliced_f32 -- for both winner encodings and all three window forms of the scatter (events up
+    to 4 608 nodes, up to 9 216, beyond)."""
+    from deepmetv2_amd import _native
+    H, k = 32, 16
+    x, _b, ptr = _ragged(sizes, H, seed=77)
+    xd, pd = x.to(dev), ptr.to(dev)
+    N = xd.shape[0]
+    g = torch.Generator().manual_seed(5)
+    W = (torch.randn(32, 64, generator=g) / 8).to(dev)
+    g_out = torch.randn(N, H, generator=g).to(dev)
+    g_add = torch.randn(N, H, generator=g).to(dev)
+    nbr, _d, loc = _native.knn_local(xd, pd, k)
+    arg = torch.randint(0, k, (N, H), generator=g, dtype=torch.uint8).to(dev)
+    arg[::7, 3] = 255
+    # winner ids (uint16 in an int16 tensor) consistent with the slots
+    lo = torch.repeat_interleave(pd[:-1], (pd[1:] - pd[:-1])).view(-1, 1)
+    win = torch.gather(nbr.long(), 1, arg.long().clamp(max=k - 1)) - lo
+    argj = torch.where(arg == 255, torch.full_like(win, 0xFFFF), win).to(torch.int32).to(torch.int16)
+    for form in ("slots", "ids"):
+        if form == "slots":
+            a0 = _native.gather_max_bwd_lds(g_out, arg, nbr, pd, nbr_local=loc, max_nodes=max(sizes))
+            a1 = _native.gather_max_bwd_lds(g_out, arg, nbr, pd, nbr_local=loc, max_nodes=max(sizes), sliced=True)
+            argk = arg
+        else:
+            a0 = _native.gather_max_bwd_j16(g_out, argj, pd, max_nodes=max(sizes))
+            a1 = _native.gather_max_bwd_j16(g_out, argj, pd, max_nodes=max(sizes), sliced=True)
+            argk = argj
+        assert tuple(a1.shape) == (8, N, 4)
+        assert torch.equal(a1.permute(1, 0, 2).reshape(N, H), a0)
+        r0 = _native.edgeconv_linear_bwd(xd, W, g_out, argk, a0, g_add=g_add)
+        r1 = _native.edgeconv_linear_bwd(xd, W, g_out, argk, a1, g_add=g_add, gq_sliced=True)
+        for u, v in zip(r0, r1):
+            assert torch.equal(u, v)
