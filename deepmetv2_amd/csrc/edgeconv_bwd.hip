@@ -368,7 +368,11 @@ __global__ __launch_bounds__(THREADS) void gather_max_bwd_lds_kernel(const float
         for (int u = 0; u < kBwdKeep; ++u) {
             const int i = tid + u * kBwdThreads;
             gk[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#if defined(DMET_BWD_ABL) && DMET_BWD_ABL == 5      // timing experiment: g_out read as if slice-major
+            if (i < n) gk[u] = reinterpret_cast<const float4 *>(g_out)[(int64_t)slice * (gq_sliced_n > 0 ? gq_sliced_n : 288000) + lo + i];
+#else
             if (i < n) gk[u] = reinterpret_cast<const float4 *>(g_out + (lo + i) * kH + c0)[0];
+#endif
             m = fmaxf(m, fmaxf(fmaxf(fabsf(gk[u].x), fabsf(gk[u].y)), fmaxf(fabsf(gk[u].z), fabsf(gk[u].w))));
         }
     } else {
