@@ -851,6 +851,7 @@ struct KnnFilterArgs {
     float *rP, *rQ;
     int r_sliced;               // layout: 0 row-major fp32, 1 slice-major fp32, 2 row-major with Q as bf16 bits
     int first_rider;
+    int emit_coalesced;         // 1: nbr / dist / nbr16 are 16-byte aligned: whole-sweep items write their rows as 16-byte pieces
     int no_rerank;              // 1: knn_rerank_kernel is not launched (dmet_knn_size_hint: no first-form event); a first-form
                                 // tail item that shows up anyway hands its queries to the exact kernel
 };
@@ -2104,15 +2105,87 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
     const int k = a.k;
     const float tau = attempt == 0 ? L.tk[M - 1] : t_fix;
     // the query's rows of the three tables; returns its k-th distance (-1: fewer than k neighbours)
-    auto emit = [&]() __attribute__((always_inline)) -> float {
+    // coop (whole-sweep items, called by ALL lanes): the 64 queries of the item own 64 consecutive rows of each table, i.e.
+    // one contiguous block; written by the lanes themselves that is k 4-byte stores per lane and table, each instruction a
+    // 4-byte piece of 64 different lines (switching the stores off measured 22 of the build's 420 us).  The rows go through
+    // the wavefront's LDS (free by now) instead and leave as 16-byte pieces of consecutive addresses; rows_on masks the
+    // rows that are written (lanes past the event's end; the second attempt rewrites only its own queries).
+    auto emit = [&](const bool rows_on, const bool coop) __attribute__((always_inline)) -> float {
         float kth = -1.0f;
+#pragma unroll
+        for (int p = 0; p < KP; ++p)
+            if (p == k - 1 && kj[p] >= 0) kth = kd[p];
+        if constexpr (KP % 4 == 0 && KP <= 20) {
+            if (coop && a.emit_coalesced && k == KP) {
+                constexpr int RP = KP / 4;       // 16-byte pieces per row
+                const unsigned long long on = __ballot(rows_on);
+                unsigned *stg = reinterpret_cast<unsigned *>(&S);        // 64 rows x KP words <= 5 120 bytes per table
+                const int64_t blk = (int64_t)q_first * KP;               // first word of the block in nbr / dist
+                wave_sync();
+#pragma unroll
+                for (int q = 0; q < RP; ++q)
+                    *reinterpret_cast<uint4 *>(stg + lane * KP + 4 * q) =
+                        make_uint4((unsigned)kj[4 * q], (unsigned)kj[4 * q + 1], (unsigned)kj[4 * q + 2], (unsigned)kj[4 * q + 3]);
+                wave_sync();
+#pragma unroll
+                for (int t = 0; t < RP; ++t) {
+                    const int pi = t * 64 + lane;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(stg + 4 * pi);
+                    if ((on >> (pi / RP)) & 1ull) *reinterpret_cast<uint4 *>(a.nbr + blk + 4 * pi) = v;
+                }
+                wave_sync();
+#pragma unroll
+                for (int q = 0; q < RP; ++q)
+                    *reinterpret_cast<uint4 *>(stg + lane * KP + 4 * q) =
+                        make_uint4(__float_as_uint(kd[4 * q]), __float_as_uint(kd[4 * q + 1]), __float_as_uint(kd[4 * q + 2]),
+                                   __float_as_uint(kd[4 * q + 3]));
+                wave_sync();
+#pragma unroll
+                for (int t = 0; t < RP; ++t) {
+                    const int pi = t * 64 + lane;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(stg + 4 * pi);
+                    if ((on >> (pi / RP)) & 1ull) *reinterpret_cast<uint4 *>(a.dist + blk + 4 * pi) = v;
+                }
+                if (a.nbr16) {
+                    if constexpr (KP % 8 == 0) {
+                        constexpr int RH = KP / 8;   // 16-byte pieces per uint16 row
+                        wave_sync();
+#pragma unroll
+                        for (int q = 0; q < RH; ++q) {
+                            uint4 w;
+                            w.x = (unsigned)local_id16(kj[8 * q], ev_lo) | ((unsigned)local_id16(kj[8 * q + 1], ev_lo) << 16);
+                            w.y = (unsigned)local_id16(kj[8 * q + 2], ev_lo) | ((unsigned)local_id16(kj[8 * q + 3], ev_lo) << 16);
+                            w.z = (unsigned)local_id16(kj[8 * q + 4], ev_lo) | ((unsigned)local_id16(kj[8 * q + 5], ev_lo) << 16);
+                            w.w = (unsigned)local_id16(kj[8 * q + 6], ev_lo) | ((unsigned)local_id16(kj[8 * q + 7], ev_lo) << 16);
+                            *reinterpret_cast<uint4 *>(stg + lane * (KP / 2) + 4 * q) = w;
+                        }
+                        wave_sync();
+#pragma unroll
+                        for (int t = 0; t < RH; ++t) {
+                            const int pi = t * 64 + lane;
+                            const uint4 v = *reinterpret_cast<const uint4 *>(stg + 4 * pi);
+                            if ((on >> (pi / RH)) & 1ull)
+                                *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned *>(a.nbr16 + blk) + 4 * pi) = v;
+                        }
+                    } else if (rows_on) {
+                        uint16_t *r16 = a.nbr16 + (int64_t)myq * k;
+#pragma unroll
+                        for (int p = 0; p + 1 < KP; p += 2)
+                            reinterpret_cast<unsigned *>(r16)[p >> 1] =
+                                (unsigned)local_id16(kj[p], ev_lo) | ((unsigned)local_id16(kj[p + 1], ev_lo) << 16);
+                    }
+                }
+                wave_sync();       // the staging area is the next attempt's entry list
+                return kth;
+            }
+        }
+        if (!rows_on) return kth;
 #pragma unroll
         for (int p = 0; p < KP; ++p) {
             if (p < k) {
                 a.nbr[(int64_t)myq * k + p] = kj[p];
                 a.dist[(int64_t)myq * k + p] = kd[p];
             }
-            if (p == k - 1 && kj[p] >= 0) kth = kd[p];
         }
         if (a.nbr16) {
             uint16_t *r16 = a.nbr16 + (int64_t)myq * k;
@@ -2132,8 +2205,8 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
     };
     if (nsub == 1) {
         bool retry = false;
+        const float kth = emit(act, true);
         if (act) {
-            const float kth = emit();
             // certificate: every dropped candidate had key >= tau (see the header of this form).  Candidates were
             // dropped (tau below the sentinel) but fewer than k neighbours came back (kth < 0): not certified either
             const float nx = a.nrm[myq];
@@ -2210,7 +2283,7 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
             kd[p] = __uint_as_float((unsigned)(kk[p] >> 32));
             kj[p] = kd[p] == kKnnSentinel ? -1 : (int32_t)(unsigned)kk[p];
         }
-        const float kth = emit();
+        const float kth = emit(true, false);      // (inside a divergent branch: every lane writes its own rows)
         const float nx = a.nrm[myq];
         const float an = __builtin_sqrtf(nx) * 1.000001f;
         const float rn = an + __builtin_sqrtf(fmaxf(kth, 0.0f)) * 1.00002f;
@@ -2595,7 +2668,8 @@ int launch_knn(const float *x, const int64_t *ptr, int B, int64_t N, int D, int 
     if (use_filter) {
         KnnFilterArgs f{x, ptr, B, N, k, w.nrm, w.rec, w.fplan, w.forder, w.fpos_of, w.ftile_ptr,
                         w.psd, w.psj, nbr, dist, nbr16, w.flags, w.any, w.qflag, w.qlist, w.tile_ptr, QT, filter_form2(),
-                        NH == 1 ? 1.0f : 1.5f, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+                        NH == 1 ? 1.0f : 1.5f, nullptr, nullptr, nullptr, nullptr, 0, 0,
+                        (aligned16(nbr) && aligned16(dist) && aligned16(nbr16) && !env_is("DMET_KNN_EMIT", "lanes")) ? 1 : 0, 0};
         // every event is a second-form event (the caller says so): the first form's tail merge has nothing to do
         f.no_rerank = (f.form2 && g_size_hint.min_nodes >= kF2MinNodes && g_size_hint.max_nodes >= g_size_hint.min_nodes &&
                        g_size_hint.max_nodes <= kF2MaxNodes) ? 1 : 0;
