@@ -261,18 +261,20 @@ def knn_local(x: torch.Tensor, ptr: torch.Tensor, k: int, stats: Optional[dict] 
 
 
 def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int, skip_self: bool = False,
-           pad: bool = True, local: bool = False):
+           pad: bool = True, local: bool = False, int32_rows: bool = True):
     """(nbr[N,max_nbr] int32, cnt[N] int32).  pad=False leaves the slots >= cnt[i] unwritten instead of filling them
     with -1 (the fill is most of a 255-wide table's bytes); only for consumers that go by cnt.
     local=True: a third result, the rows again as event-local uint16 ids (int16-typed [N, roundup8(max_nbr)], slots
     cnt[i] .. roundup8(cnt[i]) - 1 = 0xFFFF, the rest unwritten) for gather_max_local_j16; None when the all-pairs
-    form is selected."""
+    form is selected.  int32_rows=False (with local=True, pad=False, windowed form): the int32 table is not written at all
+    and comes back as None -- for callers whose consumers read the uint16 rows (graph.NeighborTable expands them on demand)."""
     dev = _require_device(x, ptr)
     L = _lib.load()
     x = _f32c(x.detach(), "x")
     N, D = x.shape
     B = ptr.numel() - 1
-    nbr = torch.empty((N, max_nbr), dtype=torch.int32, device=dev)
+    skip32 = bool(local and not int32_rows and not pad and RADIUS_FORM != "sweep")
+    nbr = None if skip32 else torch.empty((N, max_nbr), dtype=torch.int32, device=dev)
     cnt = torch.empty((N,), dtype=torch.int32, device=dev)
     if local:
         rows16 = None
@@ -282,7 +284,8 @@ def radius(x: torch.Tensor, ptr: torch.Tensor, r: float, max_nbr: int, skip_self
             ws = _ws(L.dmet_radius_workspace_bytes(N), dev)
             with _on(dev):
                 _lib.check(L.dmet_radius_windowed_local_f32(x.data_ptr(), ptr.data_ptr(), B, N, D, float(r), max_nbr,
-                                                            1 if skip_self else 0, 1 if pad else 0, nbr.data_ptr(),
+                                                            1 if skip_self else 0, 1 if pad else 0,
+                                                            nbr.data_ptr() if nbr is not None else None,
                                                             cnt.data_ptr(), rows16.data_ptr(), stride16, ws.data_ptr(),
                                                             ws.numel(), _stream(dev)), "dmet_radius_windowed_local_f32")
             return nbr, cnt, rows16
@@ -498,8 +501,9 @@ def gather_max_counted_j16(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, 
 
 
 def gather_max_local_j16(P: torch.Tensor, Q: torch.Tensor, rows16: torch.Tensor, cnt: torch.Tensor,
-                         order: Optional[torch.Tensor], ptr: torch.Tensor, kmax: int, sliced: bool):
-    """gather_max_counted_j16 reading the ids from the uint16 rows of radius(..., local=True): identical (out, argj)."""
+                         order: Optional[torch.Tensor], ptr: torch.Tensor, kmax: int, sliced: bool, want_arg: bool = True):
+    """gather_max_counted_j16 reading the ids from the uint16 rows of radius(..., local=True): identical (out, argj);
+    want_arg=False (inference): (out, None)."""
     dev = _require_device(P, Q, rows16, cnt, ptr)
     L = _lib.load()
     if sliced:
@@ -507,7 +511,7 @@ def gather_max_local_j16(P: torch.Tensor, Q: torch.Tensor, rows16: torch.Tensor,
     else:
         N, H = P.shape
     out = torch.empty((N, H), dtype=torch.float32, device=dev)
-    argj = torch.empty((N, H), dtype=torch.int16, device=dev)
+    argj = torch.empty((N, H), dtype=torch.int16, device=dev) if want_arg else None
     _t = timer.record('gather_max', dev)
     _note_gather("gather_max_lds_kernel, counted rows (radius table as event-local uint16 rows; Q slice resident in LDS, "
                  "winner ids, rows ordered by depth" + (", slice-major P/Q)" if sliced else ")"))
@@ -515,7 +519,7 @@ def gather_max_local_j16(P: torch.Tensor, Q: torch.Tensor, rows16: torch.Tensor,
         _lib.check(L.dmet_gather_max_local_j16_f32(P.data_ptr(), Q.data_ptr(), rows16.data_ptr(), rows16.shape[1],
                                                    cnt.data_ptr(), order.data_ptr() if order is not None else None,
                                                    ptr.data_ptr(), ptr.numel() - 1, N, kmax, H, 1 if sliced else 0,
-                                                   out.data_ptr(), argj.data_ptr(), _stream(dev)),
+                                                   out.data_ptr(), argj.data_ptr() if argj is not None else None, _stream(dev)),
                    "dmet_gather_max_local_j16_f32")
     if _t is not None:
         _t.record(torch.cuda.current_stream(dev))

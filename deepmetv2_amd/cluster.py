@@ -6,6 +6,7 @@ model/dynamic_reduction_network.py:86,94 (knn_graph); train.py:48, evaluate.py:8
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -100,7 +101,10 @@ def knn(x: torch.Tensor, y: torch.Tensor, k: int, batch_x: Optional[torch.Tensor
 
 
 def radius_table(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None, loop: bool = False,
-                 max_num_neighbors: int = 32, num_events: Optional[int] = None) -> NeighborTable:
+                 max_num_neighbors: int = 32, num_events: Optional[int] = None, int32_rows: Optional[bool] = None) -> NeighborTable:
+    """The radius graph as a NeighborTable.  int32_rows=False: only the event-local uint16 rows are written (what the
+    fused EdgeConv reads on events of at most 65534 nodes); `.nbr` is expanded from them if somebody asks.  None: False
+    when the caller registered the batch's largest event (register_batch(max_nodes=) <= 65534), else True."""
     x = _check_x(x)
     if x.shape[1] > 8:
         raise ValueError("radius_graph supports up to 8 coordinates")
@@ -108,10 +112,13 @@ def radius_table(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None
     m = max_num_neighbors if loop else max_num_neighbors + 1
     info = batch_info(batch, x.shape[0], x.device, num_events)
     # no -1 fill of the unused slots: every consumer of a table with `cnt` goes by cnt
-    nbr, _cnt, rows16 = _native.radius(x, info.ptr, r, m, skip_self=not loop, pad=False, local=True)
+    if int32_rows is None:
+        int32_rows = not (info.max_nodes is not None and info.max_nodes <= 65534
+                          and os.environ.get("DMET_RADIUS_INT32", "lazy") == "lazy")
+    nbr, _cnt, rows16 = _native.radius(x, info.ptr, r, m, skip_self=not loop, pad=False, local=True, int32_rows=int32_rows)
     # with self loops every node finds at least itself (the cap counts hits in index order, but a full row is not empty)
     return NeighborTable(nbr, info.ptr, dense=False, max_nodes=info.max_nodes, cnt=_cnt, nonempty=bool(loop),
-                         rows16=rows16)
+                         rows16=rows16, shape=(x.shape[0], m))
 
 
 def radius_graph(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None, loop: bool = False,
@@ -120,4 +127,5 @@ def radius_graph(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None
     """torch_cluster.radius_graph (train.py:48 passes r=0.4, loop=True, max_num_neighbors=255)."""
     if flow not in ("source_to_target", "target_to_source"):
         raise ValueError(f"flow must be 'source_to_target' or 'target_to_source', got {flow!r}")
-    return radius_table(x, r, batch, loop, max_num_neighbors, batch_size).edge_index(flow)
+    # the [2,E] view is cut from the int32 table: have the build write it (radius_table alone leaves it out when it can)
+    return radius_table(x, r, batch, loop, max_num_neighbors, batch_size, int32_rows=True).edge_index(flow)

@@ -67,7 +67,8 @@ BN_KNN_FUSE = os.environ.get("DMET_BN_KNN_FUSE", "1")
 def _lds_eligible(x, weight, table: NeighborTable, any_size: bool = False) -> bool:
     return (x.shape[1] == 32 and weight.shape[0] == 32 and table.k in _native.LDS_GATHER_K
             and table.ptr is not None and table.max_nodes is not None
-            and (any_size or table.max_nodes <= _LDS_MAX_EVENT_NODES) and table.nbr.data_ptr() % 16 == 0)
+            and (any_size or table.max_nodes <= _LDS_MAX_EVENT_NODES)
+            and (not table.has_int32_table() or table.nbr.data_ptr() % 16 == 0))
 
 
 class _EdgeConvLinearMax(torch.autograd.Function):
@@ -112,6 +113,11 @@ class _EdgeConvLinearMax(torch.autograd.Function):
             elif ctx.j16:
                 out, arg = _native.gather_max_counted_j16(P, Q, table.nbr, table.cnt, table.order_by_count(), table.ptr,
                                                           sliced)
+            elif (lds and not need_grad and table.rows16 is not None and _native.GATHER_MAX_FORM == "auto"
+                  and os.environ.get("DMET_RADIUS_IDS", "rows16") == "rows16"):
+                # inference over a radius table: the same uint16 rows, the maximum alone
+                out, arg = _native.gather_max_local_j16(P, Q, table.rows16, table.cnt, table.order_by_count(), table.ptr,
+                                                        table.k, sliced, want_arg=False)
             else:
                 out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad, cnt=table.cnt, lds=lds,
                                               sliced=sliced)

@@ -1481,7 +1481,7 @@ extern "C" int dmet_gather_max_local_j16_f32(const float *P, const float *Q, con
     DMET_REQUIRE(H >= kSliceC && H % kSliceC == 0 && H <= DMET_MAX_H,
                  "dmet_gather_max_local_j16_f32: H=%d must be a multiple of %d", H, kSliceC);
     if (N == 0 || B == 0) return 0;
-    DMET_REQUIRE(P && Q && nbr16 && cnt && ptr && out && argj, "dmet_gather_max_local_j16_f32: null pointer");
+    DMET_REQUIRE(P && Q && nbr16 && cnt && ptr && out, "dmet_gather_max_local_j16_f32: null pointer");
     DMET_REQUIRE(aligned16(P) && aligned16(Q) && aligned16(out) && aligned16(nbr16) &&
                      (reinterpret_cast<uintptr_t>(argj) & 7u) == 0,
                  "dmet_gather_max_local_j16_f32: pointers must be 16-B (argj: 8-B) aligned");
@@ -1490,6 +1490,18 @@ extern "C" int dmet_gather_max_local_j16_f32(const float *P, const float *Q, con
     const int64_t blocks = groups * kNumXcd * nsl;
     hipStream_t st = as_stream(stream);
     uint8_t *a8 = reinterpret_cast<uint8_t *>(argj);
+    if (!argj) {      // inference: the maximum alone
+        if (pq_sliced)
+            hipLaunchKernelGGL((gather_max_lds_counted_kernel<false, true, true, true>), dim3((unsigned)blocks),
+                               dim3(kLdsGatherThreads), 0, st, P, Q, nullptr, cnt, ptr, B, kmax, H, out, a8, N, order, nbr16,
+                               stride16);
+        else
+            hipLaunchKernelGGL((gather_max_lds_counted_kernel<false, false, true, true>), dim3((unsigned)blocks),
+                               dim3(kLdsGatherThreads), 0, st, P, Q, nullptr, cnt, ptr, B, kmax, H, out, a8, N, order, nbr16,
+                               stride16);
+        DMET_LAUNCH_CHECK("gather_max_lds_counted_kernel (uint16 rows, no winners)");
+        return 0;
+    }
     if (pq_sliced)
         hipLaunchKernelGGL((gather_max_lds_counted_kernel<true, true, true, true>), dim3((unsigned)blocks),
                            dim3(kLdsGatherThreads), 0, st, P, Q, nullptr, cnt, ptr, B, kmax, H, out, a8, N, order, nbr16,

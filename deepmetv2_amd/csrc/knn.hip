@@ -2980,7 +2980,7 @@ __global__ __launch_bounds__(kWave * 4) void radius_window_kernel(const float *_
                         stage32[stored & 3] = j;
                         if (row16) stage16[stored & 7] = (uint16_t)(j - lo);
                         ++stored;
-                        if ((stored & 3) == 0) {   // rows are only 4-byte aligned (255-wide tables)
+                        if ((stored & 3) == 0 && nbr) {   // rows are only 4-byte aligned (255-wide tables)
                             struct __attribute__((packed, aligned(4))) I4 { int32_t a, b, c, d; };
                             const int4 v = *reinterpret_cast<const int4 *>(stage32);
                             *reinterpret_cast<I4 *>(row + stored - 4) = I4{v.x, v.y, v.z, v.w};
@@ -3033,7 +3033,8 @@ __global__ __launch_bounds__(kWave * 4) void radius_window_kernel(const float *_
     if (pending > 0 && __any(seen < max_nbr)) sweep(pending);
     if (valid) {
         cntout[qq] = stored;
-        for (int s = stored & ~3; s < stored; ++s) row[s] = stage32[s & 3];     // the unfinished slots
+        if (nbr)
+            for (int s = stored & ~3; s < stored; ++s) row[s] = stage32[s & 3];     // the unfinished slots
         if (row16 && (stored & 7) != 0) {   // the last started chunk of 8 reads as "no neighbour" beyond the row's end
             for (int s = stored & 7; s < 8; ++s) stage16[s] = 0xFFFFu;
             *reinterpret_cast<uint4 *>(row16 + (stored & ~7)) = *reinterpret_cast<const uint4 *>(stage16);
@@ -3229,7 +3230,9 @@ extern "C" int dmet_radius_windowed_local_f32(const float *x, const int64_t *ptr
     DMET_REQUIRE(D >= 1 && D <= 8, "dmet_radius_windowed_f32: D=%d not in [1,8]", D);
     DMET_REQUIRE(max_nbr >= 1, "dmet_radius_windowed_f32: max_nbr=%d", max_nbr);
     if (N == 0 || B == 0) return 0;
-    DMET_REQUIRE(x && ptr && nbr && cnt && ws, "dmet_radius_windowed_f32: null pointer");
+    // nbr == NULL: only the uint16 rows are written (a caller whose consumers read those: the 255-wide int32 table is 294 MB
+    // of address space at 288 000 nodes, its ~36 used slots per row 41 MB of 16-byte pieces: 12 of the kernel's 130 us)
+    DMET_REQUIRE(x && ptr && cnt && ws && (nbr || (nbr16 && !fill)), "dmet_radius_windowed_f32: null pointer");
     DMET_REQUIRE(ws_bytes >= dmet_radius_workspace_bytes(N), "dmet_radius_windowed_f32: workspace too small");
     int32_t *order = reinterpret_cast<int32_t *>((reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u);
     const float r2 = r * r;

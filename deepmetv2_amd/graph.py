@@ -216,11 +216,15 @@ class NeighborTable:
     """nbr[N,k] int32 global node ids, -1 = empty slot.  Row i lists the message SOURCES of target i.
     With `cnt` (radius tables) only the first cnt[i] slots of row i are defined; the rest may be unwritten."""
 
-    def __init__(self, nbr: torch.Tensor, ptr: Optional[torch.Tensor], dense: bool, dist: Optional[torch.Tensor] = None,
+    def __init__(self, nbr: Optional[torch.Tensor], ptr: Optional[torch.Tensor], dense: bool, dist: Optional[torch.Tensor] = None,
                  max_nodes: Optional[int] = None, cnt: Optional[torch.Tensor] = None,
                  nbr_local: Optional[torch.Tensor] = None, nonempty: bool = False,
-                 rows16: Optional[torch.Tensor] = None, full_rows: bool = False):
-        self.nbr = nbr
+                 rows16: Optional[torch.Tensor] = None, full_rows: bool = False, shape: Optional[Tuple[int, int]] = None):
+        # nbr=None with `shape` = (N, k), `rows16`, `cnt` and `ptr`: a counted table that exists as event-local uint16 rows
+        # only (cluster.radius_table); the int32 form is expanded from them the first time somebody asks for `.nbr`
+        if nbr is None and (shape is None or rows16 is None or cnt is None or ptr is None):
+            raise ValueError("NeighborTable without an int32 table needs shape, rows16, cnt and ptr")
+        self._nbr = nbr
         # True: every row is EXPECTED to hold k entries (kNN with self loops, every event >= k nodes): the [2,E] view is
         # sized E = N k without asking the device; the expectation is verified by a deferred check (knn_table).  Unlike
         # `dense` it is not relied upon for masking: a short row (non-finite query) still yields 0 and no gradient.
@@ -234,13 +238,30 @@ class NeighborTable:
         self.ptr = ptr
         self.max_nodes = max_nodes
         self.cnt = cnt              # optional int32 [N]: slots beyond cnt[i] in row i are all -1 (wide, shallow tables)
-        self.num_nodes, self.k = nbr.shape
+        self.num_nodes, self.k = (nbr.shape if nbr is not None else shape)
         self.dense = dense          # True: no -1 entries anywhere (every row has exactly k neighbours)
         self.dist = dist
         self._rev = None
         self._rp = None
         self._edges = None
         self._edge_index = {}
+
+    @property
+    def nbr(self) -> torch.Tensor:
+        if self._nbr is None:
+            # global ids of the first cnt[i] slots of row i, -1 beyond (the uint16 rows hold event-local ids; slots past
+            # the last started chunk of 8 are unwritten)
+            self.join()
+            N, k = self.num_nodes, self.k
+            counts = (self.ptr[1:] - self.ptr[:-1])
+            lo = torch.repeat_interleave(self.ptr[:-1], counts, output_size=N).to(torch.int32).view(-1, 1)
+            loc = self.rows16[:, :k].to(torch.int32) & 0xFFFF
+            slot = torch.arange(k, device=loc.device, dtype=torch.int32).view(1, -1)
+            self._nbr = torch.where(slot < self.cnt.view(-1, 1), loc + lo, torch.full_like(loc, -1)).contiguous()
+        return self._nbr
+
+    def has_int32_table(self) -> bool:
+        return self._nbr is not None
 
     def join(self) -> "NeighborTable":
         """Make the table's device tensors usable on the current stream (a table built by graph.build_async; no-op else)."""
@@ -277,7 +298,7 @@ class NeighborTable:
         if self._rp is None:
             if self.dense or self.full_rows:
                 N, k = self.num_nodes, self.k
-                self._rp = (torch.arange(0, (N + 1) * k, k, dtype=torch.int32, device=self.nbr.device), N * k)
+                self._rp = (torch.arange(0, (N + 1) * k, k, dtype=torch.int32, device=self.ptr.device if self._nbr is None else self._nbr.device), N * k)
             else:
                 rp = _native.table_rowptr(self.nbr, self.cnt)
                 self._rp = (rp, int(rp[-1].item()) if self.num_nodes else 0)
@@ -343,7 +364,7 @@ class GraphFuture:
             cur = torch.cuda.current_stream()
             cur.wait_stream(self._side_stream)
             t = self._table
-            for name in ("nbr", "cnt", "rows16", "nbr_local", "dist"):
+            for name in ("_nbr", "cnt", "rows16", "nbr_local", "dist"):     # (_nbr: `.nbr` would expand a table kept as uint16 rows)
                 v = getattr(t, name, None)
                 if torch.is_tensor(v) and v.is_cuda:
                     v.record_stream(cur)            # allocated on the side stream, consumed on this one

@@ -125,7 +125,10 @@ int dmet_radius_windowed_f32(const float *x, const int64_t *ptr, int B, int64_t 
                              dmet_stream_t stream);
 /* Same, and optionally a second copy of every row as EVENT-LOCAL uint16 ids (nbr16 != NULL: rows of stride16 ids,
  * stride16 % 8 == 0, stride16 >= max_nbr, 16-byte aligned; slots cnt[i] .. roundup8(cnt[i]) - 1 hold 0xFFFF, the rest
- * of the row is unwritten; meaningful for events of at most 65534 nodes) for dmet_gather_max_local_j16_f32. */
+ * of the row is unwritten; meaningful for events of at most 65534 nodes) for dmet_gather_max_local_j16_f32.
+ * With nbr16 given and fill == 0, nbr may be NULL: the int32 table is then not written at all (for callers whose
+ * consumers read the uint16 rows -- 288 000 x 255 int32 slots are 294 MB of address space, the ~36 used slots per row
+ * 41 MB of 16-byte pieces). */
 int dmet_radius_windowed_local_f32(const float *x, const int64_t *ptr, int B, int64_t N, int D, float r, int max_nbr,
                                    int skip_self, int fill, int32_t *nbr, int32_t *cnt, uint16_t *nbr16, int stride16,
                                    void *ws, size_t ws_bytes, dmet_stream_t stream);
@@ -204,7 +207,7 @@ int dmet_gather_max_counted_lds_j16_f32(const float *P, const float *Q, const in
 /* Second form of the ids for the same gather: rows of event-local uint16 ids written by the radius kernel itself
  * (dmet_radius_windowed_local_f32: nbr16[N][stride16], stride16 a multiple of 8 and >= max_nbr, 16-byte aligned; the
  * last started chunk of 8 of every row is padded with 0xFFFF; events of at most 65534 nodes): one aligned 16-byte
- * load per 8 slots, no packing pass.  Identical out / argj. */
+ * load per 8 slots, no packing pass.  Identical out / argj.  argj == NULL (inference): the maximum alone. */
 int dmet_gather_max_local_j16_f32(const float *P, const float *Q, const uint16_t *nbr16, int stride16,
                                   const int32_t *cnt, const int32_t *order, const int64_t *ptr, int B, int64_t N,
                                   int kmax, int H, int pq_sliced, float *out, uint16_t *argj, dmet_stream_t stream);

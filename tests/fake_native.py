@@ -24,7 +24,7 @@ def knn_local(x, ptr, k, stats=None):
     return nbr, dist, loc
 
 
-def radius(x, ptr, r, max_nbr, skip_self=False, pad=True, local=False):
+def radius(x, ptr, r, max_nbr, skip_self=False, pad=True, local=False, int32_rows=True):
     import ctypes  # noqa: F401
     if local:
         nbr, cnt = radius(x, ptr, r, max_nbr, skip_self, pad)
@@ -38,7 +38,7 @@ def radius(x, ptr, r, max_nbr, skip_self=False, pad=True, local=False):
         loc = torch.where(slot < c, loc, torch.full_like(loc, 0xFFFF))       # pad of the last chunk
         loc = torch.where(slot < (c + 7) // 8 * 8, loc, torch.full_like(loc, 0x1234))   # unwritten: poison
         loc &= 0xFFFF
-        return nbr, cnt, torch.where(loc >= 0x8000, loc - 0x10000, loc).to(torch.int16)
+        return (nbr if (int32_rows or pad) else None), cnt, torch.where(loc >= 0x8000, loc - 0x10000, loc).to(torch.int16)
     x = x.detach().float().contiguous()
     N, D = x.shape
     nbr = torch.empty((N, max_nbr), dtype=torch.int32)

@@ -1672,3 +1672,43 @@ def test_backward_scatter_slice_major_handover(dev, sizes):
         r1 = _native.edgeconv_linear_bwd(xd, W, g_out, argk, a1, g_add=g_add, gq_sliced=True)
         for u, v in zip(r0, r1):
             assert torch.equal(u, v)
+
+
+def test_radius_table_without_int32_rows(dev):
+    """N1 (train.py:48): with the batch's largest event registered, radius_table writes the event-local uint16 rows only
+    (the 255-wide int32 table is not even allocated); the fused EdgeConv -- training AND inference -- reads those, and
+    `.nbr`, expanded on demand, equals the table of the int32-writing build slot for slot (first cnt[i] slots, -1 beyond)."""
+    import deepmetv2_amd as dm
+    from deepmetv2_amd import synth
+    sizes = [700, 90, 1300, 1, 40]
+    x, y, batch, ptr = synth.make_events(sizes, seed=21, device=dev)
+    dm.register_batch(batch, ptr, len(sizes), max_nodes=max(sizes), min_nodes=min(sizes))
+    etaphi = torch.stack([x[:, 3], torch.atan2(x[:, 1], x[:, 0])], 1).contiguous()
+    lazy = dm.radius_table(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255)
+    full = dm.radius_table(etaphi, r=0.4, batch=batch, loop=True, max_num_neighbors=255, int32_rows=True)
+    if os.environ.get("DMET_RADIUS", "windowed") == "windowed" and os.environ.get("DMET_RADIUS_INT32", "lazy") == "lazy":
+        assert not lazy.has_int32_table() and full.has_int32_table()
+    assert torch.equal(lazy.cnt, full.cnt)
+    conv = dm.EdgeConv(torch.nn.Sequential(torch.nn.Linear(64, 32))).to(dev)
+    h = torch.randn(sum(sizes), 32, device=dev)
+    outs = {}
+    for name, table in (("lazy", lazy), ("full", full)):
+        hh = h.clone().requires_grad_(True)
+        o = conv(hh, table)
+        o.square().sum().backward()
+        with torch.no_grad():
+            o_eval = conv(h, table)
+        outs[name] = (o.detach(), hh.grad.clone(), o_eval, [p.grad.clone() for p in conv.parameters()])
+        conv.zero_grad()
+    for u, v in zip(outs["lazy"][:3], outs["full"][:3]):
+        assert torch.equal(u, v)
+    for u, v in zip(outs["lazy"][3], outs["full"][3]):
+        assert torch.equal(u, v)
+    assert torch.equal(outs["lazy"][0], outs["lazy"][2])       # training and inference forms agree
+    if os.environ.get("DMET_RADIUS", "windowed") == "windowed" and os.environ.get("DMET_RADIUS_INT32", "lazy") == "lazy":
+        assert not lazy.has_int32_table()                       # nobody needed it
+    k = lazy.k
+    slot = torch.arange(k, device=dev).view(1, -1)
+    want = torch.where(slot < full.cnt.view(-1, 1), full.nbr, torch.full_like(full.nbr, -1))
+    assert torch.equal(lazy.nbr, want)
+    assert torch.equal(lazy.edge_index("source_to_target"), full.edge_index("source_to_target"))
