@@ -1705,10 +1705,15 @@ def test_radius_table_without_int32_rows(dev):
     for u, v in zip(outs["lazy"][3], outs["full"][3]):
         assert torch.equal(u, v)
     assert torch.equal(outs["lazy"][0], outs["lazy"][2])       # training and inference forms agree
-    if os.environ.get("DMET_RADIUS", "windowed") == "windowed" and os.environ.get("DMET_RADIUS_INT32", "lazy") == "lazy":
-        assert not lazy.has_int32_table()                       # nobody needed it
+    default_ids = os.environ.get("DMET_RADIUS_J16", "1") != "0" and os.environ.get("DMET_RADIUS_IDS", "rows16") == "rows16"
+    if (os.environ.get("DMET_RADIUS", "windowed") == "windowed" and os.environ.get("DMET_RADIUS_INT32", "lazy") == "lazy"
+            and default_ids and os.environ.get("DMET_GATHER_MAX_FORM", "auto") == "auto"):
+        assert not lazy.has_int32_table()                       # nobody needed it (the switches above read the int32 rows)
     k = lazy.k
     slot = torch.arange(k, device=dev).view(1, -1)
-    want = torch.where(slot < full.cnt.view(-1, 1), full.nbr, torch.full_like(full.nbr, -1))
-    assert torch.equal(lazy.nbr, want)
+    used = slot < full.cnt.view(-1, 1)                          # slots beyond cnt[i] are unwritten in a table the build wrote
+    minus = torch.full_like(full.nbr, -1)
+    assert torch.equal(torch.where(used, lazy.nbr, minus), torch.where(used, full.nbr, minus))
+    if os.environ.get("DMET_RADIUS", "windowed") == "windowed" and os.environ.get("DMET_RADIUS_INT32", "lazy") == "lazy" and default_ids:
+        assert bool((torch.where(used, minus, lazy.nbr) == -1).all())   # an EXPANDED table is -1 beyond cnt[i]
     assert torch.equal(lazy.edge_index("source_to_target"), full.edge_index("source_to_target"))

@@ -5,10 +5,13 @@
 # (DMET_GATHER_MAX_FORM=l2-only: the direct slice-major calls; DMET_KNN_PATH=exact: the flagged-query counters).
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out/toggles
-for t in "DMET_NONE=1" "DMET_GATHER_MAX_FORM=l2-only" "DMET_EDGECONV_FORM=fused" "DMET_RADIUS=sweep" "DMET_RADIUS_IDS=int32" \
-         "DMET_RADIUS_J16=0" "DMET_KNN_FILTER=1" "DMET_KNN_PATH=exact" "DMET_FUSED_ENCODER=0" "DMET_GATHER_BWD=reverse" \
-         "DMET_PQ_SLICED=0" "DMET_GATHER_BALANCED=0" "DMET_GATHER_BALANCED=1" "DMET_GATHER_MIXED=1" \
-         "DMET_KNN_RIDER=0" "DMET_ENCODER_FWD=valu" "DMET_ENCODER_BWD=valu" "DMET_HEAD_FWD=valu" "DMET_HEAD_BWD=valu" "DMET_BN_KNN_FUSE=0" "DMET_BN_HEAD_FUSE=0" "DMET_ENC_BN_FUSE=0" "DMET_BN_NLS_FUSE=0" $EXTRA_TOGGLES; do
+DEFAULT_TOGGLES="DMET_NONE=1 DMET_GATHER_MAX_FORM=l2-only DMET_EDGECONV_FORM=fused DMET_RADIUS=sweep DMET_RADIUS_IDS=int32 \
+DMET_RADIUS_J16=0 DMET_KNN_FILTER=1 DMET_KNN_PATH=exact DMET_FUSED_ENCODER=0 DMET_GATHER_BWD=reverse \
+DMET_PQ_SLICED=0 DMET_GATHER_BALANCED=0 DMET_GATHER_BALANCED=1 DMET_GATHER_MIXED=1 \
+DMET_KNN_RIDER=0 DMET_ENCODER_FWD=valu DMET_ENCODER_BWD=valu DMET_HEAD_FWD=valu DMET_HEAD_BWD=valu DMET_BN_KNN_FUSE=0 DMET_BN_HEAD_FUSE=0 DMET_ENC_BN_FUSE=0 DMET_BN_NLS_FUSE=0 \
+DMET_DEFER_FINALIZE=0 DMET_GQ_SLICED=0 DMET_KNN_EMIT=lanes DMET_RADIUS_INT32=full"
+# ONLY_TOGGLES="A=1 B=0": just these;  EXTRA_TOGGLES: appended to the default list
+for t in ${ONLY_TOGGLES:-$DEFAULT_TOGGLES $EXTRA_TOGGLES}; do
   n=$(echo $t | tr "=" "_")
   # the whole log is kept (round 2 kept `tail -8` only: three failures under DMET_KNN_FILTER=1 had no recorded cause)
   env $t timeout -k 10 400 python -m pytest tests -m gpu -q --tb=short -rf > gpurun_out/toggles/$n.txt 2>&1
