@@ -686,7 +686,15 @@ inline int64_t enc_nodes_per_wave(int64_t N, int64_t *nwaves)
 {
     const int64_t target_waves = 2048;   // 256 CUs x 8 resident wavefronts
     int64_t npw = (N + target_waves - 1) / target_waves;
+    // rounded DOWN to whole 64-node chunks: at least target_waves wavefronts' worth of partials, so that the matrix-core
+    // kernel (32-node tiles dealt round-robin, grid capped at 512 workgroups AND at the partial count) gets its full grid --
+    // rounded up, 288 000 nodes gave 375 workgroups: 6 tiles per wavefront with half of the SIMDs holding two wavefronts
+    // (12 tiles) against <= 5 per wavefront, two wavefronts on every SIMD
+#ifdef DMET_ENC_NPW_UP
     npw = (npw + 63) / 64 * 64;
+#else
+    npw = npw / 64 * 64;
+#endif
     if (npw < 64) npw = 64;
     int64_t nw = (N + npw - 1) / npw;
     nw = (nw + kEncBwdWaves - 1) / kEncBwdWaves * kEncBwdWaves;
