@@ -44,10 +44,14 @@ __host__ __device__ constexpr int defer_blocks(int kind)
 __global__ __launch_bounds__(1024) void finalize_groups_kernel(const FinalizeArgs a)
 {
     __shared__ float red0[32][33], red1[32][33];
-    int g = 0;
-    while (g + 1 < a.n && (int)blockIdx.x >= a.first_block[g + 1]) ++g;
-    const DeferDesc &d = a.d[g];
-    const int blk = (int)blockIdx.x - a.first_block[g];
+    // the block's descriptor, picked with STATIC indices (a dynamically indexed kernel-argument array is copied to scratch
+    // memory first: the launch took 11 us that way)
+    DeferDesc d = a.d[0];
+    int first = 0;
+#pragma unroll
+    for (int i = 1; i < kDeferMax; ++i)
+        if (i < a.n && (int)blockIdx.x >= a.first_block[i]) { d = a.d[i]; first = a.first_block[i]; }
+    const int blk = (int)blockIdx.x - first;
     const int e = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const float *__restrict__ partial = d.partial;
     const int64_t nparts = d.nparts;
