@@ -64,3 +64,20 @@ def test_oracle_is_not_reachable_from_the_product():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{f} imports the oracle"
                 assert "libdmet_oracle" not in text and "ref_ops" not in text, f"{f} reaches into oracle/"
                 assert not re.search(r"#include\s+[\"<][^\"<>]*oracle", text), f"{f} includes oracle sources"
+
+
+def test_deferral_and_size_hint_host_state(lib):
+    """The host-side state machines of dmet_finalize_defer_begin / _pending / _flush and dmet_knn_size_hint need no GPU:
+    outside a deferral nothing is pending (-1), inside it an empty queue flushes without a launch (stream NULL), a second
+    flush is a no-op, negative sizes are refused through the error string like every other argument check."""
+    assert lib.dmet_finalize_pending() == -1
+    assert lib.dmet_finalize_flush(None) == 0            # no deferral: nothing to do
+    assert lib.dmet_finalize_defer_begin() == 0
+    assert lib.dmet_finalize_pending() == 0
+    assert lib.dmet_finalize_defer_begin() == 0          # beginning again resets the queue
+    assert lib.dmet_finalize_flush(None) == 0            # empty queue: no launch
+    assert lib.dmet_finalize_pending() == -1
+    assert lib.dmet_knn_size_hint(800, 4500) == 0
+    assert lib.dmet_knn_size_hint(0, 0) == 0             # "unknown" clears it
+    assert lib.dmet_knn_size_hint(-1, 10) != 0
+    assert b"dmet_knn_size_hint" in lib.dmet_last_error()
