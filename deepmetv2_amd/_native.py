@@ -137,6 +137,8 @@ def finalize_defer_begin() -> bool:
     alive here.  DMET_DEFER_FINALIZE=0: a no-op (every call sums its own partials at once, as without this call)."""
     if not DEFER_FINALIZE:
         return False
+    if _DEFER["active"]:
+        finalize_flush()     # a deferral somebody left open (an exception between begin and flush): its sums are formed first
     _lib.check(_lib.load().dmet_finalize_defer_begin(), "dmet_finalize_defer_begin")
     _DEFER["active"], _DEFER["keep"], _DEFER["dev"] = True, [], None
     return True

@@ -140,6 +140,11 @@ using namespace dmet;
 extern "C" int dmet_finalize_defer_begin(void)
 {
     std::lock_guard<std::mutex> lock(g_defer_mutex);
+    // sums still queued belong to gradients that nobody has formed yet: dropping them silently would leave those gradients
+    // unwritten for good
+    DMET_REQUIRE(!(g_defer.active && g_defer.n > 0),
+                 "dmet_finalize_defer_begin: %d weight-gradient sums of the previous deferral are still queued (dmet_finalize_flush first)",
+                 g_defer.n);
     g_defer.active = true;
     g_defer.n = 0;
     return 0;

@@ -519,7 +519,8 @@ int dmet_head_bwd_f32(const float *emb, int64_t N, const float *W1, const float 
  * launches its own as before -- and dmet_finalize_flush(stream) forms every queued sum in ONE launch (the same
  * additions in the same order: same bits) and ends the deferral.  Contract: the gradient outputs and the workspaces of
  * the queued calls must stay allocated and untouched until the flush has been enqueued on the same stream; the outputs
- * hold garbage before it.  dmet_finalize_pending(): queued steps, -1 outside a deferral. */
+ * hold garbage before it.  dmet_finalize_pending(): queued steps, -1 outside a deferral.  Beginning a deferral while sums
+ * of an earlier one are still queued is refused (-22): they would never be formed. */
 int dmet_finalize_defer_begin(void);
 int dmet_finalize_pending(void);
 int dmet_finalize_flush(dmet_stream_t stream);

@@ -1720,3 +1720,28 @@ def test_radius_table_without_int32_rows(dev):
     if os.environ.get("DMET_RADIUS", "windowed") == "windowed" and os.environ.get("DMET_RADIUS_INT32", "lazy") == "lazy" and default_ids:
         assert bool((torch.where(used, minus, lazy.nbr) == -1).all())   # an EXPANDED table is -1 beyond cnt[i]
     assert torch.equal(lazy.edge_index("source_to_target"), full.edge_index("source_to_target"))
+
+
+def test_deferral_is_not_dropped_by_a_second_begin(dev):
+    """K5: beginning a deferral while sums of an earlier one are queued would leave those gradients unwritten for good --
+    the C entry refuses, the Python wrapper forms the open deferral's sums first."""
+    from deepmetv2_amd import _lib, _native
+    L = _lib.load()
+    N = 700
+    g = torch.Generator().manual_seed(9)
+    emb = torch.randn(N, 32, generator=g).to(dev)
+    params = [(torch.randn(16, 32, generator=g) / 6).to(dev), torch.randn(16, generator=g).to(dev),
+              (torch.randn(1, 16, generator=g) / 4).to(dev), torch.randn(1, generator=g).to(dev)]
+    out = _native.head_fwd(emb, params)
+    g_out = torch.randn(N, generator=g).to(dev)
+    want = _native.head_bwd(emb, params, out, g_out)             # sums formed at once
+    assert _native.finalize_defer_begin()
+    got = _native.head_bwd(emb, params, out, g_out)              # queued
+    assert L.dmet_finalize_pending() == 1
+    assert L.dmet_finalize_defer_begin() != 0 and b"still queued" in L.dmet_last_error()
+    assert _native.finalize_defer_begin()                        # the wrapper flushes the open deferral, then begins anew
+    assert L.dmet_finalize_pending() == 0
+    _native.finalize_flush()
+    torch.cuda.synchronize()
+    for u, v in zip(want, got):
+        assert torch.equal(u, v)
