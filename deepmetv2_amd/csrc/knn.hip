@@ -2061,7 +2061,16 @@ __device__ __forceinline__ void filter2_wave(const KnnFilterArgs &a, F2Wave &S, 
         for (int p = KP - 1; p >= 1; --p) kk[p] = g[p - 1] ? kk[p - 1] : (g[p] ? nk : kk[p]);
         kk[0] = g[0] ? nk : kk[0];
     };
-    if constexpr (KP <= 16) {
+    // Rounds of rows in flight: three (KP <= 16) were chosen in round 2 -- the kernel has since grown to 256 VGPRs + 56
+    // bytes of scratch per lane with them (-Rpass-analysis=kernel-resource-usage), i.e. spill traffic inside this
+    // latency-bound loop; with two it needs 237 registers and no scratch and the build is 8-10 us faster (second session
+    // of round 3; DMET_RR_THREE brings the third back for A/B)
+#ifdef DMET_RR_THREE
+    constexpr bool kThreeRounds = KP <= 16;
+#else
+    constexpr bool kThreeRounds = false;
+#endif
+    if constexpr (kThreeRounds) {
         // three rounds of rows in flight: the loop is bound by the gathers' latency
         int32_t ja = pop(), jb, jc;
         HalfRows pa = fetch(ja), pb, pc;
