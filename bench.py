@@ -510,7 +510,7 @@ def main():
             prewarm_steps += 8
     if hip_graph_auto and not args.hip_graph:
         # host-bound?  time the launch thread's enqueue of one eager step from an idle stream against the GPU's time per
-        # step over a short burst; above 0.8 the timed region replays hipGraphs instead (all ranks decide alike)
+        # step over a short burst; above 0.5 the timed region replays hipGraphs instead (all ranks decide alike)
         hts = []
         for _ in range(7):
             torch.cuda.synchronize(dev)
@@ -521,12 +521,15 @@ def main():
             step()
         torch.cuda.synchronize(dev)
         ratio = sorted(hts)[3] / ((time.perf_counter() - tg) / 24)
-        want = ratio > 0.8
+        # 0.5, not the 0.8 of the first session: at 0.8 the launch thread has no headroom left -- one box measured 0.80 in
+        # this probe, stayed eager and then ran the 300 timed steps at 1.675 ms (38.2k events/s) where the replayed step
+        # takes 1.38 (46.3k): any stall of the launch thread (allocator, Python) is GPU idle time it never catches up on
+        want = ratio > 0.5
         if use_group:
             flag = torch.tensor([1.0 if want else 0.0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             want = bool(flag.item() > 0)
-        hip_graph_note = f"auto: host enqueue / step time of the eager loop = {ratio:.2f} ({'>' if want else '<='} 0.8)"
+        hip_graph_note = f"auto: host enqueue / step time of the eager loop = {ratio:.2f} ({'>' if want else '<='} 0.5)"
         if want:
             g = graphed_train_step()
             if g is not None:
