@@ -49,8 +49,9 @@ def parse_args():
     ap.add_argument("--hip-graph", dest="hip_graph", action="store_true", default=None,
                     help="replay the step as two hipGraphs around the gradient all-reduce (per-kernel HIP-event figures "
                          "then come from a few eager steps after the timed region).  Default: on for --gpus N > 1 (the "
-                         "eager step costs the launch thread ~0.8 of the GPU time: N ranks on one host plus the RCCL "
-                         "proxy threads have no headroom for it), off at N = 1")
+                         "eager step costs the launch thread 0.6-0.9 of the GPU time: N ranks on one host plus the RCCL "
+                         "proxy threads have no headroom for it); at N = 1 decided by a probe: on when the launch thread "
+                         "needs more than half of the step")
     ap.add_argument("--no-hip-graph", dest="hip_graph", action="store_false")
     ap.add_argument("--model", choices=["fused", "stock-knn-graph", "stock-dynamic"], default="fused",
                     help="fused: this repo's model.Net (fused encoder / head kernels, BatchNorm riders, FlatAdamW); "
