@@ -51,6 +51,7 @@ SIGNATURES = {
     "dmet_gather_max_lds_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "dmet_gather_max_counted_lds_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp]),
     "dmet_gather_max_lds_sliced_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
+    "dmet_gather_max_lds_sliced_cap_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _i64, _vp]),
     "dmet_gather_max_lds16_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "dmet_edge_mlp2_supported": (_i, [_i, _i, _i, _i]),
     "dmet_edge_mlp2_bf16": (_i, [_vp, _i64, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -379,11 +379,12 @@ def bn_node_linear_split(raw: torch.Tensor, residual: Optional[torch.Tensor], ga
 
 def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optional[torch.Tensor],
                want_arg: bool, cnt: Optional[torch.Tensor] = None, lds: bool = False,
-               nbr_local: Optional[torch.Tensor] = None, sliced: bool = False, mixed: bool = False
-               ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+               nbr_local: Optional[torch.Tensor] = None, sliced: bool = False, mixed: bool = False,
+               max_nodes: Optional[int] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """out = P + max over the rows of Q listed in nbr (+ uint8 arg).  lds=True: the caller knows every event fits
     the LDS image (<= 5119 nodes, k in LDS_GATHER_K, H % 8 == 0) -> LDS-resident kernel; mixed=True: some events do not,
-    the form is chosen per event inside the call (row-major P / Q); else gathers come from L2."""
+    the form is chosen per event inside the call (row-major P / Q); else gathers come from L2.  max_nodes: the batch's
+    largest event when the caller knows it (a hint: batches of small events run two 512-thread workgroups per CU)."""
     dev = _require_device(P, Q, nbr)
     L = _lib.load()
     if mixed and cnt is None and not sliced and ptr is not None and GATHER_MAX_FORM == "auto":
@@ -420,11 +421,12 @@ def gather_max(P: torch.Tensor, Q: torch.Tensor, nbr: torch.Tensor, ptr: Optiona
         _note_gather("gather_max_lds_kernel (per-event Q slice resident in LDS; slice-major P/Q, "
                      + ("uint16 event-local ids)" if nbr_local is not None else "int32 ids)"))
         with _on(dev):
-            _lib.check(L.dmet_gather_max_lds_sliced_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(),
-                                                        nbr_local.data_ptr() if nbr_local is not None else None,
-                                                        ptr.data_ptr(), ptr.numel() - 1, N, k, H, out.data_ptr(),
-                                                        arg.data_ptr() if want_arg else None, _stream(dev)),
-                       "dmet_gather_max_lds_sliced_f32")
+            _lib.check(L.dmet_gather_max_lds_sliced_cap_f32(P.data_ptr(), Q.data_ptr(), nbr.data_ptr(),
+                                                            nbr_local.data_ptr() if nbr_local is not None else None,
+                                                            ptr.data_ptr(), ptr.numel() - 1, N, k, H, out.data_ptr(),
+                                                            arg.data_ptr() if want_arg else None, int(max_nodes or 0),
+                                                            _stream(dev)),
+                       "dmet_gather_max_lds_sliced_cap_f32")
         if _t is not None:
             _t.record(torch.cuda.current_stream(dev))
         return out, arg

@@ -141,7 +141,7 @@ class _EdgeConvLinearMax(torch.autograd.Function):
             else:
                 P, Q = _native.node_linear_split(x, weight, bias, sliced=sliced)
             out, arg = _native.gather_max(P, Q, table.nbr, table.ptr, want_arg=need_grad, lds=lds,
-                                          nbr_local=table.nbr_local, sliced=sliced, mixed=mixed)
+                                          nbr_local=table.nbr_local, sliced=sliced, mixed=mixed, max_nodes=table.max_nodes)
         if need_grad:
             ctx.save_for_backward(x, weight, arg)
             ctx.table = table

@@ -348,7 +348,7 @@ __device__ __forceinline__ void load_ids16_pair(unsigned (&w)[K4], const uint16_
 // SLICED: P and Q are the slice-major tables of dmet_node_linear_split_sliced_f32 ([H/8][N][8]); out / arg stay
 // row-major.
 // One segment of work: nodes [i0, i1) of event b, slice sl (the whole event's Q slice is staged either way).
-template <bool WITH_ARG, int K4, int GML_MODE, bool IDS16, bool SLICED>
+template <bool WITH_ARG, int K4, int GML_MODE, bool IDS16, bool SLICED, int ROWS = kLdsGatherRows, int THREADS = kLdsGatherThreads>
 __device__ __forceinline__ void gather_max_lds_segment(
     float4 *__restrict__ qs, const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ nbr,
     const uint16_t *__restrict__ nbr16, const int64_t *__restrict__ ptr, int k, int H,
@@ -356,7 +356,7 @@ __device__ __forceinline__ void gather_max_lds_segment(
     const int i1)
 {
     static_assert(K4 >= 1 && K4 <= 8, "k = 4 K4 <= 32");
-    constexpr int RPI = kLdsGatherThreads / 2;                                // rows per iteration (2 lanes per node)
+    constexpr int RPI = THREADS / 2;                                // rows per iteration (2 lanes per node)
     const int lo = (int)ptr[b], hi = (int)ptr[b + 1];
     const int n = hi - lo;
     if (n <= 0 || i0 >= i1) return;
@@ -370,7 +370,7 @@ __device__ __forceinline__ void gather_max_lds_segment(
     // float4 index of this lane's 4 channels of node `i` in P / Q (row-major, or slice-major [H/8][N][8])
     auto pq_at = [&](const int64_t i) -> int64_t { return SLICED ? ((int64_t)sl * N + i) * 2 + half : i * h4 + col4; };
 
-    if (n + 1 > kLdsGatherRows) {
+    if (n + 1 > ROWS) {
         if (skip_big) return;   // dmet_gather_max_mixed_f32: the L2-form kernel of the same call takes this event
         // event too large for the LDS image: same arithmetic, rows gathered from global memory (L2)
         for (int r = r0; r < i1; r += RPI) {
@@ -404,7 +404,7 @@ __device__ __forceinline__ void gather_max_lds_segment(
     if (GML_MODE != 1) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const int nchunk = (n + 31) / 32;
-        for (int c = wave; c < nchunk; c += kLdsGatherThreads / 64) {
+        for (int c = wave; c < nchunk; c += THREADS / 64) {
             int row = 32 * c + (lane >> 1);
             row = min(row, n - 1);   // tail lanes re-read the last row into rows >= n (row n is rewritten below)
             const float4 *src = SLICED ? Q4 + ((int64_t)sl * N + lo + row) * 2 + (lane & 1)
@@ -575,21 +575,26 @@ inline int num_cus()
 // gridDim.x equal ranges, the workgroups of an XCD taking one contiguous part of it.  A workgroup walks the
 // (event, slice) segments of its range, staging the Q slice of each (a range that cuts an (event, slice) in two makes
 // two workgroups stage it: the price of the balance).  At B * H/8 = 256 equal events both mappings coincide.
-template <bool WITH_ARG, int K4, int GML_MODE = 0, bool IDS16 = false, bool SLICED = false>
-__global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
+// ROWS / THREADS: rows of the LDS image and threads of the workgroup.  The full form (5 120 rows = 160 KB, 1 024 threads) is
+// one workgroup per CU -- by the image AND by its registers (115 VGPRs: four wavefronts per SIMD).  For batches whose largest
+// event fits 2 559 rows (dmet_gather_max_lds_sliced_cap_f32: the sizes real data has) the half form -- 80 KB, 512 threads --
+// puts TWO workgroups on a CU: one stages while the other gathers.
+template <bool WITH_ARG, int K4, int GML_MODE = 0, bool IDS16 = false, bool SLICED = false, int ROWS = kLdsGatherRows,
+          int THREADS = kLdsGatherThreads>
+__global__ __launch_bounds__(THREADS) void gather_max_lds_kernel(
     const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ nbr,
     const uint16_t *__restrict__ nbr16, const int64_t *__restrict__ ptr, int B, int k, int H,
     float *__restrict__ out, uint8_t *__restrict__ arg, int64_t N, int skip_big, int balanced)
 {
-    __shared__ __attribute__((aligned(16))) float4 qs[kLdsGatherRows * 2];   // [n_b + 1][2] float4 = 8 channels/node
+    __shared__ __attribute__((aligned(16))) float4 qs[ROWS * 2];   // [n_b + 1][2] float4 = 8 channels/node
     const int nsl = H / kSliceC;
     if (!balanced) {
         const int grp = blockIdx.x / (kNumXcd * nsl), rem = blockIdx.x % (kNumXcd * nsl);
         const int b = grp * kNumXcd + (rem % kNumXcd);
         const int sl = rem / kNumXcd;
         if (b >= B) return;
-        gather_max_lds_segment<WITH_ARG, K4, GML_MODE, IDS16, SLICED>(qs, P, Q, nbr, nbr16, ptr, k, H, out, arg, N, skip_big,
-                                                                       b, sl, 0, (int)(ptr[b + 1] - ptr[b]));
+        gather_max_lds_segment<WITH_ARG, K4, GML_MODE, IDS16, SLICED, ROWS, THREADS>(qs, P, Q, nbr, nbr16, ptr, k, H, out, arg, N,
+                                                                                      skip_big, b, sl, 0, (int)(ptr[b + 1] - ptr[b]));
         return;
     }
     const int64_t L = (int64_t)nsl * N;
@@ -607,8 +612,8 @@ __global__ __launch_bounds__(kLdsGatherThreads) void gather_max_lds_kernel(
         const int64_t rel = pos - (int64_t)nsl * lo;       // < nsl * n
         const int sl = (int)(rel / n), i0 = (int)(rel - (int64_t)sl * n);
         const int i1 = (int)((end - pos) < (int64_t)(n - i0) ? i0 + (end - pos) : n);
-        gather_max_lds_segment<WITH_ARG, K4, GML_MODE, IDS16, SLICED>(qs, P, Q, nbr, nbr16, ptr, k, H, out, arg, N, skip_big,
-                                                                       b0, sl, i0, i1);
+        gather_max_lds_segment<WITH_ARG, K4, GML_MODE, IDS16, SLICED, ROWS, THREADS>(qs, P, Q, nbr, nbr16, ptr, k, H, out, arg, N,
+                                                                                      skip_big, b0, sl, i0, i1);
         pos += i1 - i0;
         __syncthreads();                   // the image is restaged by the next segment
     }
@@ -1314,9 +1319,12 @@ extern "C" int dmet_gather_max_bf16q(const float *P, const uint16_t *Qh, const i
     return 0;
 }
 
+constexpr int kLdsGatherRowsHalf = kLdsGatherRows / 2;       // 2 560 rows = 80 KB
+constexpr int kLdsGatherThreadsHalf = kLdsGatherThreads / 2; // 512 threads: two such workgroups per CU
+
 static int gather_max_lds_impl(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr16,
                                const int64_t *ptr, int B, int64_t N, int k, int H, float *out, uint8_t *arg,
-                               bool sliced, dmet_stream_t stream, int skip_big = 0)
+                               bool sliced, dmet_stream_t stream, int skip_big = 0, int64_t max_nodes = 0)
 {
     DMET_REQUIRE(N >= 0 && N < (int64_t)2147483647, "dmet_gather_max_lds_f32: N out of range");
     DMET_REQUIRE(k >= 1 && k <= 255, "dmet_gather_max_lds_f32: k=%d not in [1,255]", k);
@@ -1344,6 +1352,30 @@ static int gather_max_lds_impl(const float *P, const float *Q, const int32_t *nb
         if (blocks > most) blocks = most;
     }
     hipStream_t st = as_stream(stream);
+    // batches of small events (the caller's hint; an event beyond it would take the in-kernel L2 path: slower, never wrong):
+    // the half form, one workgroup per (event, slice), two per CU
+    if (sliced && nbr16 && max_nodes > 0 && max_nodes + 1 <= kLdsGatherRowsHalf && (k == 8 || k == 16 || k == 20 || k == 32) &&
+        !env_is("DMET_GATHER_HALF_IMAGE", "0")) {
+        const int64_t hblocks = groups * kNumXcd * nsl;
+#define DMET_GMH(K4_)                                                                                                  \
+        do {                                                                                                           \
+            if (arg)                                                                                                   \
+                hipLaunchKernelGGL((gather_max_lds_kernel<true, K4_, 0, true, true, kLdsGatherRowsHalf, kLdsGatherThreadsHalf>), \
+                                   dim3((unsigned)hblocks), dim3(kLdsGatherThreadsHalf), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, \
+                                   out, arg, N, skip_big, 0);                                                          \
+            else                                                                                                       \
+                hipLaunchKernelGGL((gather_max_lds_kernel<false, K4_, 0, true, true, kLdsGatherRowsHalf, kLdsGatherThreadsHalf>), \
+                                   dim3((unsigned)hblocks), dim3(kLdsGatherThreadsHalf), 0, st, P, Q, nbr, nbr16, ptr, B, k, H, \
+                                   out, arg, N, skip_big, 0);                                                          \
+        } while (0)
+        if (k == 8) DMET_GMH(2);
+        else if (k == 16) DMET_GMH(4);
+        else if (k == 20) DMET_GMH(5);
+        else DMET_GMH(8);
+#undef DMET_GMH
+        DMET_LAUNCH_CHECK("gather_max_lds_kernel (80 KB image)");
+        return 0;
+    }
 #define DMET_GML_LAUNCH(ARG_, K4_, I16_)                                                                          \
     do {                                                                                                          \
         if (sliced)                                                                                               \
@@ -1432,6 +1464,14 @@ extern "C" int dmet_gather_max_lds_sliced_f32(const float *P, const float *Q, co
                                               int H, float *out, uint8_t *arg, dmet_stream_t stream)
 {
     return gather_max_lds_impl(P, Q, nbr, nbr_local, ptr, B, N, k, H, out, arg, true, stream);
+}
+
+extern "C" int dmet_gather_max_lds_sliced_cap_f32(const float *P, const float *Q, const int32_t *nbr,
+                                                  const uint16_t *nbr_local, const int64_t *ptr, int B, int64_t N, int k,
+                                                  int H, float *out, uint8_t *arg, int64_t max_nodes, dmet_stream_t stream)
+{
+    DMET_REQUIRE(max_nodes >= 0, "dmet_gather_max_lds_sliced_cap_f32: max_nodes=%lld", (long long)max_nodes);
+    return gather_max_lds_impl(P, Q, nbr, nbr_local, ptr, B, N, k, H, out, arg, true, stream, 0, max_nodes);
 }
 
 extern "C" int dmet_gather_max_counted_lds_f32(const float *P, const float *Q, const int32_t *nbr, const int32_t *cnt,

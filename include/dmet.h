@@ -177,6 +177,14 @@ int dmet_bn_node_linear_split_f32(const float *raw, const float *residual, const
 int dmet_gather_max_lds_sliced_f32(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr_local,
                                    const int64_t *ptr, int B, int64_t N, int k, int H, float *out, uint8_t *arg,
                                    dmet_stream_t stream);
+/* Same with a HINT on the batch's largest event (max_nodes; 0 = unknown = the entry above).  The kernel above is one
+ * workgroup per CU whatever the event size -- by its 160 KB image and by its registers -- so its staging phase overlaps with
+ * nothing.  For batches whose largest event fits 2 559 rows -- what model/data_loader.py:67-90 yields on real data -- and
+ * uint16 ids given, workgroups of 512 threads on 80 KB images run two to a CU (one stages while the other gathers).  An
+ * event beyond the hint takes the in-kernel L2 path: slower, never wrong.  Same bits. */
+int dmet_gather_max_lds_sliced_cap_f32(const float *P, const float *Q, const int32_t *nbr, const uint16_t *nbr_local,
+                                       const int64_t *ptr, int B, int64_t N, int k, int H, float *out, uint8_t *arg,
+                                       int64_t max_nodes, dmet_stream_t stream);
 /* Same contract with a per-node slot count: only the first cnt[i] slots of row i are examined (radius tables are
  * max_num_neighbors wide but a few dozen deep).  cnt may be NULL (= k for every node). */
 int dmet_gather_max_counted_f32(const float *P, const float *Q, const int32_t *nbr, const int32_t *cnt, int64_t N,

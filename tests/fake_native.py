@@ -67,7 +67,7 @@ def node_linear_split(x, W, b, sliced=False):   # the stand-in keeps row-major t
     return P.detach(), (x @ W[:, H:].t()).detach()
 
 
-def gather_max(P, Q, nbr, ptr, want_arg, cnt=None, lds=False, nbr_local=None, sliced=False, mixed=False):
+def gather_max(P, Q, nbr, ptr, want_arg, cnt=None, lds=False, nbr_local=None, sliced=False, mixed=False, max_nodes=None):
     if nbr_local is not None:
         # the local table must describe the same graph (this is what the uint16 kernel would gather)
         counts = (ptr[1:] - ptr[:-1]).long()

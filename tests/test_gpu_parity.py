@@ -1745,3 +1745,26 @@ def test_deferral_is_not_dropped_by_a_second_begin(dev):
     torch.cuda.synchronize()
     for u, v in zip(want, got):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("k", [16, 20])
+def test_gather_half_form_for_small_event_batches(dev, k):
+    """K3: with the batch's largest event known to fit 2 559 rows the LDS gather runs 512-thread workgroups on 80 KB images,
+    two to a CU (dmet_gather_max_lds_sliced_cap_f32) -- same (out, arg) bits as the full form; an event BEYOND the hint takes
+    the in-kernel L2 path and still comes out right."""
+    from deepmetv2_amd import _native
+    sizes = [2000, 1, 2559, 700, 33, 1800]
+    x, _b, ptr = _ragged(sizes, 32, seed=61)
+    xd, pd = x.to(dev), ptr.to(dev)
+    g = torch.Generator().manual_seed(3)
+    W = (torch.randn(32, 64, generator=g) / 8).to(dev)
+    b = torch.randn(32, generator=g).to(dev)
+    nbr, _d, loc = _native.knn_local(xd, pd, k)
+    P, Q = _native.node_linear_split(xd, W, b, sliced=True)
+    for want_arg in (True, False):
+        full = _native.gather_max(P, Q, nbr, pd, want_arg, lds=True, nbr_local=loc, sliced=True)
+        half = _native.gather_max(P, Q, nbr, pd, want_arg, lds=True, nbr_local=loc, sliced=True, max_nodes=max(sizes))
+        lied = _native.gather_max(P, Q, nbr, pd, want_arg, lds=True, nbr_local=loc, sliced=True, max_nodes=1000)
+        for other in (half, lied):
+            assert torch.equal(full[0], other[0])
+            assert (full[1] is None) == (other[1] is None) and (full[1] is None or torch.equal(full[1], other[1]))

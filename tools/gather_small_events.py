@@ -22,4 +22,5 @@ for label, sizes in (("128 x 1000", [1000] * 128), ("128 x 2000", [2000] * 128),
     P, Q = _native.node_linear_split(x, W, b, sliced=True); Pr, Qr = _native.node_linear_split(x, W, b, sliced=False)
     t_l2 = med(lambda: _native.gather_max(Pr, Qr, nbr, ptr, want_arg=True, lds=False))
     t_full = med(lambda: _native.gather_max(P, Q, nbr, ptr, want_arg=True, lds=True, nbr_local=loc, sliced=True))
-    print(f"{label:22s} N={N:7d}  L2 form {t_l2:6.1f}   LDS form (160 KB image) {t_full:6.1f}", flush=True)
+    t_half = med(lambda: _native.gather_max(P, Q, nbr, ptr, want_arg=True, lds=True, nbr_local=loc, sliced=True, max_nodes=max(sizes)))
+    print(f"{label:22s} N={N:7d}  L2 form {t_l2:6.1f}   LDS form (160 KB image, 1024 threads) {t_full:6.1f}   half form (80 KB, 512 threads) {t_half:6.1f}", flush=True)

@@ -9,7 +9,7 @@ DEFAULT_TOGGLES="DMET_NONE=1 DMET_GATHER_MAX_FORM=l2-only DMET_EDGECONV_FORM=fus
 DMET_RADIUS_J16=0 DMET_KNN_FILTER=1 DMET_KNN_PATH=exact DMET_FUSED_ENCODER=0 DMET_GATHER_BWD=reverse \
 DMET_PQ_SLICED=0 DMET_GATHER_BALANCED=0 DMET_GATHER_BALANCED=1 DMET_GATHER_MIXED=1 \
 DMET_KNN_RIDER=0 DMET_ENCODER_FWD=valu DMET_ENCODER_BWD=valu DMET_HEAD_FWD=valu DMET_HEAD_BWD=valu DMET_BN_KNN_FUSE=0 DMET_BN_HEAD_FUSE=0 DMET_ENC_BN_FUSE=0 DMET_BN_NLS_FUSE=0 \
-DMET_DEFER_FINALIZE=0 DMET_GQ_SLICED=0 DMET_KNN_EMIT=lanes DMET_RADIUS_INT32=full"
+DMET_DEFER_FINALIZE=0 DMET_GQ_SLICED=0 DMET_KNN_EMIT=lanes DMET_RADIUS_INT32=full DMET_GATHER_HALF_IMAGE=0"
 # ONLY_TOGGLES="A=1 B=0": just these;  EXTRA_TOGGLES: appended to the default list
 for t in ${ONLY_TOGGLES:-$DEFAULT_TOGGLES $EXTRA_TOGGLES}; do
   n=$(echo $t | tr "=" "_")
