@@ -1752,6 +1752,7 @@ def test_gather_half_form_for_small_event_batches(dev, k):
     """K3: with the batch's largest event known to fit 2 559 rows the LDS gather runs 512-thread workgroups on 80 KB images,
     two to a CU (dmet_gather_max_lds_sliced_cap_f32) -- same (out, arg) bits as the full form; an event BEYOND the hint takes
     the in-kernel L2 path and still comes out right."""
+    _default_path_only("DMET_GATHER_MAX_FORM", "l2-only", "the test calls the LDS-resident kernels on slice-major tables directly")
     from deepmetv2_amd import _native
     sizes = [2000, 1, 2559, 700, 33, 1800]
     x, _b, ptr = _ragged(sizes, 32, seed=61)
