@@ -1725,6 +1725,7 @@ def test_radius_table_without_int32_rows(dev):
 def test_deferral_is_not_dropped_by_a_second_begin(dev):
     """K5: beginning a deferral while sums of an earlier one are queued would leave those gradients unwritten for good --
     the C entry refuses, the Python wrapper forms the open deferral's sums first."""
+    _default_path_only("DMET_DEFER_FINALIZE", "0", "the deferral is switched off: there is nothing to queue")
     from deepmetv2_amd import _lib, _native
     L = _lib.load()
     N = 700
